@@ -1,0 +1,166 @@
+/*
+ * pnp_hip.h — C-ABI of libpnp_hip.so: the MI355X (gfx950) kernels behind the PnP-AdaNet
+ * training hot path (dilated-residual segmenter fwd/bwd + Wasserstein critics).
+ *
+ * The reference (carrenD/Medical-Cross-Modality-Domain-Adaptation) has NO FFI of its own: every op is
+ * a TensorFlow-1.4 graph op created in layers.py / ops.py / source_segmenter.py / adversarial.py.
+ * Each entry point below therefore names the reference call site whose TF op it replaces
+ * (file:line into /root/reference).  The Python host side binds these with ctypes
+ * (see INTEGRATION.md); nothing in the signatures is a torch type.
+ *
+ * Conventions
+ *   - tensors: dense float32, activations NHWC, filters HWIO (exactly the reference layout)
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated inside;
+ *     scratch comes from a caller-provided workspace (size from pnp_*_workspace_bytes)
+ *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous w.r.t. the host
+ *   - return 0 on success, <0 on error (PNP_E*), message via pnp_last_error(); never throws
+ */
+#ifndef PNP_HIP_H
+#define PNP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNP_OK 0
+#define PNP_EINVAL (-1)   /* bad argument / unsupported geometry */
+#define PNP_ELAUNCH (-2)  /* hip launch error */
+#define PNP_EWORKSPACE (-3) /* workspace too small */
+
+#define PNP_PAD_ZERO 0      /* tf.nn.conv2d(padding='SAME') zero padding, layers.py:18,67 */
+#define PNP_PAD_SYMMETRIC 1 /* tf.pad(x, k//2, 'SYMMETRIC') + VALID conv, layers.py:19-24,68-73 */
+
+int pnp_abi_version(void);
+const char* pnp_last_error(void);
+/* cu_count, max clock (kHz), LDS bytes per CU, gcn arch name (<=63 chars) of `device` */
+int pnp_device_info(int device, int* cu_count, int* clock_khz, int* lds_bytes, char* arch, int arch_len);
+
+/* Geometry shared by the three conv entry points (all describe the FORWARD convolution):
+ *   x [N,H,W,C]  w [R,S,C,K]  y [N,OH,OW,K]
+ *   y[n,oh,ow,k] = sum_{r,s,c} xpad[n, oh*stride - pad_t + r*dil, ow*stride - pad_l + s*dil, c] * w[r,s,c,k]
+ *   pad_mode PNP_PAD_ZERO: out-of-range taps read 0 (TF SAME; pad_t/pad_l = the TF "pad before" amounts)
+ *   pad_mode PNP_PAD_SYMMETRIC: out-of-range taps mirror including the edge (tf.pad SYMMETRIC), pad_t=pad_l=k//2
+ * Dropout (tf.nn.dropout, layers.py:25,74,93) is fused in the forward epilogue:
+ *   y *= mask(seed, stream_id, flat_index) / keep_prob    (keep_prob >= 1 disables it)
+ * mask is the Philox4x32-10 stream documented in pnp_dropout (below). */
+typedef struct pnp_conv_geom {
+    int32_t N, H, W, C;     /* input */
+    int32_t K, R, S;        /* filter count and size */
+    int32_t OH, OW;         /* output spatial size */
+    int32_t stride, dil;    /* same in both spatial dims (reference only uses square) */
+    int32_t pad_t, pad_l;   /* pad before (top / left) */
+    int32_t pad_mode;       /* PNP_PAD_* */
+} pnp_conv_geom;
+
+/* replaces tf.nn.conv2d (layers.py:18,24,67,73) and tf.nn.atrous_conv2d (layers.py:86,92) + tf.nn.dropout */
+int pnp_conv2d_fwd(const float* x, const float* w, float* y, const pnp_conv_geom* g,
+                   float keep_prob, uint64_t seed, uint32_t stream_id, void* stream);
+
+/* gradient w.r.t. the conv input (TF autodiff of the ops above; Conv2DBackpropInput).
+ * dy is the gradient w.r.t. the conv accumulator (i.e. AFTER the dropout mask has been applied by the caller).
+ * workspace: pnp_conv2d_dgrad_workspace_bytes(g). */
+size_t pnp_conv2d_dgrad_workspace_bytes(const pnp_conv_geom* g);
+int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_geom* g,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* gradient w.r.t. the filter (Conv2DBackpropFilter). dw [R,S,C,K] is overwritten. */
+size_t pnp_conv2d_wgrad_workspace_bytes(const pnp_conv_geom* g);
+int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_geom* g,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Naive one-thread-per-output direct convolution (fp32 fmaf chain in r,s,c order). On-device
+ * cross-check for the MFMA kernels at sizes the CPU oracle cannot reach; not used by the product path. */
+int pnp_conv2d_fwd_naive(const float* x, const float* w, float* y, const pnp_conv_geom* g, void* stream);
+
+/* tf.nn.dropout (layers.py:25,74,93): y = x * floor(keep + u) / keep with u = Philox4x32-10(key=(seed_lo,seed_hi),
+ * counter=(flat_index/4, stream_id, 0, 0))[flat_index%4] * 2^-32.  Used for the backward of the fused epilogue. */
+int pnp_dropout(const float* x, float* y, size_t n, float keep_prob, uint64_t seed, uint32_t stream_id, void* stream);
+
+/* tf.contrib.layers.batch_norm(decay=.9, eps=1e-3, updates_collections=None) (layers.py:95-100), fused batch-norm semantics.
+ * x,y: [P,C] (P = N*H*W).  stats: mean[C], var[C] (biased).  ws: pnp_bn_workspace_bytes(P,C). */
+size_t pnp_bn_workspace_bytes(int64_t P, int32_t C);
+int pnp_bn_stats(const float* x, float* mean, float* var, int64_t P, int32_t C,
+                 void* workspace, size_t workspace_bytes, void* stream);
+/* moving_mean -= (1-decay)*(moving_mean-mean); moving_var likewise with var*P/(P-1) (Bessel) */
+int pnp_bn_update_moving(float* moving_mean, float* moving_var, const float* mean, const float* var,
+                         int64_t P, int32_t C, float decay, void* stream);
+/* y = act( gamma*(x-mean)*rsqrt(var+eps) + beta + shortcut_padded ), act = leaky-ReLU(alpha) if alpha>=0 else identity.
+ * shortcut (optional, may be NULL) has Cs channels, zero-padded (C-Cs)/2 on each side of the channel axis
+ * (layers.py:159-165 residual_block: tf.pad(x,[..,[C/2,C/2]]) + add + leaky_relu). */
+int pnp_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                 const float* shortcut, int32_t Cs, float* y, int64_t P, int32_t C, float eps, float alpha,
+                 void* stream);
+/* backward of pnp_bn_apply.  dz = dout * (out>0 ? 1 : alpha).  dbeta = sum dz, dgamma = sum dz*xhat.
+ * training=1 : dx = gamma*rstd*(dz - dbeta/P - xhat*dgamma/P);  training=0 (frozen stats): dx = gamma*rstd*dz
+ * dx is then multiplied by the dropout mask of the producing conv when keep_prob<1 (layers.py:25: conv->dropout->BN).
+ * dshortcut (optional) receives dz restricted to the Cs un-padded channels. */
+int pnp_bn_bwd(const float* dout, const float* out, const float* x, const float* mean, const float* var,
+               const float* gamma, float* dx, float* dgamma, float* dbeta, float* dshortcut, int32_t Cs,
+               int64_t P, int32_t C, float eps, float alpha, int32_t training,
+               float keep_prob, uint64_t seed, uint32_t stream_id,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* relu/leaky-relu of (a + shortcut) with no BN (not on the reference path; kept for the dead helpers) — omitted. */
+
+/* tf.nn.max_pool(ksize 2, stride 2, SAME) (layers.py:102-103); H,W even. */
+int pnp_maxpool2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int pnp_maxpool2_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ops.PS (ops.py:3-27) closed form: out[n, i*r+u, j*r+v, c] = x[n, i, j, c*r*r + v*r + u];  x [N,A,B,nc*r*r] */
+int pnp_ps_fwd(const float* x, float* y, int32_t N, int32_t A, int32_t B, int32_t r, int32_t nc, void* stream);
+int pnp_ps_bwd(const float* dy, float* dx, int32_t N, int32_t A, int32_t B, int32_t r, int32_t nc, void* stream);
+
+/* backward of tf.pad(x, p, 'SYMMETRIC') in H and W: dx[N,H,W,C] from dxp[N,H+2p,W+2p,C] */
+int pnp_sympad_bwd(const float* dxp, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t p, void* stream);
+
+/* Segmentation loss of source_segmenter.py:211-273 (weighted cross-entropy + soft Dice), 5..8 classes.
+ * logits, y (one-hot float, lib._label_decomp) : [P, ncls].
+ * out[0]=miu_cross*xent + miu_dice*dice, out[1]=xent, out[2]=dice ; dlogits = d out[0] / d logits * gscale.
+ * ws: pnp_seg_loss_workspace_bytes(P, ncls).  The per-class sums land in ws and are reused by the bwd call. */
+size_t pnp_seg_loss_workspace_bytes(int64_t P, int32_t ncls);
+int pnp_seg_loss_fwd(const float* logits, const float* y, float* out, int64_t P, int32_t ncls,
+                     float miu_cross, float miu_dice, void* workspace, size_t workspace_bytes, void* stream);
+int pnp_seg_loss_bwd(const float* logits, const float* y, float* dlogits, int64_t P, int32_t ncls,
+                     float miu_cross, float miu_dice, float gscale,
+                     const void* workspace, size_t workspace_bytes, void* stream);
+/* pixel_wise_softmax_2 + tf.argmax (layers.py:134-138, source_segmenter.py:80-81): exp(z)/sum exp(z), lowest index on ties */
+int pnp_softmax_argmax(const float* logits, float* prob /*nullable*/, int64_t* label, int64_t P, int32_t ncls, void* stream);
+/* lib._dice_eval (lib.py:96-110): out[0]=mean dice, out[1..ncls]=per class; label = argmax map, y one-hot */
+int pnp_dice_eval(const int64_t* label, const float* y, float* out, int64_t P, int32_t ncls,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Optimisers over ONE flat fp32 arena.  The arena is cut in chunks of PNP_OPT_CHUNK elements; chunk_l2[c] is the
+ * L2 coefficient (reg_coeff * multiplicity, source_segmenter.py:132-135,237) applied to that chunk: g += l2 * w.
+ * chunk_mask[c]==0 skips the chunk (frozen variables).  Either table may be NULL. */
+#define PNP_OPT_CHUNK 1024
+/* tf.train.AdamOptimizer (source_segmenter.py:378): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); w -= lr_t*m/(sqrt(v)+eps) */
+int pnp_adam_step(float* w, const float* g, float* m, float* v, size_t n, const float* chunk_l2,
+                  const uint8_t* chunk_mask, float lr, float beta1, float beta2, float eps, int32_t t, void* stream);
+/* tf.train.RMSPropOptimizer(decay .9, momentum 0, eps 1e-10) (adversarial.py:643-652): ms=.9ms+.1g^2; w-=lr*g/sqrt(ms+eps) */
+int pnp_rmsprop_step(float* w, const float* g, float* ms, size_t n, const float* chunk_l2, const uint8_t* chunk_mask,
+                     float lr, float decay, float eps, void* stream);
+/* tf.train.MomentumOptimizer (source_segmenter.py:370): acc = mom*acc + g ; w -= lr*acc */
+int pnp_momentum_step(float* w, const float* g, float* acc, size_t n, const float* chunk_l2, const uint8_t* chunk_mask,
+                      float lr, float momentum, void* stream);
+/* tf.clip_by_value weight clipping (adversarial.py:654), chunk_mask selects the clipped chunks */
+int pnp_clip(float* w, size_t n, const uint8_t* chunk_mask, float lo, float hi, void* stream);
+/* sum over chunks of chunk_l2[c] * sum(w^2)/2  (tf.nn.l2_loss, source_segmenter.py:237) -> out[0] */
+int pnp_l2_loss(const float* w, size_t n, const float* chunk_l2, float* out, void* workspace, size_t workspace_bytes, void* stream);
+size_t pnp_reduce_workspace_bytes(size_t n);
+
+/* Critic input assembly (adversarial.py:325-335): concat on C of [tile(a,3) | b | c | d | logits | float(argmax logits)] */
+int pnp_critic_input_fwd(const float* a, int32_t Ca, int32_t tile_a, const float* b, int32_t Cb, const float* c, int32_t Cc,
+                         const float* d, int32_t Cd, const float* logits, int32_t ncls, float* out, int64_t P, void* stream);
+int pnp_critic_input_bwd(const float* dout, float* da, int32_t Ca, int32_t tile_a, float* db, int32_t Cb, float* dc, int32_t Cc,
+                         float* dd, int32_t Cd, float* dlogits, int32_t ncls, int64_t P, void* stream);
+
+/* y = a*x + b*y elementwise (gradient fan-in adds) */
+int pnp_axpby(const float* x, float* y, size_t n, float a, float b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNP_HIP_H */

@@ -1,0 +1,107 @@
+"""ctypes binding of libpnp_hip.so (C-ABI declared in include/pnp_hip.h).
+
+This is the ONLY route from the Python host code to the GPU arithmetic.  There is no CPU or
+PyTorch fallback: if the shared library is missing or a call fails, we raise.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpnp_hip.so")
+
+PAD_ZERO = 0
+PAD_SYMMETRIC = 1
+OPT_CHUNK = 1024
+
+
+class ConvGeom(ctypes.Structure):
+    """mirror of `pnp_conv_geom` (include/pnp_hip.h)"""
+    _fields_ = [(n, c_int32) for n in
+                ("N", "H", "W", "C", "K", "R", "S", "OH", "OW", "stride", "dil", "pad_t", "pad_l", "pad_mode")]
+
+    def key(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+class PnpError(RuntimeError):
+    pass
+
+
+_F = c_void_p  # device float* (passed as integer address)
+_G = POINTER(ConvGeom)
+
+# name -> (restype, argtypes); every symbol of include/pnp_hip.h must appear here (tests check it)
+PROTOTYPES = {
+    "pnp_abi_version": (c_int, []),
+    "pnp_last_error": (c_char_p, []),
+    "pnp_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "pnp_conv2d_fwd": (c_int, [_F, _F, _F, _G, c_float, c_uint64, c_uint32, c_void_p]),
+    "pnp_conv2d_dgrad_workspace_bytes": (c_size_t, [_G]),
+    "pnp_conv2d_dgrad": (c_int, [_F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
+    "pnp_conv2d_wgrad_workspace_bytes": (c_size_t, [_G]),
+    "pnp_conv2d_wgrad": (c_int, [_F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
+    "pnp_conv2d_fwd_naive": (c_int, [_F, _F, _F, _G, c_void_p]),
+    "pnp_dropout": (c_int, [_F, _F, c_size_t, c_float, c_uint64, c_uint32, c_void_p]),
+    "pnp_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "pnp_bn_stats": (c_int, [_F, _F, _F, c_int64, c_int32, c_void_p, c_size_t, c_void_p]),
+    "pnp_bn_update_moving": (c_int, [_F, _F, _F, _F, c_int64, c_int32, c_float, c_void_p]),
+    "pnp_bn_apply": (c_int, [_F, _F, _F, _F, _F, _F, c_int32, _F, c_int64, c_int32, c_float, c_float, c_void_p]),
+    "pnp_bn_bwd": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int32, c_float, c_float, c_int32,
+                           c_float, c_uint64, c_uint32, c_void_p, c_size_t, c_void_p]),
+    "pnp_maxpool2_fwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "pnp_maxpool2_bwd": (c_int, [_F, _F, _F, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "pnp_ps_fwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "pnp_ps_bwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "pnp_sympad_bwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "pnp_seg_loss_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "pnp_seg_loss_fwd": (c_int, [_F, _F, _F, c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    "pnp_seg_loss_bwd": (c_int, [_F, _F, _F, c_int64, c_int32, c_float, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    "pnp_softmax_argmax": (c_int, [_F, _F, c_void_p, c_int64, c_int32, c_void_p]),
+    "pnp_dice_eval": (c_int, [c_void_p, _F, _F, c_int64, c_int32, c_void_p, c_size_t, c_void_p]),
+    "pnp_adam_step": (c_int, [_F, _F, _F, _F, c_size_t, _F, c_void_p, c_float, c_float, c_float, c_float, c_int32, c_void_p]),
+    "pnp_rmsprop_step": (c_int, [_F, _F, _F, c_size_t, _F, c_void_p, c_float, c_float, c_float, c_void_p]),
+    "pnp_momentum_step": (c_int, [_F, _F, _F, c_size_t, _F, c_void_p, c_float, c_float, c_void_p]),
+    "pnp_clip": (c_int, [_F, c_size_t, c_void_p, c_float, c_float, c_void_p]),
+    "pnp_l2_loss": (c_int, [_F, c_size_t, _F, _F, c_void_p, c_size_t, c_void_p]),
+    "pnp_reduce_workspace_bytes": (c_size_t, [c_size_t]),
+    "pnp_critic_input_fwd": (c_int, [_F, c_int32, c_int32, _F, c_int32, _F, c_int32, _F, c_int32, _F, c_int32, _F, c_int64, c_void_p]),
+    "pnp_critic_input_bwd": (c_int, [_F, _F, c_int32, c_int32, _F, c_int32, _F, c_int32, _F, c_int32, _F, c_int32, c_int64, c_void_p]),
+    "pnp_axpby": (c_int, [_F, _F, c_size_t, c_float, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpnp_hip.so (once).  Raises PnpError if it has not been built — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PnpError(
+            "libpnp_hip.so not found at %s — build it with `python __graft_entry__.py` "
+            "(or `make -C %s/csrc`). There is no CPU fallback." % (LIB_PATH, _HERE))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError here == ABI drift; let it propagate loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pnp_abi_version() != 1:
+        raise PnpError("libpnp_hip.so ABI version %d != 1" % lib.pnp_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().pnp_last_error()
+        raise PnpError("%s failed (%d): %s" % (what, code, msg.decode() if msg else "?"))
+
+
+def device_info(device=0):
+    lib = load()
+    cu, clk, lds = c_int(), c_int(), c_int()
+    arch = ctypes.create_string_buffer(64)
+    check(lib.pnp_device_info(device, ctypes.byref(cu), ctypes.byref(clk), ctypes.byref(lds), arch, 64), "pnp_device_info")
+    return {"cu_count": cu.value, "clock_khz": clk.value, "lds_bytes_per_cu": lds.value, "arch": arch.value.decode()}

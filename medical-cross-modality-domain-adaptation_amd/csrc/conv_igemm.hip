@@ -1,0 +1,741 @@
+// conv_igemm.hip — NHWC x HWIO implicit-GEMM convolution on gfx950 fp32 matrix cores.
+//
+// Replaces tf.nn.conv2d / tf.nn.atrous_conv2d (+ tf.pad SYMMETRIC, + tf.nn.dropout) at
+// /root/reference/layers.py:18,24,67,73,86,92 and their TF-autodiff gradients.
+//
+// GEMM view (no im2col buffer is ever materialised):
+//   fwd  : Y[M=N*OH*OW][K]   = A[M][R*S*C] * Wm[R*S*C][K]       A gathered from x on the fly
+//   dgrad: the same kernel on dy with flipped/transposed filters (and zero-upsampled dy for stride>1)
+//   wgrad: dW[R*S*C][K]      = At[R*S*C][P=N*OH*OW] * dY[P][K]  split over P across workgroups
+//
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD = the 157 TF fp32 peak).
+// Workgroup = 4 waves (256 threads); BK = 32 reduction elements per LDS stage; LDS double-buffered,
+// next stage prefetched into registers while the current one feeds the MFMAs (1 barrier / stage).
+//
+// LDS layouts (dwords):
+//   fwd  A tile  [BM][36]     row = output pixel, 32 k's contiguous (+4 pad). A fragments are read with
+//                             ONE ds_read_b128 per 4 MFMAs: lane l takes k = 8q+4*(l>>5)+{0..3}; MFMA j of the
+//                             group then contracts k-pair {8q+j, 8q+4+j} (a k-permutation, legal because the
+//                             B fragment uses the same pairing).  Stride 36 dwords => 16-B slot = 9*row mod 16,
+//                             a bijection over each b128 lane group => conflict-free.
+//   B tile       [32][BN+4]   row = k, n contiguous; fragment = ds_read_b32, lanes 0-31 consecutive => conflict-free.
+//   wgrad A tile [32][BM+4]   row = pixel (reduction index), m' contiguous; ds_read_b32 like B.
+#include "pnp_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    float* y;
+    int N, H, W, C, K, R, S, OH, OW, stride, dil, pad_t, pad_l, pad_mode;
+    int ups;    // zero-upsampling factor of the input (dgrad of a strided conv); 1 otherwise
+    int M;      // N*OH*OW
+    int Kred;   // R*S*C
+    int OHW;    // OH*OW
+    int nblk_m, nblk_n;
+    int nsplit, chunks_per_split;   // wgrad only
+    long long split_stride;          // wgrad only: elements between split partials
+    uint32_t drop_thresh, drop_key;
+    float drop_scale;
+    int do_drop;
+    int xcd_swizzle;
+};
+
+// virtual coordinate -> real coordinate; returns false when the tap reads zero
+__device__ __forceinline__ bool map_coord(int v, int H, int ups, int mode, int& i) {
+    if (mode == PNP_PAD_SYMMETRIC) {
+        if (v < 0) v = -1 - v;
+        else if (v >= H) v = 2 * H - 1 - v;
+        i = v;
+        return (unsigned)v < (unsigned)H;
+    }
+    if (ups == 1) {
+        i = v;
+        return (unsigned)v < (unsigned)H;
+    }
+    if (v < 0) return false;
+    int q = v / ups;
+    i = q;
+    return (q * ups == v) && (q < H);
+}
+
+// bijective XCD-aware remap: consecutive tiles (which share the A rows / filter panel) land on one XCD's L2
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int NX = 8;
+    int q = nblk / NX, r = nblk % NX;
+    int xcd = bid % NX, idx = bid / NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <int TM, int TN>
+struct Acc {
+    f32x16 v[TM][TN];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[i][j][e] = 0.f;
+    }
+};
+
+// ---- B tile (weights for fwd, dy for wgrad): row-major [rows][ncols] global matrix ------------
+template <int BN>
+struct BLoader {
+    static constexpr int C4 = BN / 4;             // float4 columns per row
+    static constexpr int RP = NTHREADS / C4;      // rows per pass
+    static constexpr int NP = BK / RP;            // passes
+    static constexpr int LD = BN + 4;
+    f32x4 reg[NP];
+    int bcol, brow;
+    __device__ __forceinline__ void init(int t) {
+        bcol = t % C4;
+        brow = t / C4;
+    }
+    // rows [k0, k0+32) of a [nrows][ncols] matrix, columns [n0, n0+BN)
+    __device__ __forceinline__ void load(const float* __restrict__ b, int k0, int nrows, int ncols, int n0) {
+        const int n = n0 + 4 * bcol;
+        const bool vec = (ncols & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int k = k0 + brow + RP * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < nrows) {
+                const float* p = b + (size_t)k * ncols + n;
+                if (vec) {
+                    if (n < ncols) v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < ncols) v[e] = p[e];
+                }
+            }
+            reg[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* lds) const {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            *reinterpret_cast<f32x4*>(lds + (brow + RP * i) * LD + 4 * bcol) = reg[i];
+    }
+};
+
+// ---- fwd A tile: [BM pixels][32 k] gathered from x ---------------------------------------------
+// MODE 0: C % 32 == 0 (whole stage shares one filter tap), 1: C % 4 == 0, 2: any C (scalar)
+template <int BM, int MODE>
+struct FwdALoader {
+    static constexpr int NR = BM / 32;   // rows per thread
+    static constexpr int LD = BK + 4;
+    f32x4 reg[NR];
+    int kg, mrow;
+    int pixbase[NR], vh0[NR], vw0[NR];
+    unsigned valid;
+    __device__ __forceinline__ void init(int t, int m0, const ConvArgs& a) {
+        kg = t & 7;
+        mrow = t >> 3;
+        valid = 0;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            int m = m0 + mrow + 32 * i;
+            bool ok = m < a.M;
+            if (!ok) m = 0;
+            int n = m / a.OHW;
+            int rem = m - n * a.OHW;
+            int oh = rem / a.OW;
+            int ow = rem - oh * a.OW;
+            pixbase[i] = n * a.H * a.W;
+            vh0[i] = oh * a.stride - a.pad_t;
+            vw0[i] = ow * a.stride - a.pad_l;
+            if (ok) valid |= 1u << i;
+        }
+    }
+    __device__ __forceinline__ f32x4 gather4(const ConvArgs& a, int i, int rs, int c) const {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int r = rs / a.S;
+        int s = rs - r * a.S;
+        int ih = 0, iw = 0;
+        bool ok = (valid >> i) & 1u;
+        ok = ok && map_coord(vh0[i] + r * a.dil, a.H, a.ups, a.pad_mode, ih);
+        ok = ok && map_coord(vw0[i] + s * a.dil, a.W, a.ups, a.pad_mode, iw);
+        if (ok) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(pixbase[i] + ih * a.W + iw) * a.C + c));
+        return v;
+    }
+    __device__ __forceinline__ float gather1(const ConvArgs& a, int i, int kf) const {
+        if (kf >= a.Kred) return 0.f;
+        int rs = kf / a.C;
+        int c = kf - rs * a.C;
+        int r = rs / a.S;
+        int s = rs - r * a.S;
+        int ih = 0, iw = 0;
+        bool ok = (valid >> i) & 1u;
+        ok = ok && map_coord(vh0[i] + r * a.dil, a.H, a.ups, a.pad_mode, ih);
+        ok = ok && map_coord(vw0[i] + s * a.dil, a.W, a.ups, a.pad_mode, iw);
+        return ok ? a.x[(size_t)(pixbase[i] + ih * a.W + iw) * a.C + c] : 0.f;
+    }
+    __device__ __forceinline__ void load(const ConvArgs& a, int k0) {
+        if constexpr (MODE == 0) {
+            int rs = k0 / a.C;                 // block-uniform
+            int c = k0 - rs * a.C + 4 * kg;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) reg[i] = gather4(a, i, rs, c);
+        } else if constexpr (MODE == 1) {
+            int kf = k0 + 4 * kg;
+            int rs = kf / a.C;
+            int c = kf - rs * a.C;
+            bool kok = kf < a.Kred;            // C%4==0 => Kred%4==0 => whole float4 in range
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                reg[i] = kok ? gather4(a, i, rs, c) : z;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gather1(a, i, k0 + 4 * kg + e);
+                reg[i] = v;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* lds) const {
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            *reinterpret_cast<f32x4*>(lds + (mrow + 32 * i) * LD + 4 * kg) = reg[i];
+    }
+};
+
+// ---- wgrad A tile: [32 pixels][BM m'] gathered from x, m' = (r*S+s)*C + c ----------------------
+// MODE 0: C % BM == 0 (block-uniform tap), 1: C % 4 == 0, 2: any C
+template <int BM, int MODE>
+struct WgradALoader {
+    static constexpr int C4 = BM / 4;
+    static constexpr int RP = NTHREADS / C4;
+    static constexpr int NP = BK / RP;
+    static constexpr int LD = BM + 4;
+    f32x4 reg[NP];
+    int acol, arow;
+    int rs_u, c_u;          // MODE 0/1: this thread's tap and channel (fixed for the whole kernel)
+    bool mok;               // MODE 1: m' in range
+    int mm;                 // first m' of this thread
+    __device__ __forceinline__ void init(int t, int mm0, const ConvArgs& a) {
+        acol = t % C4;
+        arow = t / C4;
+        mm = mm0 + 4 * acol;
+        mok = mm < a.Kred;
+        int m_ = mok ? mm : 0;
+        rs_u = m_ / a.C;
+        c_u = m_ - rs_u * a.C;
+    }
+    __device__ __forceinline__ bool pixel(const ConvArgs& a, int p, int rs, int& off) const {
+        int n = p / a.OHW;
+        int rem = p - n * a.OHW;
+        int oh = rem / a.OW;
+        int ow = rem - oh * a.OW;
+        int r = rs / a.S;
+        int s = rs - r * a.S;
+        int ih = 0, iw = 0;
+        bool ok = map_coord(oh * a.stride - a.pad_t + r * a.dil, a.H, 1, a.pad_mode, ih);
+        ok = ok && map_coord(ow * a.stride - a.pad_l + s * a.dil, a.W, 1, a.pad_mode, iw);
+        off = (n * a.H + ih) * a.W + iw;
+        return ok;
+    }
+    __device__ __forceinline__ void load(const ConvArgs& a, int p0, int pend) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int p = p0 + arow + RP * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < pend) {
+                if constexpr (MODE <= 1) {
+                    int off;
+                    if (mok && pixel(a, p, rs_u, off))
+                        v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)off * a.C + c_u));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int m_ = mm + e;
+                        if (m_ < a.Kred) {
+                            int rs = m_ / a.C;
+                            int c = m_ - rs * a.C;
+                            int off;
+                            if (pixel(a, p, rs, off)) v[e] = a.x[(size_t)off * a.C + c];
+                        }
+                    }
+                }
+            }
+            reg[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* lds) const {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            *reinterpret_cast<f32x4*>(lds + (arow + RP * i) * LD + 4 * acol) = reg[i];
+    }
+};
+
+// ---- MFMA stage: 32 k's of A(LDS) x B(LDS) into the wave's TM x TN accumulators ----------------
+// A_MMAJOR: A tile is [m][36] (fwd) else [k][LDA] (wgrad)
+template <int TM, int TN, bool A_MMAJOR, int LDA, int LDB>
+__device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const float* __restrict__ Bs,
+                                           int wm0, int wn0, int lane, Acc<TM, TN>& acc) {
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int kq = 0; kq < BK / 8; ++kq) {
+        const int kb = kq * 8 + 4 * h;
+        f32x4 a[TM];
+        if constexpr (A_MMAJOR) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                a[tm] = *reinterpret_cast<const f32x4*>(As + (wm0 + tm * 32 + l31) * LDA + kb);
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[tm][j] = As[(kb + j) * LDA + wm0 + tm * 32 + l31];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float b[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[(kb + j) * LDB + wn0 + tn * 32 + l31];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn], acc.v[tm][tn], 0, 0, 0);
+        }
+    }
+}
+
+// ================================ forward / dgrad kernel ========================================
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int LDA = BK + 4, LDB = BN + 4;
+    constexpr int ASZ = BM * LDA, BSZ = BK * LDB;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int bid = blockIdx.x;
+    const int nblk = a.nblk_m * a.nblk_n;
+    if (a.xcd_swizzle) bid = xcd_remap(bid, nblk);
+    const int mt = bid / a.nblk_n, nt = bid - mt * a.nblk_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+    FwdALoader<BM, MODE> la;
+    BLoader<BN> lb;
+    la.init(t, m0, a);
+    lb.init(t);
+
+    Acc<TM, TN> acc;
+    acc.zero();
+
+    const int nchunks = (a.Kred + BK - 1) / BK;
+    la.load(a, 0);
+    lb.load(a.w, 0, a.Kred, a.K, n0);
+    la.store(lds);
+    lb.store(lds + 2 * ASZ);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        const bool more = (c + 1) < nchunks;
+        if (more) {
+            la.load(a, (c + 1) * BK);
+            lb.load(a.w, (c + 1) * BK, a.Kred, a.K, n0);
+        }
+        mfma_stage<TM, TN, true, LDA, LDB>(lds + cur * ASZ, lds + 2 * ASZ + cur * BSZ, wm0, wn0, lane, acc);
+        if (more) {
+            la.store(lds + (cur ^ 1) * ASZ);
+            lb.store(lds + 2 * ASZ + (cur ^ 1) * BSZ);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn0 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < a.M && n < a.K) {
+                    float v = acc.v[tm][tn][r];
+                    const size_t idx = (size_t)m * a.K + n;
+                    if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                    a.y[idx] = v;
+                }
+            }
+        }
+}
+
+// ===================================== wgrad kernel ============================================
+// a.x = x, a.w = dy ([P][K]), a.y = dW or the split workspace.  grid.x = nblk_m*nblk_n*nsplit
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nblk = a.nblk_m * a.nblk_n;
+    const int z = blockIdx.x / nblk;
+    int bid = blockIdx.x - z * nblk;
+    const int mt = bid / a.nblk_n, nt = bid - mt * a.nblk_n;
+    const int mm0 = mt * BM, n0 = nt * BN;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+    WgradALoader<BM, MODE> la;
+    BLoader<BN> lb;
+    la.init(t, mm0, a);
+    lb.init(t);
+
+    Acc<TM, TN> acc;
+    acc.zero();
+
+    const int P = a.M;
+    const int nchunks_total = (P + BK - 1) / BK;
+    const int c_begin = z * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    if (c_end > nchunks_total) c_end = nchunks_total;
+    const int nchunks = c_end - c_begin;
+    if (nchunks > 0) {
+        la.load(a, c_begin * BK, P);
+        lb.load(a.w, c_begin * BK, P, a.K, n0);
+        la.store(lds);
+        lb.store(lds + 2 * ASZ);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int cur = c & 1;
+            const bool more = (c + 1) < nchunks;
+            if (more) {
+                la.load(a, (c_begin + c + 1) * BK, P);
+                lb.load(a.w, (c_begin + c + 1) * BK, P, a.K, n0);
+            }
+            mfma_stage<TM, TN, false, LDA, LDB>(lds + cur * ASZ, lds + 2 * ASZ + cur * BSZ, wm0, wn0, lane, acc);
+            if (more) {
+                la.store(lds + (cur ^ 1) * ASZ);
+                lb.store(lds + 2 * ASZ + (cur ^ 1) * BSZ);
+            }
+            __syncthreads();
+        }
+    }
+
+    float* out = a.y + (size_t)z * a.split_stride;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn0 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < a.Kred && n < a.K) out[(size_t)m * a.K + n] = acc.v[tm][tn][r];
+            }
+        }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nsplit,
+                                     size_t stride) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gs = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += gs) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * stride + i];
+        out[i] = s;
+    }
+}
+
+// w [R][S][C][K] -> wt [R][S][K][C] with both spatial axes flipped (filters of the dgrad convolution)
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int R, int S, int C, int K) {
+    __shared__ float tile[32][33];
+    const int rs = blockIdx.z;
+    const int r = rs / S, s = rs - r * S;
+    const int rs_f = (R - 1 - r) * S + (S - 1 - s);
+    const float* src = w + (size_t)rs * C * K;
+    float* dst = wt + (size_t)rs_f * K * C;
+    const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, k = k0 + tx;
+        tile[i][tx] = (c < C && k < K) ? src[(size_t)c * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int k = k0 + i, c = c0 + tx;
+        if (k < K && c < C) dst[(size_t)k * C + c] = tile[tx][i];
+    }
+}
+
+__global__ void naive_conv_kernel(ConvArgs a) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)a.M * a.K;
+    if (idx >= total) return;
+    const int k = (int)(idx % a.K);
+    const int m = (int)(idx / a.K);
+    const int n = m / a.OHW;
+    const int rem = m - n * a.OHW;
+    const int oh = rem / a.OW, ow = rem - oh * a.OW;
+    float acc = 0.f;
+    for (int r = 0; r < a.R; ++r)
+        for (int s = 0; s < a.S; ++s) {
+            int ih = 0, iw = 0;
+            if (!map_coord(oh * a.stride - a.pad_t + r * a.dil, a.H, a.ups, a.pad_mode, ih)) continue;
+            if (!map_coord(ow * a.stride - a.pad_l + s * a.dil, a.W, a.ups, a.pad_mode, iw)) continue;
+            const float* xp = a.x + ((size_t)(n * a.H + ih) * a.W + iw) * a.C;
+            const float* wp = a.w + (size_t)((r * a.S + s) * a.C) * a.K + k;
+            for (int c = 0; c < a.C; ++c) acc = fmaf(xp[c], wp[(size_t)c * a.K], acc);
+        }
+    a.y[idx] = acc;
+}
+
+// sympad backward: dx[n,h,w,c] = sum of dxp over every padded position that mirrors onto (h,w)
+__global__ void sympad_bwd_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int N, int H, int W, int C,
+                                  int p) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)N * H * W * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    size_t q = idx / C;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H);
+    const int n = (int)(q / H);
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    // padded rows mapping to h: h+p always; (p-1-h) if h<p; (2H-1-h+p) if h >= H-p
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + p;
+    if (h < p) hs[nh++] = p - 1 - h;
+    if (h >= H - p) hs[nh++] = 2 * H - 1 - h + p;
+    ws[nw++] = w + p;
+    if (w < p) ws[nw++] = p - 1 - w;
+    if (w >= W - p) ws[nw++] = 2 * W - 1 - w + p;
+    float s = 0.f;
+    for (int i = 0; i < nh; ++i)
+        for (int j = 0; j < nw; ++j) s += dxp[(((size_t)n * Hp + hs[i]) * Wp + ws[j]) * C + c];
+    dx[idx] = s;
+}
+
+// ------------------------------------ host side -------------------------------------------------
+int check_geom(const pnp_conv_geom* g, const char* who) {
+    PNP_REQUIRE(g != nullptr, "%s: null geometry", who);
+    PNP_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->C > 0 && g->K > 0 && g->R > 0 && g->S > 0 && g->OH > 0 &&
+                    g->OW > 0 && g->stride > 0 && g->dil > 0,
+                "%s: non-positive dimension", who);
+    PNP_REQUIRE(g->pad_mode == PNP_PAD_ZERO || g->pad_mode == PNP_PAD_SYMMETRIC, "%s: bad pad_mode %d", who, g->pad_mode);
+    PNP_REQUIRE(g->pad_t >= 0 && g->pad_l >= 0, "%s: negative padding", who);
+    if (g->pad_mode == PNP_PAD_SYMMETRIC)
+        PNP_REQUIRE(g->pad_t <= g->H && g->pad_l <= g->W, "%s: symmetric pad larger than the image", who);
+    // last tap of the last output must not run past the (padded) input by more than the implicit zero region in
+    // symmetric mode (pad-then-VALID): (OH-1)*stride + (R-1)*dil - pad_t <= H-1+pad_t
+    if (g->pad_mode == PNP_PAD_SYMMETRIC) {
+        PNP_REQUIRE((g->OH - 1) * g->stride + (g->R - 1) * g->dil - g->pad_t <= g->H - 1 + g->pad_t &&
+                        (g->OW - 1) * g->stride + (g->S - 1) * g->dil - g->pad_l <= g->W - 1 + g->pad_l,
+                    "%s: SYMMETRIC geometry reads past the mirrored border", who);
+    }
+    const long long xin = (long long)g->N * g->H * g->W * g->C, yout = (long long)g->N * g->OH * g->OW * g->K;
+    PNP_REQUIRE(xin < (1ll << 31) && yout < (1ll << 31), "%s: tensor exceeds 2^31 elements", who);
+    return PNP_OK;
+}
+
+ConvArgs make_args(const float* x, const float* w, float* y, const pnp_conv_geom* g) {
+    ConvArgs a{};
+    a.x = x; a.w = w; a.y = y;
+    a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->C; a.K = g->K; a.R = g->R; a.S = g->S;
+    a.OH = g->OH; a.OW = g->OW; a.stride = g->stride; a.dil = g->dil; a.pad_t = g->pad_t; a.pad_l = g->pad_l;
+    a.pad_mode = g->pad_mode;
+    a.ups = 1;
+    a.M = g->N * g->OH * g->OW;
+    a.Kred = g->R * g->S * g->C;
+    a.OHW = g->OH * g->OW;
+    a.nsplit = 1; a.chunks_per_split = 0; a.split_stride = 0;
+    a.do_drop = 0; a.drop_scale = 1.f; a.drop_key = 0; a.drop_thresh = 0;
+    a.xcd_swizzle = 1;
+    return a;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_fwd_tile(ConvArgs& a, hipStream_t st) {
+    a.nblk_m = pnp_cdiv(a.M, BM);
+    a.nblk_n = pnp_cdiv(a.K, BN);
+    dim3 grid((unsigned)(a.nblk_m * a.nblk_n));
+    const int mode = (a.C % 32 == 0) ? 0 : ((a.C % 4 == 0) ? 1 : 2);
+    if (mode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0>), grid, dim3(NTHREADS), 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 1>), grid, dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 2>), grid, dim3(NTHREADS), 0, st, a);
+    PNP_CHECK_LAUNCH("conv_fwd_kernel");
+    return PNP_OK;
+}
+
+int launch_fwd(ConvArgs& a, hipStream_t st) {
+    if (a.K > 64) return launch_fwd_tile<128, 128, 2, 2>(a, st);
+    if (a.K > 32) return launch_fwd_tile<128, 64, 2, 2>(a, st);
+    return launch_fwd_tile<128, 32, 4, 1>(a, st);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStream_t st) {
+    a.nblk_m = pnp_cdiv(a.Kred, BM);
+    a.nblk_n = pnp_cdiv(a.K, BN);
+    const int nblk = a.nblk_m * a.nblk_n;
+    const int nchunks = pnp_cdiv(a.M, BK);
+    int nsplit = pnp_cdiv(1024, nblk);
+    int max_split = nchunks / 8;
+    if (max_split < 1) max_split = 1;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    const size_t nout = (size_t)a.Kred * a.K;
+    if (nsplit > 1 && ws_bytes < nsplit * nout * sizeof(float)) {
+        nsplit = (int)(ws_bytes / (nout * sizeof(float)));
+        if (nsplit < 2) nsplit = 1;
+    }
+    a.chunks_per_split = pnp_cdiv(nchunks, nsplit);
+    nsplit = pnp_cdiv(nchunks, a.chunks_per_split);
+    a.nsplit = nsplit;
+    a.split_stride = (long long)nout;
+    a.y = (nsplit > 1) ? ws : dw;
+    dim3 grid((unsigned)(nblk * nsplit));
+    const int mode = (a.C % BM == 0) ? 0 : ((a.C % 4 == 0) ? 1 : 2);
+    if (mode == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 0>), grid, dim3(NTHREADS), 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 1>), grid, dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 2>), grid, dim3(NTHREADS), 0, st, a);
+    PNP_CHECK_LAUNCH("conv_wgrad_kernel");
+    if (nsplit > 1) {
+        int nb = pnp_cdiv((long long)nout, 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, dw, nout, nsplit, nout);
+        PNP_CHECK_LAUNCH("splitk_reduce_kernel");
+    }
+    return PNP_OK;
+}
+
+size_t wgrad_ws(const pnp_conv_geom* g) {
+    // worst case: up to 1024/nblk splits, bounded by 64 MiB of partials beyond one copy
+    const size_t nout = (size_t)g->R * g->S * g->C * g->K;
+    const long long P = (long long)g->N * g->OH * g->OW;
+    int nblk = pnp_cdiv((long long)g->R * g->S * g->C, 128) * pnp_cdiv(g->K, g->K > 64 ? 128 : (g->K > 32 ? 64 : 32));
+    int nsplit = pnp_cdiv(1024, nblk);
+    int max_split = (int)(pnp_cdiv(P, BK) / 8);
+    if (max_split < 1) max_split = 1;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit <= 1) return 0;
+    return (size_t)nsplit * nout * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pnp_conv2d_fwd(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
+                   uint32_t stream_id, void* stream) {
+    if (int e = check_geom(g, "pnp_conv2d_fwd")) return e;
+    PNP_REQUIRE(x && w && y, "pnp_conv2d_fwd: null pointer");
+    PNP_REQUIRE(keep_prob > 0.f, "pnp_conv2d_fwd: keep_prob must be > 0");
+    ConvArgs a = make_args(x, w, y, g);
+    if (keep_prob < 1.f) {
+        a.do_drop = 1;
+        a.drop_scale = 1.f / keep_prob;
+        a.drop_key = pnp_drop_key(seed, stream_id);
+        a.drop_thresh = pnp_drop_thresh(keep_prob);
+    }
+    return launch_fwd(a, (hipStream_t)stream);
+}
+
+int pnp_conv2d_fwd_naive(const float* x, const float* w, float* y, const pnp_conv_geom* g, void* stream) {
+    if (int e = check_geom(g, "pnp_conv2d_fwd_naive")) return e;
+    ConvArgs a = make_args(x, w, y, g);
+    const size_t total = (size_t)a.M * a.K;
+    hipLaunchKernelGGL(naive_conv_kernel, dim3((unsigned)pnp_cdiv((long long)total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    PNP_CHECK_LAUNCH("naive_conv_kernel");
+    return PNP_OK;
+}
+
+// dgrad workspace: [flipped/transposed filters R*S*K*C] [+ padded dx for SYMMETRIC]
+size_t pnp_conv2d_dgrad_workspace_bytes(const pnp_conv_geom* g) {
+    if (!g) return 0;
+    size_t b = (size_t)g->R * g->S * g->C * g->K * sizeof(float);
+    b = (b + 255) & ~(size_t)255;
+    if (g->pad_mode == PNP_PAD_SYMMETRIC)
+        b += (size_t)g->N * (g->H + 2 * g->pad_t) * (g->W + 2 * g->pad_l) * g->C * sizeof(float);
+    return b;
+}
+
+int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_geom* g, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (int e = check_geom(g, "pnp_conv2d_dgrad")) return e;
+    PNP_REQUIRE(dy && w && dx && workspace, "pnp_conv2d_dgrad: null pointer");
+    PNP_REQUIRE(workspace_bytes >= pnp_conv2d_dgrad_workspace_bytes(g), "pnp_conv2d_dgrad: workspace too small");
+    if (g->pad_mode == PNP_PAD_SYMMETRIC) PNP_REQUIRE(g->pad_t == g->pad_l, "pnp_conv2d_dgrad: SYMMETRIC needs pad_t == pad_l");
+    hipStream_t st = (hipStream_t)stream;
+    float* wt = (float*)workspace;
+    size_t woff = ((size_t)g->R * g->S * g->C * g->K * sizeof(float) + 255) & ~(size_t)255;
+    dim3 tg((unsigned)pnp_cdiv(g->K, 32), (unsigned)pnp_cdiv(g->C, 32), (unsigned)(g->R * g->S));
+    hipLaunchKernelGGL(flip_transpose_kernel, tg, dim3(256), 0, st, w, wt, g->R, g->S, g->C, g->K);
+    PNP_CHECK_LAUNCH("flip_transpose_kernel");
+
+    // dgrad as a stride-1 convolution over dy (zero-upsampled by `stride`), output = (padded) input image
+    const bool sym = g->pad_mode == PNP_PAD_SYMMETRIC;
+    pnp_conv_geom d{};
+    d.N = g->N; d.H = g->OH; d.W = g->OW; d.C = g->K; d.K = g->C; d.R = g->R; d.S = g->S;
+    d.OH = sym ? g->H + 2 * g->pad_t : g->H;
+    d.OW = sym ? g->W + 2 * g->pad_l : g->W;
+    d.stride = 1; d.dil = g->dil;
+    d.pad_t = g->dil * (g->R - 1) - (sym ? 0 : g->pad_t);
+    d.pad_l = g->dil * (g->S - 1) - (sym ? 0 : g->pad_l);
+    d.pad_mode = PNP_PAD_ZERO;
+    PNP_REQUIRE(d.pad_t >= 0 && d.pad_l >= 0, "pnp_conv2d_dgrad: forward padding exceeds the filter extent");
+    float* out = sym ? (float*)((char*)workspace + woff) : dx;
+    ConvArgs a = make_args(dy, wt, out, &d);
+    a.ups = g->stride;
+    if (int e = launch_fwd(a, st)) return e;
+    if (sym) {
+        const size_t total = (size_t)g->N * g->H * g->W * g->C;
+        hipLaunchKernelGGL(sympad_bwd_kernel, dim3((unsigned)pnp_cdiv((long long)total, 256)), dim3(256), 0, st,
+                           (const float*)out, dx, g->N, g->H, g->W, g->C, g->pad_t);
+        PNP_CHECK_LAUNCH("sympad_bwd_kernel");
+    }
+    return PNP_OK;
+}
+
+size_t pnp_conv2d_wgrad_workspace_bytes(const pnp_conv_geom* g) { return g ? wgrad_ws(g) : 0; }
+
+int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_geom* g, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (int e = check_geom(g, "pnp_conv2d_wgrad")) return e;
+    PNP_REQUIRE(x && dy && dw, "pnp_conv2d_wgrad: null pointer");
+    ConvArgs a = make_args(x, dy, dw, g);
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    if (!ws) workspace_bytes = 0;
+    if (a.K > 64) return launch_wgrad_tile<128, 128, 2, 2>(a, dw, ws, workspace_bytes, st);
+    if (a.K > 32) return launch_wgrad_tile<128, 64, 2, 2>(a, dw, ws, workspace_bytes, st);
+    return launch_wgrad_tile<128, 32, 4, 1>(a, dw, ws, workspace_bytes, st);
+}
+
+int pnp_sympad_bwd(const float* dxp, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t p, void* stream) {
+    PNP_REQUIRE(dxp && dx && N > 0 && H > 0 && W > 0 && C > 0 && p >= 0 && p <= H && p <= W, "pnp_sympad_bwd: bad argument");
+    const size_t total = (size_t)N * H * W * C;
+    hipLaunchKernelGGL(sympad_bwd_kernel, dim3((unsigned)pnp_cdiv((long long)total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dxp, dx, N, H, W, C, p);
+    PNP_CHECK_LAUNCH("sympad_bwd_kernel");
+    return PNP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,663 @@
+// elementwise.hip — the HBM-bound kernels of the hot path: batch-norm (+dropout-mask, +residual, +leaky-ReLU),
+// 2x2 max-pool, phase-shift (PS) upsampling, critic-input assembly, dropout, axpby.
+// Reference call sites: layers.py:95-100 (batch_norm), 145-189 (residual_block / DR_block tails),
+// 102-103 (max_pool2d), ops.py:3-27 (PS), adversarial.py:325-335 (critic input), layers.py:25,74,93 (dropout).
+// All tensors are [P][C] fp32 with C contiguous; every kernel moves 16 B per lane where C % 4 == 0.
+#include "pnp_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+inline int grid_for(size_t nvec, int cap = 256 * 8) {
+    long long b = (long long)((nvec + NT - 1) / NT);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column reductions over [P][C]: each block reduces a slab of rows for every channel.
+// partial layout: ws[(blk * 2 + q) * C + c], q in {0,1}
+// KIND 0: BN statistics  q0 = sum(x - s), q1 = sum((x-s)^2) with shift s = x[0][c]
+// KIND 1: BN backward    q0 = sum(dz),    q1 = sum(dz * xhat)
+struct ColArgs {
+    const float* x;      // KIND0: x ; KIND1: x (pre-BN input)
+    const float* dout;   // KIND1
+    const float* out;    // KIND1 (post activation), may be null when alpha<0
+    const float* mean;   // KIND1
+    const float* var;    // KIND1
+    float* ws;
+    long long P;
+    int C;
+    int rows_per_block;
+    float eps, alpha;
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(NT) colreduce_kernel(ColArgs a) {
+    __shared__ float red[NT * 8];
+    const int C4 = a.C >> 2;
+    const int rpi = NT / C4;                 // rows per iteration (C4 <= 256 guaranteed by the host)
+    const int t = threadIdx.x;
+    const int cg = t % C4, rsub = t / C4;
+    const bool active = rsub < rpi;
+    const long long r0 = (long long)blockIdx.x * a.rows_per_block;
+    long long r1 = r0 + a.rows_per_block;
+    if (r1 > a.P) r1 = a.P;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    if (active) {
+        const int c = cg * 4;
+        f32x4 m, rs;
+        if constexpr (KIND == 0) {
+            m = ld4(a.x + c);   // shift
+        } else {
+            m = ld4(a.mean + c);
+            f32x4 v = ld4(a.var + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rs[e] = 1.0f / sqrtf(v[e] + a.eps);
+        }
+        for (long long r = r0 + rsub; r < r1; r += rpi) {
+            const size_t off = (size_t)r * a.C + c;
+            f32x4 xv = ld4(a.x + off);
+            if constexpr (KIND == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = xv[e] - m[e];
+                    s0[e] += d;
+                    s1[e] = fmaf(d, d, s1[e]);
+                }
+            } else {
+                f32x4 g = ld4(a.dout + off);
+                if (a.alpha >= 0.f) {
+                    f32x4 o = ld4(a.out + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : g[e] * a.alpha;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float xh = (xv[e] - m[e]) * rs[e];
+                    s0[e] += g[e];
+                    s1[e] = fmaf(g[e], xh, s1[e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[t * 8 + e] = s0[e];
+        red[t * 8 + 4 + e] = s1[e];
+    }
+    __syncthreads();
+    if (t < C4) {
+        f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+        for (int j = 0; j < rpi; ++j) {
+            const int tt = j * C4 + t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[e] += red[tt * 8 + e];
+                a1[e] += red[tt * 8 + 4 + e];
+            }
+        }
+        float* w0 = a.ws + ((size_t)blockIdx.x * 2 + 0) * a.C + t * 4;
+        float* w1 = a.ws + ((size_t)blockIdx.x * 2 + 1) * a.C + t * 4;
+        st4(w0, a0);
+        st4(w1, a1);
+    }
+}
+
+// scalar fallback for C % 4 != 0 or C > 1024: one thread per channel per block-slab
+template <int KIND>
+__global__ void colreduce_scalar_kernel(ColArgs a) {
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    const long long r0 = (long long)blockIdx.x * a.rows_per_block;
+    long long r1 = r0 + a.rows_per_block;
+    if (r1 > a.P) r1 = a.P;
+    float s0 = 0.f, s1 = 0.f;
+    float m, rs = 0.f;
+    if constexpr (KIND == 0) m = a.x[c];
+    else { m = a.mean[c]; rs = 1.0f / sqrtf(a.var[c] + a.eps); }
+    for (long long r = r0; r < r1; ++r) {
+        const size_t off = (size_t)r * a.C + c;
+        float xv = a.x[off];
+        if constexpr (KIND == 0) {
+            float d = xv - m;
+            s0 += d;
+            s1 = fmaf(d, d, s1);
+        } else {
+            float g = a.dout[off];
+            if (a.alpha >= 0.f) g = a.out[off] > 0.f ? g : g * a.alpha;
+            s0 += g;
+            s1 = fmaf(g, (xv - m) * rs, s1);
+        }
+    }
+    a.ws[((size_t)blockIdx.x * 2 + 0) * a.C + c] = s0;
+    a.ws[((size_t)blockIdx.x * 2 + 1) * a.C + c] = s1;
+}
+
+// final combine over blocks in double. KIND 0 -> mean,var ; KIND 1 -> dbeta (o0), dgamma (o1)
+template <int KIND>
+__global__ void colreduce_final_kernel(const float* __restrict__ ws, const float* __restrict__ x0, float* o0, float* o1,
+                                       int nblk, int C, long long P) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s0 += (double)ws[((size_t)b * 2 + 0) * C + c];
+        s1 += (double)ws[((size_t)b * 2 + 1) * C + c];
+    }
+    if constexpr (KIND == 0) {
+        const double inv = 1.0 / (double)P;
+        const double md = s0 * inv;                 // mean of (x - shift)
+        double var = s1 * inv - md * md;
+        if (var < 0.0) var = 0.0;
+        o0[c] = (float)((double)x0[c] + md);
+        o1[c] = (float)var;
+    } else {
+        o0[c] = (float)s0;
+        o1[c] = (float)s1;
+    }
+}
+
+int colreduce_plan(long long P, int C, int* nblk, int* rpb) {
+    // ~2048 blocks max, at least 64 rows per block
+    long long b = (P + 63) / 64;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    long long r = (P + b - 1) / b;
+    b = (P + r - 1) / r;
+    *nblk = (int)b;
+    *rpb = (int)r;
+    (void)C;
+    return 0;
+}
+
+template <int KIND>
+int run_colreduce(ColArgs a, float* o0, float* o1, void* ws, size_t ws_bytes, hipStream_t st, const char* who) {
+    int nblk, rpb;
+    colreduce_plan(a.P, a.C, &nblk, &rpb);
+    const size_t need = (size_t)nblk * 2 * a.C * sizeof(float);
+    if (ws_bytes < need || !ws) {
+        pnp_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
+        return PNP_EWORKSPACE;
+    }
+    a.ws = (float*)ws;
+    a.rows_per_block = rpb;
+    if ((a.C & 3) == 0 && a.C <= 1024) {
+        hipLaunchKernelGGL(colreduce_kernel<KIND>, dim3(nblk), dim3(NT), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(colreduce_scalar_kernel<KIND>, dim3(nblk, pnp_cdiv(a.C, 64)), dim3(64), 0, st, a);
+    }
+    PNP_CHECK_LAUNCH(who);
+    hipLaunchKernelGGL(colreduce_final_kernel<KIND>, dim3(pnp_cdiv(a.C, 64)), dim3(64), 0, st, (const float*)ws, a.x, o0,
+                       o1, nblk, a.C, a.P);
+    PNP_CHECK_LAUNCH(who);
+    return PNP_OK;
+}
+
+__global__ void bn_update_moving_kernel(float* mm, float* mv, const float* mean, const float* var, long long P, int C,
+                                        float decay) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float one_minus = 1.0f - decay;
+    const float bessel = P > 1 ? (float)((double)P / (double)(P - 1)) : 1.0f;
+    mm[c] -= (mm[c] - mean[c]) * one_minus;
+    mv[c] -= (mv[c] - var[c] * bessel) * one_minus;
+}
+
+struct BnApplyArgs {
+    const float *x, *mean, *var, *gamma, *beta, *shortcut;
+    float* y;
+    long long P;
+    int C, Cs;
+    float eps, alpha;
+};
+
+template <bool VEC>
+__global__ void __launch_bounds__(NT) bn_apply_kernel(BnApplyArgs a) {
+    const int CV = VEC ? (a.C >> 2) : a.C;
+    const size_t nvec = (size_t)a.P * CV;
+    const int cpad = (a.C - a.Cs) / 2;
+    const size_t gs = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += gs) {
+        const size_t row = i / CV;
+        const int cv = (int)(i - row * CV);
+        if constexpr (VEC) {
+            const int c = cv * 4;
+            f32x4 xv = ld4(a.x + i * 4), m = ld4(a.mean + c), v = ld4(a.var + c), g = ld4(a.gamma + c), b = ld4(a.beta + c);
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (xv[e] - m[e]) * (g[e] * (1.0f / sqrtf(v[e] + a.eps))) + b[e];
+            if (a.shortcut) {
+                const int cs = c - cpad;
+                if (cs >= 0 && cs < a.Cs) {
+                    f32x4 s = ld4(a.shortcut + row * a.Cs + cs);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] += s[e];
+                }
+            }
+            if (a.alpha >= 0.f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.alpha;
+            }
+            st4(a.y + i * 4, r);
+        } else {
+            const int c = cv;
+            float r = (a.x[i] - a.mean[c]) * (a.gamma[c] * (1.0f / sqrtf(a.var[c] + a.eps))) + a.beta[c];
+            if (a.shortcut) {
+                const int cs = c - cpad;
+                if (cs >= 0 && cs < a.Cs) r += a.shortcut[row * a.Cs + cs];
+            }
+            if (a.alpha >= 0.f) r = r > 0.f ? r : r * a.alpha;
+            a.y[i] = r;
+        }
+    }
+}
+
+struct BnBwdArgs {
+    const float *dout, *out, *x, *mean, *var, *gamma, *dgamma, *dbeta;
+    float *dx, *dshortcut;
+    long long P;
+    int C, Cs;
+    float eps, alpha;
+    int training;
+    int do_drop;
+    uint32_t drop_key, drop_thresh;
+    float drop_scale;
+};
+
+template <bool VEC>
+__global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(BnBwdArgs a) {
+    const int CV = VEC ? (a.C >> 2) : a.C;
+    const size_t nvec = (size_t)a.P * CV;
+    const int cpad = (a.C - a.Cs) / 2;
+    const float invP = (float)(1.0 / (double)a.P);
+    const size_t gs = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += gs) {
+        const size_t row = i / CV;
+        const int cv = (int)(i - row * CV);
+        if constexpr (VEC) {
+            const int c = cv * 4;
+            f32x4 g = ld4(a.dout + i * 4);
+            if (a.alpha >= 0.f) {
+                f32x4 o = ld4(a.out + i * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : g[e] * a.alpha;
+            }
+            if (a.dshortcut) {
+                const int cs = c - cpad;
+                if (cs >= 0 && cs < a.Cs) st4(a.dshortcut + row * a.Cs + cs, g);
+            }
+            f32x4 xv = ld4(a.x + i * 4), m = ld4(a.mean + c), v = ld4(a.var + c), ga = ld4(a.gamma + c);
+            f32x4 r;
+            if (a.training) {
+                f32x4 dg = ld4(a.dgamma + c), db = ld4(a.dbeta + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float rs = 1.0f / sqrtf(v[e] + a.eps);
+                    float xh = (xv[e] - m[e]) * rs;
+                    r[e] = ga[e] * rs * (g[e] - db[e] * invP - xh * (dg[e] * invP));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = ga[e] * (1.0f / sqrtf(v[e] + a.eps)) * g[e];
+            }
+            if (a.do_drop) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    r[e] = pnp_drop_keep((uint32_t)(i * 4 + e), a.drop_key, a.drop_thresh) ? r[e] * a.drop_scale : 0.f;
+            }
+            st4(a.dx + i * 4, r);
+        } else {
+            const int c = cv;
+            float g = a.dout[i];
+            if (a.alpha >= 0.f) g = a.out[i] > 0.f ? g : g * a.alpha;
+            if (a.dshortcut) {
+                const int cs = c - cpad;
+                if (cs >= 0 && cs < a.Cs) a.dshortcut[row * a.Cs + cs] = g;
+            }
+            float rs = 1.0f / sqrtf(a.var[c] + a.eps);
+            float r;
+            if (a.training) {
+                float xh = (a.x[i] - a.mean[c]) * rs;
+                r = a.gamma[c] * rs * (g - a.dbeta[c] * invP - xh * (a.dgamma[c] * invP));
+            } else {
+                r = a.gamma[c] * rs * g;
+            }
+            if (a.do_drop) r = pnp_drop_keep((uint32_t)i, a.drop_key, a.drop_thresh) ? r * a.drop_scale : 0.f;
+            a.dx[i] = r;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NT) dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                                                     uint32_t key, uint32_t thresh, float scale) {
+    const size_t gs = (size_t)gridDim.x * NT;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += gs) {
+        f32x4 v = ld4(x + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pnp_drop_keep((uint32_t)(i * 4 + e), key, thresh) ? v[e] * scale : 0.f;
+        st4(y + i * 4, v);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += gs)
+        y[i] = pnp_drop_keep((uint32_t)i, key, thresh) ? x[i] * scale : 0.f;
+}
+
+__global__ void __launch_bounds__(NT) axpby_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float a,
+                                                   float b) {
+    const size_t gs = (size_t)gridDim.x * NT;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += gs) {
+        f32x4 xv = ld4(x + i * 4), yv = ld4(y + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yv[e] = a * xv[e] + b * yv[e];
+        st4(y + i * 4, yv);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += gs) y[i] = a * x[i] + b * y[i];
+}
+
+// ---- 2x2/2 max-pool -----------------------------------------------------------------------------
+template <bool BWD>
+__global__ void __launch_bounds__(NT) maxpool2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      float* __restrict__ out, int N, int H, int W, int C) {
+    const int OH = H >> 1, OW = W >> 1;
+    const int CV = ((C & 3) == 0) ? (C >> 2) : C;
+    const bool vec = (C & 3) == 0;
+    const size_t total = (size_t)N * OH * OW * CV;
+    const size_t gs = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += gs) {
+        const int cv = (int)(i % CV);
+        size_t q = i / CV;
+        const int ow = (int)(q % OW);
+        q /= OW;
+        const int oh = (int)(q % OH);
+        const int n = (int)(q / OH);
+        const size_t base = (((size_t)n * H + 2 * oh) * W + 2 * ow) * C;
+        const size_t o01 = (size_t)C, o10 = (size_t)W * C, o11 = (size_t)W * C + C;
+        if (vec) {
+            const int c = cv * 4;
+            f32x4 v00 = ld4(x + base + c), v01 = ld4(x + base + o01 + c), v10 = ld4(x + base + o10 + c),
+                  v11 = ld4(x + base + o11 + c);
+            if constexpr (!BWD) {
+                f32x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]));
+                st4(out + i * 4, r);
+            } else {
+                f32x4 g = ld4(dy + i * 4);
+                f32x4 d00, d01, d10, d11;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // first maximal element in window scan order (row-major) gets the gradient
+                    float m = v00[e];
+                    int am = 0;
+                    if (v01[e] > m) { m = v01[e]; am = 1; }
+                    if (v10[e] > m) { m = v10[e]; am = 2; }
+                    if (v11[e] > m) { m = v11[e]; am = 3; }
+                    d00[e] = am == 0 ? g[e] : 0.f;
+                    d01[e] = am == 1 ? g[e] : 0.f;
+                    d10[e] = am == 2 ? g[e] : 0.f;
+                    d11[e] = am == 3 ? g[e] : 0.f;
+                }
+                st4(out + base + c, d00);
+                st4(out + base + o01 + c, d01);
+                st4(out + base + o10 + c, d10);
+                st4(out + base + o11 + c, d11);
+            }
+        } else {
+            const int c = cv;
+            float v00 = x[base + c], v01 = x[base + o01 + c], v10 = x[base + o10 + c], v11 = x[base + o11 + c];
+            if constexpr (!BWD) {
+                out[i] = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+            } else {
+                float g = dy[i];
+                float m = v00;
+                int am = 0;
+                if (v01 > m) { m = v01; am = 1; }
+                if (v10 > m) { m = v10; am = 2; }
+                if (v11 > m) { m = v11; am = 3; }
+                out[base + c] = am == 0 ? g : 0.f;
+                out[base + o01 + c] = am == 1 ? g : 0.f;
+                out[base + o10 + c] = am == 2 ? g : 0.f;
+                out[base + o11 + c] = am == 3 ? g : 0.f;
+            }
+        }
+    }
+}
+
+// ---- PS (phase shift): out[n, i*r+u, j*r+v, c] = x[n,i,j, c*r*r + v*r + u] ----------------------
+// One thread per OUTPUT element (fwd) / per INPUT-GRAD element (bwd); the thread index runs over the
+// output layout so stores are coalesced; loads hit the same 10 KB input pixel row (L1/L2 resident).
+template <bool BWD>
+__global__ void __launch_bounds__(NT) ps_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int A, int B,
+                                                int r, int nc) {
+    const int Cin = nc * r * r;
+    const size_t total = (size_t)N * A * B * Cin;
+    const size_t gs = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += gs) {
+        // decode i in the fine (output) layout [N][A*r][B*r][nc]
+        const int c = (int)(i % nc);
+        size_t q = i / nc;
+        const int wo = (int)(q % (B * r));
+        q /= (B * r);
+        const int ho = (int)(q % (A * r));
+        const int n = (int)(q / (A * r));
+        const int ii = ho / r, u = ho - ii * r;
+        const int jj = wo / r, v = wo - jj * r;
+        const size_t coarse = (((size_t)n * A + ii) * B + jj) * Cin + (size_t)c * r * r + v * r + u;
+        if constexpr (!BWD) dst[i] = src[coarse];
+        else dst[coarse] = src[i];
+    }
+}
+
+// ---- critic input assembly (adversarial.py:325-335) ---------------------------------------------
+struct CriticArgs {
+    const float *a, *b, *c, *d, *logits;
+    float* out;
+    long long P;
+    int Ca, tile_a, Cb, Cc, Cd, ncls, Ctot;
+};
+__global__ void __launch_bounds__(NT) critic_input_fwd_kernel(CriticArgs k) {
+    const size_t total = (size_t)k.P * k.Ctot;
+    const size_t gs = (size_t)gridDim.x * NT;
+    const int o1 = k.Ca * k.tile_a, o2 = o1 + k.Cb, o3 = o2 + k.Cc, o4 = o3 + k.Cd, o5 = o4 + k.ncls;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += gs) {
+        const size_t p = i / k.Ctot;
+        const int ch = (int)(i - p * k.Ctot);
+        float v;
+        if (ch < o1) v = k.a[p * k.Ca + (ch % k.Ca)];
+        else if (ch < o2) v = k.b[p * k.Cb + (ch - o1)];
+        else if (ch < o3) v = k.c[p * k.Cc + (ch - o2)];
+        else if (ch < o4) v = k.d[p * k.Cd + (ch - o3)];
+        else if (ch < o5) v = k.logits[p * k.ncls + (ch - o4)];
+        else {
+            const float* z = k.logits + p * k.ncls;
+            int am = 0;
+            float m = z[0];
+            for (int j = 1; j < k.ncls; ++j)
+                if (z[j] > m) { m = z[j]; am = j; }
+            v = (float)am;
+        }
+        k.out[i] = v;
+    }
+}
+struct CriticBwdArgs {
+    const float* dout;
+    float *da, *db, *dc, *dd, *dlogits;
+    long long P;
+    int Ca, tile_a, Cb, Cc, Cd, ncls, Ctot;
+};
+// one thread per (pixel, source channel) over the concatenated *source* channel space Ca+Cb+Cc+Cd+ncls
+__global__ void __launch_bounds__(NT) critic_input_bwd_kernel(CriticBwdArgs k) {
+    const int Csrc = k.Ca + k.Cb + k.Cc + k.Cd + k.ncls;
+    const size_t total = (size_t)k.P * Csrc;
+    const size_t gs = (size_t)gridDim.x * NT;
+    const int o1 = k.Ca * k.tile_a, o2 = o1 + k.Cb, o3 = o2 + k.Cc, o4 = o3 + k.Cd;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += gs) {
+        const size_t p = i / Csrc;
+        int ch = (int)(i - p * Csrc);
+        const float* g = k.dout + p * k.Ctot;
+        if (ch < k.Ca) {
+            float s = 0.f;
+            for (int t = 0; t < k.tile_a; ++t) s += g[t * k.Ca + ch];
+            if (k.da) k.da[p * k.Ca + ch] = s;
+            continue;
+        }
+        ch -= k.Ca;
+        if (ch < k.Cb) { if (k.db) k.db[p * k.Cb + ch] = g[o1 + ch]; continue; }
+        ch -= k.Cb;
+        if (ch < k.Cc) { if (k.dc) k.dc[p * k.Cc + ch] = g[o2 + ch]; continue; }
+        ch -= k.Cc;
+        if (ch < k.Cd) { if (k.dd) k.dd[p * k.Cd + ch] = g[o3 + ch]; continue; }
+        ch -= k.Cd;
+        if (k.dlogits) k.dlogits[p * k.ncls + ch] = g[o4 + ch];   // argmax channel has zero gradient
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pnp_bn_workspace_bytes(int64_t P, int32_t C) {
+    int nblk, rpb;
+    colreduce_plan(P, C, &nblk, &rpb);
+    return (size_t)nblk * 2 * C * sizeof(float);
+}
+
+int pnp_bn_stats(const float* x, float* mean, float* var, int64_t P, int32_t C, void* workspace, size_t workspace_bytes,
+                 void* stream) {
+    PNP_REQUIRE(x && mean && var && P > 0 && C > 0, "pnp_bn_stats: bad argument");
+    ColArgs a{};
+    a.x = x; a.P = P; a.C = C;
+    return run_colreduce<0>(a, mean, var, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_stats");
+}
+
+int pnp_bn_update_moving(float* moving_mean, float* moving_var, const float* mean, const float* var, int64_t P, int32_t C,
+                         float decay, void* stream) {
+    PNP_REQUIRE(moving_mean && moving_var && mean && var && P > 0 && C > 0, "pnp_bn_update_moving: bad argument");
+    hipLaunchKernelGGL(bn_update_moving_kernel, dim3(pnp_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, moving_mean,
+                       moving_var, mean, var, (long long)P, C, decay);
+    PNP_CHECK_LAUNCH("pnp_bn_update_moving");
+    return PNP_OK;
+}
+
+int pnp_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                 const float* shortcut, int32_t Cs, float* y, int64_t P, int32_t C, float eps, float alpha, void* stream) {
+    PNP_REQUIRE(x && mean && var && gamma && beta && y && P > 0 && C > 0, "pnp_bn_apply: bad argument");
+    if (shortcut) PNP_REQUIRE(Cs > 0 && Cs <= C && ((C - Cs) % 2) == 0, "pnp_bn_apply: bad shortcut channels %d vs %d", Cs, C);
+    BnApplyArgs a{x, mean, var, gamma, beta, shortcut, y, (long long)P, C, shortcut ? Cs : C, eps, alpha};
+    const bool vec = (C % 4 == 0) && (!shortcut || (Cs % 4 == 0 && ((C - Cs) / 2) % 4 == 0));
+    const size_t nvec = (size_t)P * (vec ? C / 4 : C);
+    if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(nvec)), dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(nvec)), dim3(NT), 0, (hipStream_t)stream, a);
+    PNP_CHECK_LAUNCH("pnp_bn_apply");
+    return PNP_OK;
+}
+
+int pnp_bn_bwd(const float* dout, const float* out, const float* x, const float* mean, const float* var,
+               const float* gamma, float* dx, float* dgamma, float* dbeta, float* dshortcut, int32_t Cs, int64_t P,
+               int32_t C, float eps, float alpha, int32_t training, float keep_prob, uint64_t seed, uint32_t stream_id,
+               void* workspace, size_t workspace_bytes, void* stream) {
+    PNP_REQUIRE(dout && x && mean && var && gamma && dx && dgamma && dbeta && P > 0 && C > 0, "pnp_bn_bwd: bad argument");
+    PNP_REQUIRE(alpha < 0.f || out, "pnp_bn_bwd: `out` is required when an activation is fused");
+    PNP_REQUIRE((size_t)P * C < (1ull << 32), "pnp_bn_bwd: tensor exceeds 2^32 elements");
+    if (dshortcut) PNP_REQUIRE(Cs > 0 && Cs <= C && ((C - Cs) % 2) == 0, "pnp_bn_bwd: bad shortcut channels");
+    hipStream_t st = (hipStream_t)stream;
+    ColArgs ca{};
+    ca.x = x; ca.dout = dout; ca.out = out; ca.mean = mean; ca.var = var; ca.P = P; ca.C = C; ca.eps = eps; ca.alpha = alpha;
+    if (int e = run_colreduce<1>(ca, dbeta, dgamma, workspace, workspace_bytes, st, "pnp_bn_bwd")) return e;
+    BnBwdArgs a{};
+    a.dout = dout; a.out = out; a.x = x; a.mean = mean; a.var = var; a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.dx = dx; a.dshortcut = dshortcut; a.P = P; a.C = C; a.Cs = dshortcut ? Cs : C; a.eps = eps; a.alpha = alpha;
+    a.training = training;
+    a.do_drop = keep_prob < 1.f;
+    a.drop_key = pnp_drop_key(seed, stream_id);
+    a.drop_thresh = pnp_drop_thresh(keep_prob);
+    a.drop_scale = keep_prob < 1.f ? 1.f / keep_prob : 1.f;
+    const bool vec = (C % 4 == 0) && (!dshortcut || (Cs % 4 == 0 && ((C - Cs) / 2) % 4 == 0));
+    const size_t nvec = (size_t)P * (vec ? C / 4 : C);
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(nvec)), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(nvec)), dim3(NT), 0, st, a);
+    PNP_CHECK_LAUNCH("pnp_bn_bwd");
+    return PNP_OK;
+}
+
+int pnp_dropout(const float* x, float* y, size_t n, float keep_prob, uint64_t seed, uint32_t stream_id, void* stream) {
+    PNP_REQUIRE(x && y && keep_prob > 0.f, "pnp_dropout: bad argument");
+    PNP_REQUIRE(n < (1ull << 32), "pnp_dropout: tensor exceeds 2^32 elements");
+    if (n == 0) return PNP_OK;
+    const float scale = keep_prob < 1.f ? 1.f / keep_prob : 1.f;
+    const uint32_t thresh = keep_prob < 1.f ? pnp_drop_thresh(keep_prob) : 0u;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, (hipStream_t)stream, x, y, n,
+                       pnp_drop_key(seed, stream_id), thresh, scale);
+    PNP_CHECK_LAUNCH("pnp_dropout");
+    return PNP_OK;
+}
+
+int pnp_axpby(const float* x, float* y, size_t n, float a, float b, void* stream) {
+    PNP_REQUIRE(x && y, "pnp_axpby: null pointer");
+    if (n == 0) return PNP_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, (hipStream_t)stream, x, y, n, a, b);
+    PNP_CHECK_LAUNCH("pnp_axpby");
+    return PNP_OK;
+}
+
+int pnp_maxpool2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    PNP_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0, "pnp_maxpool2_fwd: bad argument (H,W must be even)");
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * ((C % 4 == 0) ? C / 4 : C);
+    hipLaunchKernelGGL(maxpool2_kernel<false>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, x,
+                       (const float*)nullptr, y, N, H, W, C);
+    PNP_CHECK_LAUNCH("pnp_maxpool2_fwd");
+    return PNP_OK;
+}
+
+int pnp_maxpool2_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    PNP_REQUIRE(x && dy && dx && N > 0 && C > 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0, "pnp_maxpool2_bwd: bad argument");
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * ((C % 4 == 0) ? C / 4 : C);
+    hipLaunchKernelGGL(maxpool2_kernel<true>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C);
+    PNP_CHECK_LAUNCH("pnp_maxpool2_bwd");
+    return PNP_OK;
+}
+
+int pnp_ps_fwd(const float* x, float* y, int32_t N, int32_t A, int32_t B, int32_t r, int32_t nc, void* stream) {
+    PNP_REQUIRE(x && y && N > 0 && A > 0 && B > 0 && r > 0 && nc > 0, "pnp_ps_fwd: bad argument");
+    const size_t total = (size_t)N * A * B * nc * r * r;
+    hipLaunchKernelGGL(ps_kernel<false>, dim3(grid_for(total, 256 * 16)), dim3(NT), 0, (hipStream_t)stream, x, y, N, A, B, r, nc);
+    PNP_CHECK_LAUNCH("pnp_ps_fwd");
+    return PNP_OK;
+}
+
+int pnp_ps_bwd(const float* dy, float* dx, int32_t N, int32_t A, int32_t B, int32_t r, int32_t nc, void* stream) {
+    PNP_REQUIRE(dy && dx && N > 0 && A > 0 && B > 0 && r > 0 && nc > 0, "pnp_ps_bwd: bad argument");
+    const size_t total = (size_t)N * A * B * nc * r * r;
+    hipLaunchKernelGGL(ps_kernel<true>, dim3(grid_for(total, 256 * 16)), dim3(NT), 0, (hipStream_t)stream, dy, dx, N, A, B, r, nc);
+    PNP_CHECK_LAUNCH("pnp_ps_bwd");
+    return PNP_OK;
+}
+
+int pnp_critic_input_fwd(const float* a, int32_t Ca, int32_t tile_a, const float* b, int32_t Cb, const float* c, int32_t Cc,
+                         const float* d, int32_t Cd, const float* logits, int32_t ncls, float* out, int64_t P, void* stream) {
+    PNP_REQUIRE(a && b && c && d && logits && out && P > 0 && Ca > 0 && tile_a > 0 && Cb > 0 && Cc > 0 && Cd > 0 && ncls > 0,
+                "pnp_critic_input_fwd: bad argument");
+    CriticArgs k{a, b, c, d, logits, out, (long long)P, Ca, tile_a, Cb, Cc, Cd, ncls, Ca * tile_a + Cb + Cc + Cd + ncls + 1};
+    hipLaunchKernelGGL(critic_input_fwd_kernel, dim3(grid_for((size_t)P * k.Ctot, 256 * 16)), dim3(NT), 0, (hipStream_t)stream, k);
+    PNP_CHECK_LAUNCH("pnp_critic_input_fwd");
+    return PNP_OK;
+}
+
+int pnp_critic_input_bwd(const float* dout, float* da, int32_t Ca, int32_t tile_a, float* db, int32_t Cb, float* dc, int32_t Cc,
+                         float* dd, int32_t Cd, float* dlogits, int32_t ncls, int64_t P, void* stream) {
+    PNP_REQUIRE(dout && P > 0 && Ca > 0 && tile_a > 0 && Cb > 0 && Cc > 0 && Cd > 0 && ncls > 0, "pnp_critic_input_bwd: bad argument");
+    CriticBwdArgs k{dout, da, db, dc, dd, dlogits, (long long)P, Ca, tile_a, Cb, Cc, Cd, ncls, Ca * tile_a + Cb + Cc + Cd + ncls + 1};
+    hipLaunchKernelGGL(critic_input_bwd_kernel, dim3(grid_for((size_t)P * (Ca + Cb + Cc + Cd + ncls), 256 * 16)), dim3(NT), 0,
+                       (hipStream_t)stream, k);
+    PNP_CHECK_LAUNCH("pnp_critic_input_bwd");
+    return PNP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""torch.autograd glue over the HIP kernels (kernels.py).  torch supplies the tape; every forward and
+backward value is produced by libpnp_hip.so.
+
+Fused units (what TF-1.4 lowers layers.py's chains to, restated as one forward + one backward each):
+  Conv2dDropFn    : conv2d / atrous_conv2d -> dropout                      (layers.py:64-74, 84-93)
+  ConvBNActFn     : conv -> dropout -> batch_norm [-> + shortcut] [-> leaky_relu]
+                    (layers.py:9-45 and the tails of residual_block / DR_block, 145-189)
+  MaxPool2Fn, PSFn, SegLossFn, CriticInputFn
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+
+BN_EPS = 1e-3      # tf.contrib.layers.batch_norm default epsilon (layers.py:100 does not override it)
+BN_DECAY = 0.90    # layers.py:100
+LEAK = 0.2         # tf.nn.leaky_relu default alpha (layers.py:12,35,166,187)
+
+
+def _contig(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class Conv2dDropFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, geom, keep_prob, seed, stream_id):
+        x = _contig(x)
+        w_ = _contig(w)
+        y = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
+        ctx.save_for_backward(x, w_)
+        ctx.geom, ctx.keep, ctx.seed, ctx.sid = geom, keep_prob, seed, stream_id
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _contig(dy)
+        if ctx.keep < 1.0:
+            dy = K.dropout(dy, ctx.keep, ctx.seed, ctx.sid)
+        dx = K.conv2d_dgrad(dy, w, ctx.geom) if ctx.needs_input_grad[0] else None
+        dw = K.conv2d_wgrad(x, dy, ctx.geom) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None, None
+
+
+class ConvBNActFn(Function):
+    """y = act( BN( dropout( conv(x,w) ) ) + pad_channels(shortcut) )"""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, shortcut, geom, keep_prob, seed, stream_id, is_train, alpha):
+        x = _contig(x)
+        w_ = _contig(w)
+        xc = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
+        P = xc.numel() // xc.shape[-1]
+        if is_train:
+            mean, var = K.bn_stats(xc)
+            K.bn_update_moving(moving_mean, moving_var, mean, var, P, BN_DECAY)
+        else:
+            mean, var = moving_mean.clone(), moving_var.clone()
+        sc = _contig(shortcut) if shortcut is not None else None
+        out = K.bn_apply(xc, mean, var, gamma, beta, sc, BN_EPS, alpha)
+        ctx.save_for_backward(x, w_, xc, out, mean, var, gamma)
+        ctx.geom, ctx.keep, ctx.seed, ctx.sid = geom, keep_prob, seed, stream_id
+        ctx.is_train, ctx.alpha = is_train, alpha
+        ctx.sc_channels = sc.shape[-1] if sc is not None else 0
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, xc, out, mean, var, gamma = ctx.saved_tensors
+        dout = _contig(dout)
+        need_sc = ctx.sc_channels if ctx.needs_input_grad[6] else 0
+        dxc, dgamma, dbeta, dsc = K.bn_bwd(dout, out, xc, mean, var, gamma, need_sc, BN_EPS, ctx.alpha, ctx.is_train,
+                                           ctx.keep, ctx.seed, ctx.sid)
+        dx = K.conv2d_dgrad(dxc, w, ctx.geom) if ctx.needs_input_grad[0] else None
+        dw = K.conv2d_wgrad(x, dxc, ctx.geom) if ctx.needs_input_grad[1] else None
+        return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, None, None,
+                dsc, None, None, None, None, None, None)
+
+
+class BNActFn(Function):
+    """batch_norm alone (layers.batch_norm, layers.py:95-100), optional activation; no conv in front."""
+
+    @staticmethod
+    def forward(ctx, xc, gamma, beta, moving_mean, moving_var, is_train, alpha):
+        xc = _contig(xc)
+        P = xc.numel() // xc.shape[-1]
+        if is_train:
+            mean, var = K.bn_stats(xc)
+            K.bn_update_moving(moving_mean, moving_var, mean, var, P, BN_DECAY)
+        else:
+            mean, var = moving_mean.clone(), moving_var.clone()
+        out = K.bn_apply(xc, mean, var, gamma, beta, None, BN_EPS, alpha)
+        ctx.save_for_backward(xc, out, mean, var, gamma)
+        ctx.is_train, ctx.alpha = is_train, alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, out, mean, var, gamma = ctx.saved_tensors
+        dxc, dgamma, dbeta, _ = K.bn_bwd(_contig(dout), out, xc, mean, var, gamma, 0, BN_EPS, ctx.alpha, ctx.is_train)
+        return dxc, dgamma, dbeta, None, None, None, None
+
+
+class MaxPool2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(x)
+        ctx.save_for_backward(x)
+        return K.maxpool2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.maxpool2_bwd(x, _contig(dy))
+
+
+class PSFn(Function):
+    @staticmethod
+    def forward(ctx, x, r, nc):
+        ctx.r, ctx.nc = r, nc
+        return K.ps_fwd(_contig(x), r, nc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.ps_bwd(_contig(dy), ctx.r, ctx.nc), None, None
+
+
+class SegLossFn(Function):
+    """returns tensor [3] = (miu_cross*xent + miu_dice*dice, xent, dice).
+
+    Element 0 must be the ROOT of the backward pass (the reference does minimize(cost + reg),
+    source_segmenter.py:378): the upstream gradient is taken to be `gscale` (1, or 1/world_size under
+    data parallelism) and is applied inside the HIP kernel — no torch arithmetic on the gradient path."""
+
+    @staticmethod
+    def forward(ctx, logits, y, miu_cross, miu_dice, gscale):
+        logits = _contig(logits)
+        y = _contig(y)
+        out, ws = K.seg_loss_fwd(logits, y, miu_cross, miu_dice)
+        ctx.save_for_backward(logits, y, ws)
+        ctx.mc, ctx.md, ctx.gscale = miu_cross, miu_dice, gscale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        logits, y, ws = ctx.saved_tensors
+        g = K.seg_loss_bwd(logits, y, ws, ctx.mc, ctx.md, ctx.gscale)
+        return g, None, None, None, None
+
+
+class CriticInputFn(Function):
+    @staticmethod
+    def forward(ctx, a, b, c, d, logits, tile_a):
+        a, b, c, d, logits = map(_contig, (a, b, c, d, logits))
+        ctx.shapes = tuple(tuple(t.shape) for t in (a, b, c, d, logits))
+        ctx.tile_a = tile_a
+        return K.critic_input_fwd(a, tile_a, b, c, d, logits)
+
+    @staticmethod
+    def backward(ctx, dout):
+        need = tuple(ctx.needs_input_grad[:5])
+        da, db, dc, dd, dl = K.critic_input_bwd(_contig(dout), ctx.shapes, ctx.tile_a, need)
+        return da, db, dc, dd, dl, None

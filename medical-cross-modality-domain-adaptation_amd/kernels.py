@@ -1,0 +1,310 @@
+"""Raw (non-autograd) Python entry points over the C-ABI: torch tensors in, torch tensors out.
+
+torch is used here only as the device-memory container and for the current HIP stream; every
+arithmetic result comes from libpnp_hip.so.  Tensors are NHWC float32, filters HWIO — the
+reference's layouts (layers.py).  Each function names the reference op it stands for.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvGeom, PAD_SYMMETRIC, PAD_ZERO, check
+
+_ws_cache = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.PnpError("pnp kernels need CUDA/HIP tensors (got a CPU tensor) — there is no CPU fallback")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.PnpError("pnp kernels need contiguous float32 tensors, got %s contiguous=%s" % (t.dtype, t.is_contiguous()))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def workspace(nbytes, device, slot="main"):
+    """Grow-only scratch buffer per (device, slot). All kernels are stream-ordered on the current stream."""
+    key = (str(device), slot, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def same_pad(in_size, k, stride, dil=1):
+    """TF 'SAME': out = ceil(in/stride); pad_total = max((out-1)*stride + (k-1)*dil + 1 - in, 0); before = total//2."""
+    out = -(-in_size // stride)
+    eff = (k - 1) * dil + 1
+    total = max((out - 1) * stride + eff - in_size, 0)
+    return out, total // 2, total - total // 2
+
+
+def conv_geom(x_shape, w_shape, stride=1, dil=1, padding="SAME"):
+    """Geometry of layers.conv2d / dilate_conv2d (layers.py:64-74, 84-93)."""
+    N, H, W, C = x_shape
+    R, S, Cw, K = w_shape
+    if Cw != C:
+        raise ValueError("conv2d: input has %d channels, filter expects %d" % (C, Cw))
+    g = ConvGeom()
+    g.N, g.H, g.W, g.C, g.K, g.R, g.S = N, H, W, C, K, R, S
+    g.stride, g.dil = stride, dil
+    if padding == "SAME":
+        g.OH, g.pad_t, _ = same_pad(H, R, stride, dil)
+        g.OW, g.pad_l, _ = same_pad(W, S, stride, dil)
+        g.pad_mode = PAD_ZERO
+    elif padding == "SYMMETRIC":
+        # tf.pad(x, floor(k/2), 'SYMMETRIC') then VALID conv (layers.py:19-24)
+        ph, pw = R // 2, S // 2
+        g.pad_t, g.pad_l = ph, pw
+        g.OH = (H + 2 * ph - ((R - 1) * dil + 1)) // stride + 1
+        g.OW = (W + 2 * pw - ((S - 1) * dil + 1)) // stride + 1
+        g.pad_mode = PAD_SYMMETRIC
+    elif padding == "VALID":
+        g.pad_t = g.pad_l = 0
+        g.OH = (H - ((R - 1) * dil + 1)) // stride + 1
+        g.OW = (W - ((S - 1) * dil + 1)) // stride + 1
+        g.pad_mode = PAD_ZERO
+    else:
+        raise ValueError("unknown padding %r" % (padding,))
+    return g
+
+
+def conv2d_fwd(x, w, g, keep_prob=1.0, seed=0, stream_id=0, out=None, naive=False):
+    lib = _lib.load()
+    y = out if out is not None else torch.empty((g.N, g.OH, g.OW, g.K), dtype=torch.float32, device=x.device)
+    if naive:
+        check(lib.pnp_conv2d_fwd_naive(_p(x), _p(w), _p(y), ctypes.byref(g), _stream()), "pnp_conv2d_fwd_naive")
+    else:
+        check(lib.pnp_conv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _stream()),
+              "pnp_conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(dy, w, g):
+    lib = _lib.load()
+    dx = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dy.device)
+    nbytes = lib.pnp_conv2d_dgrad_workspace_bytes(ctypes.byref(g))
+    ws = workspace(nbytes, dy.device)
+    check(lib.pnp_conv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(g), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+          "pnp_conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(x, dy, g):
+    lib = _lib.load()
+    dw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
+    nbytes = lib.pnp_conv2d_wgrad_workspace_bytes(ctypes.byref(g))
+    ws = workspace(nbytes, x.device)
+    check(lib.pnp_conv2d_wgrad(_p(x), _p(dy), _p(dw), ctypes.byref(g), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+          "pnp_conv2d_wgrad")
+    return dw
+
+
+def dropout(x, keep_prob, seed, stream_id):
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    check(lib.pnp_dropout(_p(x), _p(y), x.numel(), float(keep_prob), int(seed), int(stream_id), _stream()), "pnp_dropout")
+    return y
+
+
+def bn_stats(x2d_like):
+    """per-channel mean / biased variance over all leading dims (layers.py:100, training path)."""
+    lib = _lib.load()
+    C = x2d_like.shape[-1]
+    P = x2d_like.numel() // C
+    mean = torch.empty(C, dtype=torch.float32, device=x2d_like.device)
+    var = torch.empty(C, dtype=torch.float32, device=x2d_like.device)
+    ws = workspace(lib.pnp_bn_workspace_bytes(P, C), x2d_like.device)
+    check(lib.pnp_bn_stats(_p(x2d_like), _p(mean), _p(var), P, C, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+          "pnp_bn_stats")
+    return mean, var
+
+
+def bn_update_moving(mm, mv, mean, var, P, decay=0.9):
+    lib = _lib.load()
+    check(lib.pnp_bn_update_moving(_p(mm), _p(mv), _p(mean), _p(var), P, mm.numel(), float(decay), _stream()),
+          "pnp_bn_update_moving")
+
+
+def bn_apply(x, mean, var, gamma, beta, shortcut=None, eps=1e-3, alpha=0.2):
+    lib = _lib.load()
+    C = x.shape[-1]
+    P = x.numel() // C
+    y = torch.empty_like(x)
+    Cs = shortcut.shape[-1] if shortcut is not None else 0
+    check(lib.pnp_bn_apply(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(shortcut), Cs, _p(y), P, C, float(eps),
+                           float(alpha), _stream()), "pnp_bn_apply")
+    return y
+
+
+def bn_bwd(dout, out, x, mean, var, gamma, shortcut_channels=0, eps=1e-3, alpha=0.2, training=True, keep_prob=1.0, seed=0,
+           stream_id=0):
+    lib = _lib.load()
+    C = x.shape[-1]
+    P = x.numel() // C
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    dsc = None
+    if shortcut_channels:
+        dsc = torch.empty(x.shape[:-1] + (shortcut_channels,), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.pnp_bn_workspace_bytes(P, C), x.device)
+    check(lib.pnp_bn_bwd(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(dsc),
+                         shortcut_channels, P, C, float(eps), float(alpha), 1 if training else 0, float(keep_prob), int(seed),
+                         int(stream_id), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_bn_bwd")
+    return dx, dgamma, dbeta, dsc
+
+
+def maxpool2_fwd(x):
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    check(lib.pnp_maxpool2_fwd(_p(x), _p(y), N, H, W, C, _stream()), "pnp_maxpool2_fwd")
+    return y
+
+
+def maxpool2_bwd(x, dy):
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    check(lib.pnp_maxpool2_bwd(_p(x), _p(dy), _p(dx), N, H, W, C, _stream()), "pnp_maxpool2_bwd")
+    return dx
+
+
+def ps_fwd(x, r, nc):
+    lib = _lib.load()
+    N, A, B, Cin = x.shape
+    if Cin != nc * r * r:
+        raise ValueError("PS: %d channels != n_channel*r*r = %d" % (Cin, nc * r * r))
+    y = torch.empty((N, A * r, B * r, nc), dtype=torch.float32, device=x.device)
+    check(lib.pnp_ps_fwd(_p(x), _p(y), N, A, B, r, nc, _stream()), "pnp_ps_fwd")
+    return y
+
+
+def ps_bwd(dy, r, nc):
+    lib = _lib.load()
+    N, Ar, Br, _ = dy.shape
+    A, B = Ar // r, Br // r
+    dx = torch.empty((N, A, B, nc * r * r), dtype=torch.float32, device=dy.device)
+    check(lib.pnp_ps_bwd(_p(dy), _p(dx), N, A, B, r, nc, _stream()), "pnp_ps_bwd")
+    return dx
+
+
+def sympad_bwd(dxp, p):
+    lib = _lib.load()
+    N, Hp, Wp, C = dxp.shape
+    dx = torch.empty((N, Hp - 2 * p, Wp - 2 * p, C), dtype=torch.float32, device=dxp.device)
+    check(lib.pnp_sympad_bwd(_p(dxp), _p(dx), N, Hp - 2 * p, Wp - 2 * p, C, p, _stream()), "pnp_sympad_bwd")
+    return dx
+
+
+def seg_loss_fwd(logits, y, miu_cross=1.0, miu_dice=1.0):
+    """returns (out[3] = total, xent, dice ; workspace tensor to hand to seg_loss_bwd)"""
+    lib = _lib.load()
+    ncls = logits.shape[-1]
+    P = logits.numel() // ncls
+    out = torch.empty(3, dtype=torch.float32, device=logits.device)
+    ws = torch.empty(lib.pnp_seg_loss_workspace_bytes(P, ncls), dtype=torch.uint8, device=logits.device)
+    check(lib.pnp_seg_loss_fwd(_p(logits), _p(y), _p(out), P, ncls, float(miu_cross), float(miu_dice),
+                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_seg_loss_fwd")
+    return out, ws
+
+
+def seg_loss_bwd(logits, y, ws, miu_cross=1.0, miu_dice=1.0, gscale=1.0):
+    lib = _lib.load()
+    ncls = logits.shape[-1]
+    P = logits.numel() // ncls
+    dl = torch.empty_like(logits)
+    check(lib.pnp_seg_loss_bwd(_p(logits), _p(y), _p(dl), P, ncls, float(miu_cross), float(miu_dice), float(gscale),
+                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_seg_loss_bwd")
+    return dl
+
+
+def softmax_argmax(logits, want_prob=True):
+    """layers.pixel_wise_softmax_2 + tf.argmax(.,3) (layers.py:134-138; source_segmenter.py:80-81)"""
+    lib = _lib.load()
+    ncls = logits.shape[-1]
+    P = logits.numel() // ncls
+    prob = torch.empty_like(logits) if want_prob else None
+    label = torch.empty(logits.shape[:-1], dtype=torch.int64, device=logits.device)
+    check(lib.pnp_softmax_argmax(_p(logits), _p(prob), ctypes.c_void_p(label.data_ptr()), P, ncls, _stream()), "pnp_softmax_argmax")
+    return prob, label
+
+
+def dice_eval(label, y):
+    """lib._dice_eval (lib.py:96-110): returns tensor [1+ncls] = (mean, per-class...)"""
+    lib = _lib.load()
+    ncls = y.shape[-1]
+    P = y.numel() // ncls
+    out = torch.empty(1 + ncls, dtype=torch.float32, device=y.device)
+    ws = workspace(1024 * 24 * 4, y.device)
+    check(lib.pnp_dice_eval(ctypes.c_void_p(label.data_ptr()), _p(y), _p(out), P, ncls, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                            _stream()), "pnp_dice_eval")
+    return out
+
+
+def _u8p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def adam_step(w, g, m, v, chunk_l2, chunk_mask, lr, beta1, beta2, eps, t):
+    check(_lib.load().pnp_adam_step(_p(w), _p(g), _p(m), _p(v), w.numel(), _p(chunk_l2), _u8p(chunk_mask), float(lr), float(beta1),
+                                    float(beta2), float(eps), int(t), _stream()), "pnp_adam_step")
+
+
+def rmsprop_step(w, g, ms, chunk_l2, chunk_mask, lr, decay=0.9, eps=1e-10):
+    check(_lib.load().pnp_rmsprop_step(_p(w), _p(g), _p(ms), w.numel(), _p(chunk_l2), _u8p(chunk_mask), float(lr), float(decay),
+                                       float(eps), _stream()), "pnp_rmsprop_step")
+
+
+def momentum_step(w, g, acc, chunk_l2, chunk_mask, lr, momentum):
+    check(_lib.load().pnp_momentum_step(_p(w), _p(g), _p(acc), w.numel(), _p(chunk_l2), _u8p(chunk_mask), float(lr),
+                                        float(momentum), _stream()), "pnp_momentum_step")
+
+
+def clip(w, chunk_mask, lo, hi):
+    check(_lib.load().pnp_clip(_p(w), w.numel(), _u8p(chunk_mask), float(lo), float(hi), _stream()), "pnp_clip")
+
+
+def l2_loss(w, chunk_l2):
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float32, device=w.device)
+    ws = workspace(lib.pnp_reduce_workspace_bytes(w.numel()), w.device)
+    check(lib.pnp_l2_loss(_p(w), w.numel(), _p(chunk_l2), _p(out), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+          "pnp_l2_loss")
+    return out
+
+
+def axpby(x, y, a, b):
+    check(_lib.load().pnp_axpby(_p(x), _p(y), x.numel(), float(a), float(b), _stream()), "pnp_axpby")
+    return y
+
+
+def critic_input_fwd(a, tile_a, b, c, d, logits):
+    lib = _lib.load()
+    P = logits.numel() // logits.shape[-1]
+    Ca, Cb, Cc, Cd, ncls = a.shape[-1], b.shape[-1], c.shape[-1], d.shape[-1], logits.shape[-1]
+    Ct = Ca * tile_a + Cb + Cc + Cd + ncls + 1
+    out = torch.empty(logits.shape[:-1] + (Ct,), dtype=torch.float32, device=logits.device)
+    check(lib.pnp_critic_input_fwd(_p(a), Ca, tile_a, _p(b), Cb, _p(c), Cc, _p(d), Cd, _p(logits), ncls, _p(out), P, _stream()),
+          "pnp_critic_input_fwd")
+    return out
+
+
+def critic_input_bwd(dout, shapes, tile_a, need=(True,) * 5):
+    lib = _lib.load()
+    (sa, sb, sc, sd, sl) = shapes
+    P = dout.numel() // dout.shape[-1]
+    mk = lambda s, n: torch.empty(s, dtype=torch.float32, device=dout.device) if n else None
+    da, db, dc, dd, dl = mk(sa, need[0]), mk(sb, need[1]), mk(sc, need[2]), mk(sd, need[3]), mk(sl, need[4])
+    check(lib.pnp_critic_input_bwd(_p(dout), _p(da), sa[-1], tile_a, _p(db), sb[-1], _p(dc), sc[-1], _p(dd), sd[-1], _p(dl), sl[-1],
+                                   P, _stream()), "pnp_critic_input_bwd")
+    return da, db, dc, dd, dl

@@ -1,0 +1,92 @@
+"""Drop-in for the step-path helpers of the reference's lib.py (label one-hot, Dice / Jaccard bookkeeping,
+list reading).  NIfTI I/O and TF checkpoint helpers (lib.py:23-72) are out of scope.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import kernels as K
+
+
+def _read_lists(fid):
+    """lib.py:7-21: text file -> list of lines (blank-ish lines dropped)"""
+    if not os.path.isfile(fid):
+        return None
+    with open(fid, 'r') as fd:
+        lines = fd.readlines()
+    out = []
+    for item in lines:
+        if len(item) < 3:
+            continue
+        out.append(item.split('\n')[0])
+    return out
+
+
+def _label_decomp(num_cls, label_vol):
+    """lib.py:75-92: integer-valued label map [B,H,W] -> one-hot float32 [B,H,W,num_cls]
+    (labels >= num_cls give an all-zero row).  Host-side numpy like the reference (it runs on the dequeued batch)."""
+    label_vol = np.asarray(label_vol)
+    out = np.zeros(label_vol.shape + (num_cls,), dtype=np.float32)
+    for i in range(num_cls):
+        out[..., i][label_vol == i] = 1.0
+    return out
+
+
+def label_decomp_device(num_cls, label_vol):
+    """same as _label_decomp for a device tensor (pure indexing, no arithmetic)"""
+    lab = label_vol.to(torch.float32)
+    cls = torch.arange(num_cls, device=lab.device, dtype=torch.float32)
+    return (lab.unsqueeze(-1) == cls).to(torch.float32).contiguous()
+
+
+def _dice_eval(compact_pred, labels, n_class):
+    """lib.py:96-110: hard Dice of the argmax map vs one-hot labels -> (mean dice, [per-class dice]) on device"""
+    out = K.dice_eval(compact_pred.contiguous(), labels.contiguous())
+    return out[0], [out[1 + i] for i in range(n_class)]
+
+
+def confusion_matrix(compact_y, compact_pred, num_classes):
+    """tf.confusion_matrix(labels, predictions) (source_segmenter.py:85): rows = ground truth, cols = prediction.
+    Monitoring only (every display_step); integer bincount on device."""
+    idx = compact_y.reshape(-1).to(torch.int64) * num_classes + compact_pred.reshape(-1).to(torch.int64)
+    return torch.bincount(idx, minlength=num_classes * num_classes).reshape(num_classes, num_classes).cpu().numpy()
+
+
+def _jaccard(conf_matrix):
+    """lib.py:121-134"""
+    num_cls = conf_matrix.shape[0]
+    jac = np.zeros(num_cls)
+    for ii in range(num_cls):
+        pp = np.sum(conf_matrix[:, ii])
+        gp = np.sum(conf_matrix[ii, :])
+        hit = conf_matrix[ii, ii]
+        jac[ii] = 0 if (pp + gp - hit) == 0 else hit * 1.0 / (pp + gp - hit)
+    return jac
+
+
+def _dice(conf_matrix):
+    """lib.py:137-151"""
+    num_cls = conf_matrix.shape[0]
+    dic = np.zeros(num_cls)
+    for ii in range(num_cls):
+        pp = np.sum(conf_matrix[:, ii])
+        gp = np.sum(conf_matrix[ii, :])
+        hit = conf_matrix[ii, ii]
+        dic[ii] = 0 if (pp + gp) == 0 else 2.0 * hit / (pp + gp)
+    return dic
+
+
+def _indicator_eval(cm, verbose=True):
+    """lib.py:155-176"""
+    contour_map = {"bg": 0, "la_myo": 1, "la_blood": 2, "lv_blood": 3, "aa": 4}
+    dice = _dice(cm)
+    jaccard = _jaccard(cm)
+    if verbose:
+        print(cm)
+        for organ, ind in list(contour_map.items()):
+            if ind < len(dice):
+                print("organ: %s" % organ)
+                print("dice: %s" % dice[int(ind)])
+                print("jaccard: %s" % jaccard[int(ind)])
+    return dice, jaccard

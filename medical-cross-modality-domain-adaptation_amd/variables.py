@@ -1,0 +1,207 @@
+"""Variable store: the eager stand-in for the TF-1.4 default graph's variable collections.
+
+The reference creates variables while it builds the graph (`layers.weight_variable`, layers.py:47-55;
+`tf.contrib.layers.batch_norm` variables, layers.py:100) and later groups them BY NAME
+(adversarial.py:478-501, 654).  Names therefore are part of the API: this store reproduces TF's
+naming (`group_1/Variable_2`, `BatchNorm_7/gamma`, `cls_scope/cls_1/...`) and keeps all float32 state in
+flat arenas so that the optimiser, the weight clip and the gradient all-reduce each run as ONE launch /
+ONE collective over contiguous memory (PNP_OPT_CHUNK-aligned segments).
+"""
+import contextlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from ._lib import OPT_CHUNK
+
+_current = None
+
+
+def current_store():
+    if _current is None:
+        raise RuntimeError("no active VariableStore: wrap graph-building code in `with store.as_default():`")
+    return _current
+
+
+class Var(object):
+    __slots__ = ("name", "shape", "trainable", "kind", "tensor", "offset", "numel", "l2_mult")
+
+    def __init__(self, name, shape, trainable, kind):
+        self.name, self.shape, self.trainable, self.kind = name, tuple(shape), trainable, kind
+        self.tensor = None
+        self.offset = -1
+        self.numel = int(np.prod(shape)) if len(shape) else 1
+        self.l2_mult = 0.0
+
+
+def truncated_normal(rng, shape, stddev):
+    """tf.truncated_normal: N(0, stddev) with samples beyond 2 sigma re-drawn (layers.py:48)."""
+    out = rng.standard_normal(size=shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return (out * stddev).astype(np.float32)
+
+
+class VariableStore(object):
+    def __init__(self, device, seed=0):
+        self.device = torch.device(device)
+        self.vars = OrderedDict()
+        self.rng = np.random.default_rng(seed)
+        self._nscope = []         # tf.name_scope stack: prefixes tf.Variable names (weight_variable)
+        self._vscope = []         # tf.variable_scope stack: prefixes get_variable / batch_norm names
+        self._uniq = {}           # per-trace unique-name counters
+        self.finalized = False
+        self.arena = None         # flat fp32: all trainable values, chunk aligned
+        self.grad_arena = None
+        self.state_arena = None   # non-trainable float state (BN moving stats, frozen weights)
+        # dropout stream: seed changes per step, stream id per conv call site within a step
+        self.drop_seed = 0
+        self._drop_stream = 0
+
+    # ---- scoping / naming (TF semantics) -----------------------------------------------------
+    @contextlib.contextmanager
+    def as_default(self):
+        global _current
+        prev = _current
+        _current = self
+        try:
+            yield self
+        finally:
+            _current = prev
+
+    @contextlib.contextmanager
+    def name_scope(self, name):
+        """tf.name_scope: affects tf.Variable (weight_variable) names only (source_segmenter.py:91...)."""
+        self._nscope.append(name)
+        try:
+            yield
+        finally:
+            self._nscope.pop()
+
+    @contextlib.contextmanager
+    def variable_scope(self, name):
+        """tf.variable_scope: affects get_variable / batch_norm names AND opens a name scope (adversarial.py:130...)."""
+        self._vscope.append(name)
+        self._nscope.append(name)
+        try:
+            yield
+        finally:
+            self._nscope.pop()
+            self._vscope.pop()
+
+    def begin_trace(self, drop_seed=None):
+        """call at the start of every forward pass: unique-name counters restart so the k-th anonymous
+        variable of a scope resolves to the same variable as in the build pass (graph re-use)."""
+        self._uniq = {}
+        self._drop_stream = 0
+        if drop_seed is not None:
+            self.drop_seed = int(drop_seed)
+
+    def next_drop_stream(self):
+        s = self._drop_stream
+        self._drop_stream += 1
+        return s
+
+    def _prefix(self, var_scope):
+        return "/".join(s for s in (self._vscope if var_scope else self._nscope) if s)
+
+    def unique(self, base, var_scope=False):
+        """TF unique_name: base, base_1, base_2, ... under the current name scope (or variable scope)."""
+        pre = self._prefix(var_scope)
+        key = (pre, base, var_scope)
+        k = self._uniq.get(key, 0)
+        self._uniq[key] = k + 1
+        leaf = base if k == 0 else "%s_%d" % (base, k)
+        return (pre + "/" + leaf) if pre else leaf
+
+    def scoped(self, leaf):
+        """name of a get_variable-style variable in the current variable scope"""
+        pre = self._prefix(True)
+        return (pre + "/" + leaf) if pre else leaf
+
+    # ---- creation / lookup ------------------------------------------------------------------------
+    def get(self, name, shape=None, init=None, trainable=True, kind="weight"):
+        v = self.vars.get(name)
+        if v is not None:
+            if shape is not None and tuple(shape) != v.shape:
+                raise ValueError("variable %s exists with shape %s, requested %s" % (name, v.shape, tuple(shape)))
+            return v
+        if self.finalized:
+            raise RuntimeError("variable %s requested after the store was finalized" % name)
+        if shape is None:
+            raise KeyError(name)
+        v = Var(name, shape, trainable, kind)
+        if init is None:
+            host = np.zeros(shape, dtype=np.float32)
+        elif callable(init):
+            host = np.asarray(init(self.rng, tuple(shape)), dtype=np.float32)
+        else:
+            host = np.full(shape, float(init), dtype=np.float32)
+        v.tensor = torch.from_numpy(np.ascontiguousarray(host)).to(self.device)
+        self.vars[name] = v
+        return v
+
+    def finalize(self):
+        """Pack every variable into chunk-aligned flat arenas (trainable -> arena(+grad), others -> state arena)."""
+        if self.finalized:
+            return
+        tr = [v for v in self.vars.values() if v.trainable]
+        st = [v for v in self.vars.values() if not v.trainable]
+
+        def pack(vs):
+            off = 0
+            for v in vs:
+                v.offset = off
+                off += -(-v.numel // OPT_CHUNK) * OPT_CHUNK
+            flat = torch.zeros(max(off, OPT_CHUNK), dtype=torch.float32, device=self.device)
+            for v in vs:
+                flat[v.offset:v.offset + v.numel].copy_(v.tensor.reshape(-1))
+                v.tensor = flat[v.offset:v.offset + v.numel].view(v.shape)
+            return flat
+
+        self.arena = pack(tr)
+        self.state_arena = pack(st)
+        self.grad_arena = torch.zeros_like(self.arena)
+        for v in tr:
+            t = v.tensor.detach()
+            t.requires_grad_(True)
+            t.grad = self.grad_arena[v.offset:v.offset + v.numel].view(v.shape)
+            v.tensor = t
+        self.finalized = True
+
+    # ---- helpers for the optimisers ---------------------------------------------------------------
+    def trainable(self):
+        return [v for v in self.vars.values() if v.trainable]
+
+    def chunk_table(self, fn, dtype):
+        """per-chunk table over the trainable arena: value fn(var) for every chunk the variable covers"""
+        n = self.arena.numel() // OPT_CHUNK
+        tab = np.zeros(n, dtype=dtype)
+        for v in self.trainable():
+            c0 = v.offset // OPT_CHUNK
+            c1 = c0 + -(-v.numel // OPT_CHUNK)
+            tab[c0:c1] = fn(v)
+        return torch.from_numpy(tab).to(self.device)
+
+    def zero_grad(self):
+        self.grad_arena.zero_()
+
+    def state_dict(self):
+        return OrderedDict((k, v.tensor.detach().cpu().numpy().copy()) for k, v in self.vars.items())
+
+    def load_state_dict(self, sd, strict=True):
+        for k, arr in sd.items():
+            if k not in self.vars:
+                if strict:
+                    raise KeyError("unexpected variable %s" % k)
+                continue
+            v = self.vars[k]
+            with torch.no_grad():
+                v.tensor.copy_(torch.from_numpy(np.asarray(arr, dtype=np.float32)).reshape(v.shape))
+        if strict:
+            missing = [k for k in self.vars if k not in sd]
+            if missing:
+                raise KeyError("missing variables: %s" % missing[:5])

@@ -1,0 +1,276 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of the TensorFlow-1.4 op semantics that the reference's
+hot path lowers to.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package; the product path (medical-cross-modality-domain-adaptation_amd/) never does.
+
+PARITY UNPINNED: the reference ships no tests / golden vectors, and TensorFlow 1.4 (an un-vendored pip
+dependency: tensorflow-gpu==1.4.0, reference README.md:24) cannot be installed here, so the arithmetic below
+is restated from TF's documented/known semantics, not checked against a TF run.  What IS pinned to the
+reference's own code: the op SEQUENCES (ops.PS, layers.*, Full_DRN.create_network, lib._label_decomp), by
+executing the reference's Python over a numpy stand-in for `tf` (tests/golden/make_golden.py).
+
+Everything works on torch CPU tensors in NHWC, dtype float32 or float64 (pass float64 tensors for the
+high-precision adjudicator), and is differentiable through torch autograd (= TF autodiff of the same graph).
+Each function cites the reference call site (file:line under /root/reference) and the TF op it restates.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3      # tf.contrib.layers.batch_norm default epsilon (layers.py:100)
+BN_DECAY = 0.90    # layers.py:100
+LEAK = 0.2         # tf.nn.leaky_relu default alpha (layers.py:12,35,166,187)
+
+
+# ---- padding arithmetic --------------------------------------------------------------------------------
+def same_pad(in_size, k, stride, dil=1):
+    """TF 'SAME' (tf.nn.conv2d / max_pool): out = ceil(in/stride); total = max((out-1)*stride + (k-1)*dil + 1 - in, 0);
+    pad_before = total // 2, the remainder goes after (asymmetric for even totals... odd totals put the extra after)."""
+    out = -(-in_size // stride)
+    eff = (k - 1) * dil + 1
+    total = max((out - 1) * stride + eff - in_size, 0)
+    return out, total // 2, total - total // 2
+
+
+def sym_index(n, p):
+    """index vector of tf.pad(..., 'SYMMETRIC') along one axis: mirror INCLUDING the edge sample"""
+    return list(range(p - 1, -1, -1)) + list(range(n)) + list(range(n - 1, n - 1 - p, -1))
+
+
+def pad_symmetric(x, ph, pw):
+    """tf.pad(x, [[0,0],[ph,ph],[pw,pw],[0,0]], 'SYMMETRIC') (layers.py:23,72,91)"""
+    ih = torch.tensor(sym_index(x.shape[1], ph), dtype=torch.long)
+    iw = torch.tensor(sym_index(x.shape[2], pw), dtype=torch.long)
+    return x.index_select(1, ih).index_select(2, iw)
+
+
+# ---- convolution ---------------------------------------------------------------------------------------
+def conv2d(x, w, stride=1, dil=1, padding="SAME"):
+    """tf.nn.conv2d (NHWC x HWIO, cross-correlation) / tf.nn.atrous_conv2d(rate=dil) (layers.py:18,24,67,73,86,92).
+    padding: 'SAME' (TF asymmetric rule), 'SYMMETRIC' (mirror-pad k//2 then VALID), 'VALID'."""
+    R, S = w.shape[0], w.shape[1]
+    if padding == "SYMMETRIC":
+        x = pad_symmetric(x, R // 2, S // 2)
+        pads = (0, 0, 0, 0)
+    elif padding == "SAME":
+        _, pt, pb = same_pad(x.shape[1], R, stride, dil)
+        _, pl, pr = same_pad(x.shape[2], S, stride, dil)
+        pads = (pl, pr, pt, pb)
+    elif padding == "VALID":
+        pads = (0, 0, 0, 0)
+    else:
+        raise ValueError(padding)
+    xn = x.permute(0, 3, 1, 2)
+    if any(pads):
+        xn = F.pad(xn, pads)
+    wn = w.permute(3, 2, 0, 1)
+    y = F.conv2d(xn, wn, None, stride=stride, padding=0, dilation=dil)
+    return y.permute(0, 2, 3, 1)
+
+
+def conv2d_direct_np(x, w, stride=1, dil=1, padding="SAME"):
+    """From-the-definition float64 loop nest (numpy) — an implementation-independent check of conv2d() above for
+    small shapes (pure-Python loops over taps only)."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    N, H, W, C = x.shape
+    R, S, _, K = w.shape
+    if padding == "SYMMETRIC":
+        x = np.pad(x, ((0, 0), (R // 2, R // 2), (S // 2, S // 2), (0, 0)), mode="symmetric")
+        pt = pl = 0
+        OH = (x.shape[1] - ((R - 1) * dil + 1)) // stride + 1
+        OW = (x.shape[2] - ((S - 1) * dil + 1)) // stride + 1
+    elif padding == "SAME":
+        OH, pt, pb = same_pad(H, R, stride, dil)
+        OW, pl, pr = same_pad(W, S, stride, dil)
+        x = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+        pt = pl = 0
+    else:
+        pt = pl = 0
+        OH = (H - ((R - 1) * dil + 1)) // stride + 1
+        OW = (W - ((S - 1) * dil + 1)) // stride + 1
+    y = np.zeros((N, OH, OW, K), dtype=np.float64)
+    for r in range(R):
+        for s in range(S):
+            patch = x[:, r * dil: r * dil + (OH - 1) * stride + 1: stride, s * dil: s * dil + (OW - 1) * stride + 1: stride, :]
+            y += np.einsum("nhwc,ck->nhwk", patch, w[r, s])
+    return y
+
+
+# ---- dropout (mask stream is the product's documented counter hash; see csrc/pnp_common.h) -------------------
+def _fmix32(h):
+    h = h.astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    h = (h * np.uint32(0x85EBCA6B)).astype(np.uint32)
+    h ^= h >> np.uint32(13)
+    h = (h * np.uint32(0xC2B2AE35)).astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    return h
+
+
+def drop_key(seed, stream_id):
+    lo = np.uint32(seed & 0xFFFFFFFF)
+    hi = np.uint32((seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        k = _fmix32(np.array([np.uint32(hi + np.uint32(0x9E3779B9) * np.uint32(stream_id + 1))], dtype=np.uint32))[0]
+        return _fmix32(np.array([lo ^ k], dtype=np.uint32))[0]
+
+
+def drop_thresh(keep):
+    t = (1.0 - float(np.float32(keep))) * 16777216.0 + 0.5
+    return np.uint32(min(max(t, 0.0), 16777216.0))
+
+
+def dropout_mask(shape, keep_prob, seed, stream_id):
+    """float32 {0,1} keep mask: tf.nn.dropout's floor(keep + u) restated on the product's counter hash
+    mask(idx) = (fmix32((idx*0xCC9E2D51) ^ key) >> 8) >= round((1-keep)*2^24)"""
+    n = int(np.prod(shape))
+    if keep_prob >= 1.0:
+        return np.ones(shape, dtype=np.float32)
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint32)
+        h = _fmix32((idx * np.uint32(0xCC9E2D51)) ^ drop_key(seed, stream_id))
+    return ((h >> np.uint32(8)) >= drop_thresh(keep_prob)).astype(np.float32).reshape(shape)
+
+
+def dropout(x, keep_prob, seed=0, stream_id=0, mask=None):
+    """tf.nn.dropout (layers.py:25,74,93): x * mask / keep"""
+    if keep_prob >= 1.0:
+        return x
+    if mask is None:
+        mask = dropout_mask(tuple(x.shape), keep_prob, seed, stream_id)
+    m = torch.from_numpy(mask).to(x.dtype)
+    return x * m * (1.0 / float(np.float32(keep_prob)) if x.dtype == torch.float32 else 1.0 / keep_prob)
+
+
+# ---- batch norm ------------------------------------------------------------------------------------------
+def batch_norm(x, gamma, beta, moving_mean, moving_var, is_training, update_moving=True):
+    """tf.contrib.layers.batch_norm(decay=.9, center, scale, eps=1e-3, updates_collections=None) (layers.py:95-100),
+    fused-batch-norm semantics: normalise with the biased batch variance; the moving variance receives the
+    Bessel-corrected one; moving stats are updated in place on every training-mode execution.
+    moving_mean / moving_var are updated IN PLACE (torch tensors, no grad)."""
+    if is_training:
+        red = (0, 1, 2)
+        n = x.shape[0] * x.shape[1] * x.shape[2]
+        mean = x.mean(dim=red)
+        var = ((x - mean) ** 2).mean(dim=red)
+        if update_moving:
+            with torch.no_grad():
+                bessel = n / (n - 1.0) if n > 1 else 1.0
+                moving_mean -= (moving_mean - mean.detach().to(moving_mean.dtype)) * (1.0 - BN_DECAY)
+                moving_var -= (moving_var - (var.detach() * bessel).to(moving_var.dtype)) * (1.0 - BN_DECAY)
+    else:
+        mean, var = moving_mean.to(x.dtype), moving_var.to(x.dtype)
+    return (x - mean) * (gamma * torch.rsqrt(var + BN_EPS)) + beta
+
+
+def leaky_relu(x, alpha=LEAK):
+    """tf.nn.leaky_relu = max(alpha*x, x); gradient alpha at x == 0 (LeakyReluGrad uses features > 0)"""
+    return torch.where(x > 0, x, x * alpha)
+
+
+def max_pool2(x):
+    """tf.nn.max_pool(ksize 2, strides 2, SAME) (layers.py:102-103), even H/W"""
+    return F.max_pool2d(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+
+
+def pad_channels(x, c_each):
+    """tf.pad(x, [[0,0],[0,0],[0,0],[c,c]]) (layers.py:159-160, 181-182)"""
+    return F.pad(x, (c_each, c_each))
+
+
+def PS(x, r, nc):
+    """closed form of ops.PS for batch >= 2 (ops.py:3-27): out[n, i*r+u, j*r+v, c] = x[n,i,j, c*r*r + v*r + u]"""
+    N, A, B, _ = x.shape
+    t = x.reshape(N, A, B, nc, r, r)          # [n,i,j,c,v,u]
+    t = t.permute(0, 1, 5, 2, 4, 3)           # [n,i,u,j,v,c]
+    return t.reshape(N, A * r, B * r, nc)
+
+
+# ---- losses ------------------------------------------------------------------------------------------------
+def softmax_weighted_loss(logits, y):
+    """Full_DRN._softmax_weighted_loss (source_segmenter.py:241-258)"""
+    p = torch.softmax(logits, dim=-1)
+    ncls = logits.shape[-1]
+    raw = 0
+    ytot = y.sum()
+    for i in range(ncls):
+        gti = y[..., i]
+        weighted = 1 - (gti.sum() / ytot)
+        raw = raw + (-1.0 * weighted * gti * torch.log(torch.clamp(p[..., i], 0.005, 1)))
+    return raw.mean()
+
+
+def dice_loss(logits, y):
+    """Full_DRN._dice_loss_fun (source_segmenter.py:260-273)"""
+    p = torch.softmax(logits, dim=-1)
+    ncls = logits.shape[-1]
+    dice = 0
+    for i in range(ncls):
+        inse = (p[..., i] * y[..., i]).sum()
+        l = (p[..., i] * p[..., i]).sum()
+        r = y[..., i].sum()
+        dice = dice + 2.0 * inse / (l + r + 1e-7)
+    return -1.0 * dice / ncls
+
+
+def pixel_wise_softmax_2(z):
+    """layers.pixel_wise_softmax_2 (layers.py:134-138): exp(z)/sum exp(z), NO max subtraction, clipped to +-1e15"""
+    e = torch.exp(z)
+    return torch.clamp(e / e.sum(dim=-1, keepdim=True), -1e15, 1e15)
+
+
+def argmax_lowest(p):
+    """tf.argmax(p, 3): lowest index on ties"""
+    pn = p.detach().cpu().numpy()
+    return torch.from_numpy(np.argmax(pn, axis=-1).astype(np.int64))
+
+
+def dice_eval(compact_pred, y, ncls):
+    """lib._dice_eval (lib.py:96-110)"""
+    pred = F.one_hot(compact_pred, ncls).to(y.dtype)
+    arr = []
+    tot = 0
+    for i in range(ncls):
+        inse = (pred[..., i] * y[..., i]).sum()
+        union = pred[..., i].sum() + y[..., i].sum()
+        d = 2.0 * inse / (union + 1e-7)
+        arr.append(d)
+        tot = tot + d
+    return tot / ncls, arr
+
+
+def label_decomp(num_cls, label_vol):
+    """lib._label_decomp (lib.py:75-92)"""
+    label_vol = np.asarray(label_vol)
+    vol = np.zeros(label_vol.shape + (num_cls,), dtype=np.float32)
+    for i in range(num_cls):
+        vol[..., i][label_vol == i] = 1
+    return vol
+
+
+def l2_loss(w):
+    """tf.nn.l2_loss = sum(w^2)/2 (source_segmenter.py:237)"""
+    return (w * w).sum() / 2
+
+
+# ---- optimisers (in-place on torch tensors, no autograd) --------------------------------------------------------
+def adam_update(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer._apply_dense: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; w -= lr_t*m/(sqrt(v)+eps)"""
+    lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    m += (g - m) * (1 - beta1)
+    v += (g * g - v) * (1 - beta2)
+    w -= lr_t * m / (torch.sqrt(v) + eps)
+
+
+def rmsprop_update(w, g, ms, lr, decay=0.9, eps=1e-10):
+    """tf.train.RMSPropOptimizer(momentum=0): ms init 1.0; ms = decay*ms + (1-decay)*g^2; w -= lr*g/sqrt(ms+eps)"""
+    ms += (g * g - ms) * (1 - decay)
+    w -= lr * g / torch.sqrt(ms + eps)
+
+
+def momentum_update(w, g, acc, lr, momentum):
+    """tf.train.MomentumOptimizer: acc = momentum*acc + g; w -= lr*acc"""
+    acc.mul_(momentum).add_(g)
+    w -= lr * acc

@@ -1,0 +1,128 @@
+"""-m gpu: the MFMA implicit-GEMM convolution (fwd / dgrad / wgrad) through the C-ABI vs the CPU oracle.
+Tolerance: fp32, max-abs error <= 2e-5 * sum_k |a_k*b_k| bound, reported relative to max|ref| (north_star: 1e-4 rel)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# (N,H,W,C,K,R,stride,dil,padding)  — every conv shape class on the reference path, spatially reduced
+CASES = [
+    (2, 16, 16, 3, 16, 3, 1, 1, "SAME"),        # g1 conv1_1: C=3 scalar loader, K=16 tile
+    (2, 16, 16, 16, 16, 3, 1, 1, "SAME"),       # wr1_x: C=16 (vec4 generic), K<32
+    (2, 16, 16, 16, 32, 3, 1, 1, "SAME"),       # wr2_1
+    (2, 12, 12, 32, 64, 3, 1, 1, "SAME"),       # wr3_1 (odd-ish spatial, M not multiple of 128)
+    (2, 8, 8, 64, 128, 3, 1, 1, "SAME"),        # wr4_1
+    (1, 8, 8, 128, 256, 3, 1, 1, "SAME"),       # wr5_1
+    (1, 8, 8, 256, 512, 3, 1, 1, "SAME"),       # wr7_1
+    (1, 8, 8, 512, 512, 3, 1, 2, "SAME"),       # g8 dilated
+    (1, 6, 6, 512, 2560, 3, 1, 1, "SYMMETRIC"), # g10 (reduced spatial)
+    (2, 24, 24, 40, 5, 5, 1, 1, "SYMMETRIC"),   # output conv 5x5, C=40, K=5 (scalar B path)
+    (2, 16, 16, 64, 64, 3, 2, 1, "SAME"),       # critic k3 s2 (asymmetric SAME pad 0,1)
+    (2, 16, 16, 128, 128, 5, 2, 1, "SAME"),     # critic k5 s2 (pad 1,2)
+    (2, 16, 16, 512, 512, 5, 4, 1, "SAME"),     # critic k5 s4 (pad 0,1)
+    (2, 4, 4, 512, 512, 3, 2, 1, "SYMMETRIC"),  # cls_6
+    (2, 16, 16, 5, 16, 3, 2, 1, "SAME"),        # mask critic C=5
+    (2, 1, 1, 2048, 1, 1, 1, 1, "VALID"),       # FC as 1x1 conv (adversarial.py:395-397)
+    (3, 9, 7, 20, 24, 3, 1, 1, "SAME"),         # ragged everything
+]
+
+
+def _mk(case, seed=0):
+    N, H, W, C, K, R, stride, dil, padding = case
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    w = (rng.standard_normal((R, R, C, K)) / np.sqrt(R * R * C)).astype(np.float32)
+    return x, w, stride, dil, padding
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    K = pkg("kernels")
+    x, w, stride, dil, padding = _mk(case)
+    g = K.conv_geom(x.shape, w.shape, stride, dil, padding)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    wt = torch.from_numpy(w).requires_grad_(True)
+    yo = T.conv2d(xt, wt, stride, dil, padding)
+    assert tuple(yo.shape) == (g.N, g.OH, g.OW, g.K)
+    dy = torch.from_numpy(np.random.default_rng(1).standard_normal(tuple(yo.shape)).astype(np.float32))
+    yo.backward(dy)
+
+    xd, wd, dyd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), dy.to(dev)
+    y = K.conv2d_fwd(xd, wd, g)
+    yn = K.conv2d_fwd(xd, wd, g, naive=True)
+    dx = K.conv2d_dgrad(dyd, wd, g)
+    dw = K.conv2d_wgrad(xd, dyd, g)
+    torch.cuda.synchronize()
+    errs = dict(naive=_rel(yn, yo), y=_rel(y, yo), dx=_rel(dx, xt.grad), dw=_rel(dw, wt.grad))
+    print(case, errs)
+    assert errs["naive"] < TOL, errs
+    assert errs["y"] < TOL, errs
+    assert errs["dx"] < TOL, errs
+    assert errs["dw"] < TOL, errs
+
+
+def test_conv_transpose_detecting(dev):
+    """A = identity-like input with ASYMMETRIC weights: catches row/col swaps in the MFMA C/D mapping"""
+    K = pkg("kernels")
+    N, H, W, C, Kc = 1, 16, 16, 64, 96
+    x = np.zeros((N, H, W, C), np.float32)
+    for i in range(H * W):
+        x[0, i // W, i % W, i % C] = 1.0 + (i % 7)
+    w = np.zeros((1, 1, C, Kc), np.float32)
+    for c in range(C):
+        for k in range(Kc):
+            w[0, 0, c, k] = c * 0.01 + k * 1.0
+    g = K.conv_geom(x.shape, w.shape, 1, 1, "SAME")
+    y = K.conv2d_fwd(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), g).cpu().numpy()
+    ref = np.einsum("nhwc,ck->nhwk", x.astype(np.float64), w[0, 0].astype(np.float64))
+    assert np.abs(y - ref).max() < 1e-3 * np.abs(ref).max()
+
+
+def test_dropout_epilogue_matches_oracle_mask(dev):
+    K = pkg("kernels")
+    x, w, stride, dil, padding = _mk((2, 16, 16, 32, 64, 3, 1, 1, "SAME"))
+    g = K.conv_geom(x.shape, w.shape, stride, dil, padding)
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    y0 = K.conv2d_fwd(xd, wd, g).cpu()
+    y1 = K.conv2d_fwd(xd, wd, g, keep_prob=0.75, seed=1234567, stream_id=5).cpu()
+    mask = T.dropout_mask(tuple(y0.shape), 0.75, 1234567, 5)
+    ref = y0 * torch.from_numpy(mask) * np.float32(1.0 / np.float32(0.75))
+    assert torch.equal(y1 != 0, (torch.from_numpy(mask) != 0) & (y0 != 0))
+    assert _rel(y1, ref) < 1e-6
+    assert abs(mask.mean() - 0.75) < 0.01
+    # the standalone dropout kernel (used in backward) draws the same stream
+    y2 = K.dropout(xd.new_tensor(y0.numpy()), 0.75, 1234567, 5).cpu()
+    assert _rel(y2, ref) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 32, 512, 512, 3, 1, "SAME"), (16, 256, 256, 16, 16, 3, 1, "SAME"),
+                                   (16, 256, 256, 64, 64, 3, 1, "SAME"), (4, 32, 32, 512, 2560, 3, 1, "SYMMETRIC")])
+def test_conv_full_size_vs_naive_kernel(dev, shape):
+    """BASELINE sizes: MFMA kernel vs the one-thread-per-output fmaf kernel on device (the CPU oracle is too slow here)
+    + linearity property conv(a*x1 + x2) == a*conv(x1) + conv(x2)."""
+    K = pkg("kernels")
+    N, H, W, C, Kc, R, dil, padding = shape
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn((N, H, W, C), generator=gen).to(dev)
+    x2 = torch.randn((N, H, W, C), generator=gen).to(dev)
+    w = (torch.randn((R, R, C, Kc), generator=gen) / np.sqrt(R * R * C)).to(dev)
+    g = K.conv_geom(tuple(x.shape), tuple(w.shape), 1, dil, padding)
+    y = K.conv2d_fwd(x, w, g)
+    yn = K.conv2d_fwd(x, w, g, naive=True)
+    assert _rel(y, yn) < 2e-5
+    y2 = K.conv2d_fwd(x2, w, g)
+    ylin = K.conv2d_fwd(x * 0.5 + x2, w, g)
+    assert _rel(ylin, y * 0.5 + y2) < 2e-5
