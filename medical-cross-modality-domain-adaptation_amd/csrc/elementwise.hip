@@ -141,14 +141,28 @@ __global__ void colreduce_scalar_kernel(ColArgs a) {
 
 // final combine over blocks in double. KIND 0 -> mean,var ; KIND 1 -> dbeta (o0), dgamma (o1)
 template <int KIND>
-__global__ void colreduce_final_kernel(const float* __restrict__ ws, const float* __restrict__ x0, float* o0, float* o1,
-                                       int nblk, int C, long long P) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(1024) colreduce_final_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
+                                                               float* o0, float* o1, int nblk, int C, long long P) {
+    // 1024 threads = 32 channels x 32 slices of the block list; fixed summation order => deterministic
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s0 += (double)ws[((size_t)b * 2 + 0) * C + c];
-        s1 += (double)ws[((size_t)b * 2 + 1) * C + c];
+    if (c < C) {
+        for (int b = sl; b < nblk; b += 32) {
+            s0 += (double)ws[((size_t)b * 2 + 0) * C + c];
+            s1 += (double)ws[((size_t)b * 2 + 1) * C + c];
+        }
+    }
+    red[0][sl][cl] = s0;
+    red[1][sl][cl] = s1;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    s0 = 0.0;
+    s1 = 0.0;
+    for (int j = 0; j < 32; ++j) {
+        s0 += red[0][j][cl];
+        s1 += red[1][j][cl];
     }
     if constexpr (KIND == 0) {
         const double inv = 1.0 / (double)P;
@@ -193,7 +207,7 @@ int run_colreduce(ColArgs a, float* o0, float* o1, void* ws, size_t ws_bytes, hi
         hipLaunchKernelGGL(colreduce_scalar_kernel<KIND>, dim3(nblk, pnp_cdiv(a.C, 64)), dim3(64), 0, st, a);
     }
     PNP_CHECK_LAUNCH(who);
-    hipLaunchKernelGGL(colreduce_final_kernel<KIND>, dim3(pnp_cdiv(a.C, 64)), dim3(64), 0, st, (const float*)ws, a.x, o0,
+    hipLaunchKernelGGL(colreduce_final_kernel<KIND>, dim3(pnp_cdiv(a.C, 32)), dim3(1024), 0, st, (const float*)ws, a.x, o0,
                        o1, nblk, a.C, a.P);
     PNP_CHECK_LAUNCH(who);
     return PNP_OK;
@@ -440,18 +454,32 @@ __global__ void __launch_bounds__(NT) ps_kernel(const float* __restrict__ src, f
     const size_t total = (size_t)N * A * B * Cin;
     const size_t gs = (size_t)gridDim.x * NT;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += gs) {
-        // decode i in the fine (output) layout [N][A*r][B*r][nc]
-        const int c = (int)(i % nc);
-        size_t q = i / nc;
-        const int wo = (int)(q % (B * r));
-        q /= (B * r);
-        const int ho = (int)(q % (A * r));
-        const int n = (int)(q / (A * r));
-        const int ii = ho / r, u = ho - ii * r;
-        const int jj = wo / r, v = wo - jj * r;
-        const size_t coarse = (((size_t)n * A + ii) * B + jj) * Cin + (size_t)c * r * r + v * r + u;
-        if constexpr (!BWD) dst[i] = src[coarse];
-        else dst[coarse] = src[i];
+        if constexpr (!BWD) {
+            // decode i in the fine (output) layout [N][A*r][B*r][nc]
+            const int c = (int)(i % nc);
+            size_t q = i / nc;
+            const int wo = (int)(q % (B * r));
+            q /= (B * r);
+            const int ho = (int)(q % (A * r));
+            const int n = (int)(q / (A * r));
+            const int ii = ho / r, u = ho - ii * r;
+            const int jj = wo / r, v = wo - jj * r;
+            const size_t coarse = (((size_t)n * A + ii) * B + jj) * Cin + (size_t)c * r * r + v * r + u;
+            dst[i] = src[coarse];
+        } else {
+            // decode i in the coarse (input-gradient) layout [N][A][B][nc*r*r]: coalesced stores, gathered loads
+            const int cc = (int)(i % Cin);
+            size_t q = i / Cin;
+            const int jj = (int)(q % B);
+            q /= B;
+            const int ii = (int)(q % A);
+            const int n = (int)(q / A);
+            const int c = cc / (r * r);
+            const int vu = cc - c * r * r;
+            const int v = vu / r, u = vu - v * r;
+            const size_t fine = (((size_t)n * A * r + ii * r + u) * (B * r) + jj * r + v) * nc + c;
+            dst[i] = src[fine];
+        }
     }
 }
 

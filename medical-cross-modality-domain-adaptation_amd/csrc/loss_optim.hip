@@ -79,11 +79,20 @@ __global__ void __launch_bounds__(NT) seg_loss_partial_kernel(const float* __res
 // ws layout: double sums[32] | float partials[nblk][32]
 __global__ void seg_loss_final_kernel(const float* __restrict__ part, double* __restrict__ sums, float* __restrict__ out,
                                       int nblk, long long P, int ncls, float miu_cross, float miu_dice) {
+    // launched with 1024 threads = 32 sums x 32 slices of the block list (fixed order => deterministic)
     __shared__ double s[4 * MAXC];
+    __shared__ double red[32][33];
     const int t = threadIdx.x;
+    const int q = t & 31, sl = t >> 5;
+    {
+        double a = 0.0;
+        for (int b = sl; b < nblk; b += 32) a += (double)part[(size_t)b * 4 * MAXC + q];
+        red[sl][q] = a;
+    }
+    __syncthreads();
     if (t < 4 * MAXC) {
         double a = 0.0;
-        for (int b = 0; b < nblk; ++b) a += (double)part[(size_t)b * 4 * MAXC + t];
+        for (int j = 0; j < 32; ++j) a += red[j][t];
         s[t] = a;
         sums[t] = a;
     }
@@ -329,7 +338,7 @@ int pnp_seg_loss_fwd(const float* logits, const float* y, float* out, int64_t P,
     float* part = (float*)((char*)workspace + 256);
     hipLaunchKernelGGL(seg_loss_partial_kernel, dim3(nblk), dim3(NT), 0, st, logits, y, part, (long long)P, ncls);
     PNP_CHECK_LAUNCH("seg_loss_partial_kernel");
-    hipLaunchKernelGGL(seg_loss_final_kernel, dim3(1), dim3(64), 0, st, (const float*)part, sums, out, nblk, (long long)P, ncls,
+    hipLaunchKernelGGL(seg_loss_final_kernel, dim3(1), dim3(1024), 0, st, (const float*)part, sums, out, nblk, (long long)P, ncls,
                        miu_cross, miu_dice);
     PNP_CHECK_LAUNCH("seg_loss_final_kernel");
     return PNP_OK;

@@ -1,0 +1,117 @@
+"""Data parallelism for the training step: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+The reference is single-GPU (train_segmenter.py:20 / train_gan.py:18 pin CUDA_VISIBLE_DEVICES); sharding the mini-batch
+over the 8 GPUs of a node is new functionality required by BASELINE.json.  Design:
+  * every rank holds a full replica (weights, optimiser state) and B/W slices of each batch; dropout streams are
+    decorrelated by rank (seed + rank);
+  * gradients live in ONE flat fp32 arena (variables.VariableStore.grad_arena), written in place by autograd;
+    the arena is cut into ~32 MiB buckets in REVERSE variable order, and each bucket is all-reduced (sum) on a side HIP
+    stream as soon as the last gradient inside it has been produced, overlapping the rest of the backward pass;
+  * the 1/W average is folded into the loss-gradient kernel (gscale), so the reduced arena feeds the optimiser directly;
+  * BatchNorm uses per-replica statistics (like every DP framework); batch-global loss normalisers are per replica too.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world_size)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class GradReducer(object):
+    """Bucketed, backward-overlapped gradient all-reduce over a VariableStore's flat gradient arena."""
+
+    def __init__(self, store, bucket_bytes=32 << 20, overlap=True, group=None):
+        self.store = store
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.overlap = overlap and self.world > 1 and store.arena.is_cuda
+        self.buckets = []       # (start, end) element ranges of the arena, in reverse variable order
+        self._pending = []      # outstanding work handles
+        self._remaining = []
+        self._var_bucket = {}
+        tr = store.trainable()
+        # buckets: walk variables from the LAST created (first gradient to be ready) to the first
+        cur_end = None
+        cur_start = None
+        members = []
+        limit = max(int(bucket_bytes) // 4, 1)
+        from ._lib import OPT_CHUNK
+        for v in reversed(tr):
+            seg_start = v.offset
+            seg_end = v.offset + -(-v.numel // OPT_CHUNK) * OPT_CHUNK
+            if cur_end is None:
+                cur_end, cur_start, members = seg_end, seg_start, [v]
+            else:
+                cur_start = seg_start
+                members.append(v)
+            if cur_end - cur_start >= limit:
+                self._close(cur_start, cur_end, members)
+                cur_end = None
+        if cur_end is not None:
+            self._close(cur_start, cur_end, members)
+        self.side = torch.cuda.Stream() if self.overlap else None
+        if self.overlap:
+            for v in tr:
+                v.tensor.register_post_accumulate_grad_hook(self._make_hook(v))
+        self.reset()
+
+    def _close(self, start, end, members):
+        b = len(self.buckets)
+        self.buckets.append((start, end))
+        for v in members:
+            self._var_bucket[v.name] = b
+        self._remaining.append(len(members))
+
+    def reset(self):
+        self._count = list(self._remaining)
+        self._pending = []
+        self._launched = [False] * len(self.buckets)
+
+    def _make_hook(self, v):
+        b = self._var_bucket[v.name]
+
+        def hook(_param):
+            self._count[b] -= 1
+            if self._count[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        s, e = self.buckets[b]
+        view = self.store.grad_arena[s:e]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+
+    def allreduce(self, grad_arena=None):
+        """call after backward: finishes every outstanding bucket; afterwards the arena holds the summed gradients."""
+        if self.world <= 1:
+            return
+        if self.overlap:
+            for b in range(len(self.buckets)):      # variables without a gradient this step (frozen / unused)
+                if not self._launched[b]:
+                    self._launch(b)
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.reset()
+        else:
+            dist.all_reduce(self.store.grad_arena, op=dist.ReduceOp.SUM, group=self.group)

@@ -256,17 +256,24 @@ def l2_loss(w):
 
 
 # ---- optimisers (in-place on torch tensors, no autograd) --------------------------------------------------------
+def _one_minus(beta, dtype):
+    if dtype == torch.float32:
+        return float(np.float32(1.0) - np.float32(beta))
+    return 1.0 - beta
+
+
 def adam_update(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
     """tf.train.AdamOptimizer._apply_dense: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; w -= lr_t*m/(sqrt(v)+eps)"""
     lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
-    m += (g - m) * (1 - beta1)
-    v += (g * g - v) * (1 - beta2)
+    # TF's ApplyAdam kernel forms (1 - beta) in the variable's dtype: for float32 that is fl32(1) - fl32(beta)
+    m += (g - m) * _one_minus(beta1, w.dtype)
+    v += (g * g - v) * _one_minus(beta2, w.dtype)
     w -= lr_t * m / (torch.sqrt(v) + eps)
 
 
 def rmsprop_update(w, g, ms, lr, decay=0.9, eps=1e-10):
     """tf.train.RMSPropOptimizer(momentum=0): ms init 1.0; ms = decay*ms + (1-decay)*g^2; w -= lr*g/sqrt(ms+eps)"""
-    ms += (g * g - ms) * (1 - decay)
+    ms += (g * g - ms) * _one_minus(decay, w.dtype)
     w -= lr * g / torch.sqrt(ms + eps)
 
 

@@ -96,9 +96,11 @@ def test_optimizers(dev):
     K.rmsprop_step(w, torch.from_numpy(g).to(dev), ms, None, None, 3e-4, 0.9, 1e-10)
     T.rmsprop_update(wo, torch.from_numpy(g), mso, 3e-4)
     assert _rel(w, wo) < 1e-6 and _rel(ms, mso) < 1e-6
+    w_before = w.cpu().clone()
     K.clip(w, md, -0.03, 0.03)
-    wc = torch.where(torch.from_numpy(me), torch.clamp(wo, -0.03, 0.03), wo)
+    wc = torch.where(torch.from_numpy(me), torch.clamp(w_before, -0.03, 0.03), w_before)
     assert torch.equal(w.cpu(), wc)
+    assert float(wc[torch.from_numpy(me)].abs().max()) <= 0.03 + 1e-9 and float(w_before.abs().max()) > 0.03
 
     # Momentum
     w = torch.from_numpy(w0.copy()).to(dev); acc = torch.zeros_like(w)

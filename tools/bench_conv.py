@@ -1,0 +1,71 @@
+"""Per-layer timing of the conv kernels at BASELINE sizes (B=16): fwd / dgrad / wgrad TFLOP/s vs the 157.3 TF fp32 MFMA peak."""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+K = importlib.import_module("medical-cross-modality-domain-adaptation_amd.kernels")
+
+PEAK = 157.3
+B = int(os.environ.get("B", 16))
+LAYERS = [  # name, H, C, K, R, dil, padding, count in segmenter fwd
+    ("g1 3->16", 256, 3, 16, 3, 1, "SAME", 1),
+    ("g1 16->16", 256, 16, 16, 3, 1, "SAME", 2),
+    ("g2 16->32", 128, 16, 32, 3, 1, "SAME", 1),
+    ("g2 32->32", 128, 32, 32, 3, 1, "SAME", 1),
+    ("g3 32->64", 64, 32, 64, 3, 1, "SAME", 1),
+    ("g3 64->64", 64, 64, 64, 3, 1, "SAME", 3),
+    ("g4 64->128", 32, 64, 128, 3, 1, "SAME", 1),
+    ("g4 128->128", 32, 128, 128, 3, 1, "SAME", 3),
+    ("g5 128->256", 32, 128, 256, 3, 1, "SAME", 1),
+    ("g5/6 256->256", 32, 256, 256, 3, 1, "SAME", 7),
+    ("g7 256->512", 32, 256, 512, 3, 1, "SAME", 1),
+    ("g7/9 512->512", 32, 512, 512, 3, 1, "SAME", 5),
+    ("g8 512->512 d2", 32, 512, 512, 3, 2, "SAME", 4),
+    ("g10 512->2560", 32, 512, 2560, 3, 1, "SYMMETRIC", 1),
+    ("out 40->5 k5", 256, 40, 5, 5, 1, "SYMMETRIC", 1),
+    ("cls1 64->64", 256, 64, 64, 3, 1, "SAME", 0),
+]
+
+
+def timeit(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    dev = torch.device("cuda:0")
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    totflop = 0.0
+    print("%-18s %9s | %8s %6s | %8s %6s | %8s %6s" % ("layer", "GFLOP", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
+    for name, H, C, Kc, R, dil, padding, cnt in LAYERS:
+        x = torch.randn((B, H, H, C), device=dev)
+        w = torch.randn((R, R, C, Kc), device=dev) * 0.05
+        g = K.conv_geom(tuple(x.shape), tuple(w.shape), 1, dil, padding)
+        dy = torch.randn((B, g.OH, g.OW, Kc), device=dev)
+        flop = 2.0 * B * g.OH * g.OW * R * R * C * Kc
+        tf = timeit(lambda: K.conv2d_fwd(x, w, g))
+        td = timeit(lambda: K.conv2d_dgrad(dy, w, g))
+        tw = timeit(lambda: K.conv2d_wgrad(x, dy, g))
+        print("%-18s %9.2f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f" % (name, flop / 1e9, tf, flop / tf / 1e9, td, flop / td / 1e9, tw,
+                                                                   flop / tw / 1e9))
+        tot["fwd"] += tf * cnt
+        tot["dgrad"] += td * cnt
+        tot["wgrad"] += tw * cnt
+        totflop += flop * cnt
+    print("segmenter conv totals (ms): fwd %.2f dgrad %.2f wgrad %.2f ; fwd GFLOP %.1f -> %.1f TF/s (%.1f%% of %.1f)" % (
+        tot["fwd"], tot["dgrad"], tot["wgrad"], totflop / 1e9, totflop / tot["fwd"] / 1e9, 100 * totflop / tot["fwd"] / 1e9 / PEAK, PEAK))
+
+
+if __name__ == "__main__":
+    main()
