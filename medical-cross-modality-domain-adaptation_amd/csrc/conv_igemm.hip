@@ -26,6 +26,10 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
+#ifndef PNP_CONV_ABLATE
+#define PNP_CONV_ABLATE 0
+#endif
+constexpr int kAblate = PNP_CONV_ABLATE;
 
 struct ConvArgs {
     const float* x;
@@ -360,16 +364,20 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
         const bool more = (c + 1) < nchunks;
-        if (more) {
+        // PNP_CONV_ABLATE (compile-time, timing experiments only — results are wrong when set):
+        //   1 = no global loads after the first stage, 2 = no MFMAs, 4 = no LDS stores, 8 = no barrier
+        // (a run-time flag here cost 12 % by itself: the branches defeat the MFMA/ds_read schedule)
+        if (more && !(kAblate & 1)) {
             la.load(a, (c + 1) * BK);
             lb.load(a.w, (c + 1) * BK, a.Kred, a.K, n0);
         }
-        mfma_stage<TM, TN, true, LDA, LDB>(lds + cur * ASZ, lds + 2 * ASZ + cur * BSZ, wm0, wn0, lane, acc);
-        if (more) {
+        if constexpr (!(kAblate & 2))
+            mfma_stage<TM, TN, true, LDA, LDB>(lds + cur * ASZ, lds + 2 * ASZ + cur * BSZ, wm0, wn0, lane, acc);
+        if (more && !(kAblate & 4)) {
             la.store(lds + (cur ^ 1) * ASZ);
             lb.store(lds + 2 * ASZ + (cur ^ 1) * BSZ);
         }
-        __syncthreads();
+        if constexpr (!(kAblate & 8)) __syncthreads();
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -577,7 +585,8 @@ ConvArgs make_args(const float* x, const float* w, float* y, const pnp_conv_geom
     a.OHW = g->OH * g->OW;
     a.nsplit = 1; a.chunks_per_split = 0; a.split_stride = 0;
     a.do_drop = 0; a.drop_scale = 1.f; a.drop_key = 0; a.drop_thresh = 0;
-    a.xcd_swizzle = 1;
+    static const int env_noswz = getenv("PNP_CONV_NOSWIZZLE") ? 1 : 0;
+    a.xcd_swizzle = env_noswz ? 0 : 1;
     return a;
 }
 

@@ -1,0 +1,192 @@
+"""not gpu: host-side logic — TF padding arithmetic KATs, dropout mask stream, oracle self-checks (closed forms and float64
+finite differences), optimiser restatements, tfrecord round trip, 2-rank gloo gradient all-reduce."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, pkg
+from oracle import tf_ops as T
+
+
+def test_same_padding_kats():
+    K = pkg("kernels")
+    # k3 s2 in256 -> (0,1); k5 s2 in128 -> (1,2); k5 s4 in16 -> (0,1); atrous rate 2 k3 -> (2,2)
+    assert K.same_pad(256, 3, 2) == (128, 0, 1) == T.same_pad(256, 3, 2)
+    assert K.same_pad(128, 5, 2) == (64, 1, 2) == T.same_pad(128, 5, 2)
+    assert K.same_pad(16, 5, 4) == (4, 0, 1) == T.same_pad(16, 5, 4)
+    assert K.same_pad(32, 3, 1, 2) == (32, 2, 2)
+    g = K.conv_geom((2, 4, 4, 512), (3, 3, 512, 512), 2, 1, "SYMMETRIC")     # cls_6: 4x4 -> 2x2
+    assert (g.OH, g.OW) == (2, 2)
+    assert T.sym_index(3, 1) == [0, 0, 1, 2, 2] and T.sym_index(3, 2) == [1, 0, 0, 1, 2, 2, 1]
+
+
+def test_conv_oracle_vs_definition():
+    rng = np.random.default_rng(0)
+    for (N, H, W, C, Kc, R, s, d, p) in [(2, 9, 7, 5, 6, 3, 1, 1, "SAME"), (1, 16, 16, 4, 3, 3, 2, 1, "SAME"), (1, 16, 16, 4, 3, 5, 2, 1, "SAME"),
+                                         (1, 16, 16, 4, 3, 5, 4, 1, "SAME"), (1, 8, 8, 3, 4, 3, 1, 2, "SAME"), (1, 6, 6, 3, 4, 5, 1, 1, "SYMMETRIC"),
+                                         (1, 4, 4, 3, 4, 3, 2, 1, "SYMMETRIC")]:
+        x = rng.standard_normal((N, H, W, C))
+        w = rng.standard_normal((R, R, C, Kc))
+        a = T.conv2d(torch.from_numpy(x), torch.from_numpy(w), s, d, p).numpy()
+        b = T.conv2d_direct_np(x, w, s, d, p)
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-12
+
+
+def test_dropout_mask_stream():
+    m = T.dropout_mask((1000, 257), 0.75, 5, 2)
+    assert abs(m.mean() - 0.75) < 5e-3
+    assert not np.array_equal(m, T.dropout_mask((1000, 257), 0.75, 5, 3))      # stream id decorrelates call sites
+    assert not np.array_equal(m, T.dropout_mask((1000, 257), 0.75, 6, 2))      # seed decorrelates steps
+    assert np.array_equal(m, T.dropout_mask((1000, 257), 0.75, 5, 2))          # reproducible
+    assert T.dropout_mask((10,), 1.0, 0, 0).all()
+    # hash KATs shared with csrc/pnp_common.h (fmix32 is the murmur3 finaliser)
+    assert int(T._fmix32(np.array([1], np.uint32))[0]) == 0x514E28B7
+    assert int(T.drop_thresh(0.75)) == 4194304
+
+
+def test_bn_closed_forms():
+    x = torch.full((2, 4, 4, 3), 5.0)
+    mm, mv = torch.zeros(3), torch.ones(3)
+    y = T.batch_norm(x, torch.ones(3), torch.zeros(3), mm, mv, True)
+    assert torch.allclose(y, torch.zeros_like(y))                       # constant input -> zero output
+    assert torch.allclose(mm, torch.full((3,), 0.5)) and torch.allclose(mv, torch.full((3,), 0.9))   # m -= (m-batch)*(1-.9)
+    x = torch.arange(32, dtype=torch.float64).reshape(2, 4, 4, 1)
+    mm, mv = torch.zeros(1, dtype=torch.float64), torch.ones(1, dtype=torch.float64)
+    T.batch_norm(x, torch.ones(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64), mm, mv, True)
+    assert abs(float(mv) - (0.9 + 0.1 * float(x.var(unbiased=True)))) < 1e-12       # Bessel-corrected moving variance
+
+
+def test_loss_closed_forms_and_finite_differences():
+    rng = np.random.default_rng(0)
+    lab = rng.integers(0, 5, size=(2, 6, 6))
+    y = torch.from_numpy(T.label_decomp(5, lab)).double()
+    big = (y * 60.0 - 30.0)                                              # confident and correct
+    assert abs(float(T.dice_loss(big, y)) + 1.0) < 1e-6                  # Dice of identical masks -> -1
+    assert abs(float(T.softmax_weighted_loss(big, y))) < 1e-6
+    de, arr = T.dice_eval(torch.from_numpy(lab), y, 5)
+    assert abs(float(de) - 1.0) < 1e-6
+    z = torch.from_numpy(rng.standard_normal((2, 6, 6, 5))).double().requires_grad_(True)
+    f = lambda t: T.softmax_weighted_loss(t, y) + T.dice_loss(t, y)
+    f(z).backward()
+    g = z.grad.clone()
+    eps = 1e-6
+    for idx in [(0, 0, 0, 0), (1, 3, 2, 4), (0, 5, 5, 2)]:
+        zp, zm = z.detach().clone(), z.detach().clone()
+        zp[idx] += eps
+        zm[idx] -= eps
+        fd = (float(f(zp)) - float(f(zm))) / (2 * eps)
+        assert abs(fd - float(g[idx])) < 1e-7
+
+
+def test_whole_network_fd_gradient_fp64():
+    """float64 finite-difference check of the oracle's segmenter backward (tiny random direction on two variables)"""
+    from oracle import nets
+    rng = np.random.default_rng(1)
+    state = {}
+    for k, s in nets.segmenter_variable_shapes().items():
+        if "Variable" in k:
+            state[k] = rng.standard_normal(s) * np.sqrt(2.0 / (s[0] * s[1] * s[2]))
+        elif k.endswith("gamma") or k.endswith("moving_variance"):
+            state[k] = np.ones(s)
+        else:
+            state[k] = np.zeros(s)
+    state["output/Variable"] *= 0.05
+    V = nets.make_variables(state, dtype=torch.float64)
+    x = torch.from_numpy(rng.standard_normal((2, 256, 256, 3)))
+    lab = np.zeros((2, 256, 256), np.int64)
+    lab[:, 60:120, 50:200] = 1
+    lab[:, 130:200, 30:90] = 2
+    lab[:, 150:220, 120:220] = 3
+    lab[0, 10:40, 10:60] = 4
+    y = torch.from_numpy(T.label_decomp(5, lab)).double()
+
+    def loss():
+        lg = nets.segmenter_forward(V, x, 1.0, True, True)
+        c, r, _, _ = nets.segmenter_cost(V, lg, y)
+        return c + r
+    L = loss()
+    L.backward()
+    for name in ("group_9/Variable_1", "BatchNorm_29/gamma"):
+        d = torch.from_numpy(rng.standard_normal(tuple(V[name].shape)))
+        d = d / d.norm()
+        ana = float((V[name].grad * d).sum())
+        eps = 1e-4          # small enough that few leaky-ReLU / max-pool kinks are crossed
+        with torch.no_grad():
+            V[name] += eps * d
+            lp = float(loss())
+            V[name] -= 2 * eps * d
+            lm = float(loss())
+            V[name] += eps * d
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - ana) < 5e-3 * abs(ana) + 1e-9, (name, fd, ana)
+
+
+def test_optimizer_restatements():
+    w = torch.tensor([1.0, -2.0], dtype=torch.float64)
+    g = torch.tensor([0.5, -0.25], dtype=torch.float64)
+    m, v = torch.zeros(2, dtype=torch.float64), torch.zeros(2, dtype=torch.float64)
+    T.adam_update(w, g, m, v, 1e-3, 1)
+    # step 1 of Adam moves every weight by lr*g/(|g| + eps*sqrt(1-b2)) ~ lr*sign(g)
+    assert torch.allclose(w, torch.tensor([1.0 - 1e-3, -2.0 + 1e-3], dtype=torch.float64), atol=1e-9)
+    w = torch.tensor([1.0], dtype=torch.float64)
+    ms = torch.ones(1, dtype=torch.float64)                               # RMSProp slot "rms" is initialised to ONE in TF
+    T.rmsprop_update(w, torch.tensor([2.0], dtype=torch.float64), ms, 3e-4)
+    assert abs(float(ms) - (0.9 + 0.1 * 4.0)) < 1e-12 and abs(float(w) - (1.0 - 3e-4 * 2.0 / np.sqrt(1.3 + 1e-10))) < 1e-12
+
+
+def test_variable_store_arena_layout():
+    ss = pkg("source_segmenter")
+    net = ss.Full_DRN(channels=3, n_class=5, batch_size=2, device="cpu", cost_kwargs={})
+    st = net.store
+    assert st.arena.numel() % 1024 == 0 and st.grad_arena.shape == st.arena.shape
+    tot = 0
+    for v in st.trainable():
+        assert v.offset % 1024 == 0 and v.tensor.requires_grad and v.tensor.grad is not None
+        assert v.tensor.data_ptr() == st.arena.data_ptr() + 4 * v.offset        # views of ONE flat arena
+        assert v.tensor.grad.data_ptr() == st.grad_arena.data_ptr() + 4 * v.offset
+        tot += v.numel
+    assert tot == 39302456 + 30 * 2 * 0 + sum(v.numel for v in st.trainable() if v.kind == "bn")
+    l2 = st.chunk_table(lambda v: 1e-4 * v.l2_mult, np.float32).numpy()
+    w43 = st.vars["group_4/Variable_3"]
+    assert np.allclose(l2[w43.offset // 1024], 2e-4) and l2[st.vars["group_4/Variable_2"].offset // 1024] == 0
+    assert l2[st.vars["BatchNorm/gamma"].offset // 1024] == 0
+
+
+def test_gloo_two_rank_gradient_allreduce(tmp_path):
+    """N>1 path on CPU: 2 ranks (gloo), each fills its gradient arena with rank-dependent values; after GradReducer.allreduce
+    both hold the sum; buckets tile the arena exactly."""
+    script = tmp_path / "w.py"
+    script.write_text('''
+import importlib, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+par = importlib.import_module("medical-cross-modality-domain-adaptation_amd.parallel")
+ss = importlib.import_module("medical-cross-modality-domain-adaptation_amd.source_segmenter")
+rank, local, world = par.init_distributed("gloo")
+net = ss.Full_DRN(channels=3, n_class=5, batch_size=2, device="cpu", cost_kwargs={}, world_size=world)
+red = par.GradReducer(net.store, bucket_bytes=8 << 20, overlap=True)
+assert not red.overlap      # CPU tensors: plain all-reduce path
+cover = np.zeros(net.store.arena.numel(), np.int32)
+for s, e in red.buckets:
+    cover[s:e] += 1
+assert (cover == 1).all(), "buckets must tile the arena exactly once"
+assert len(red.buckets) >= 10
+net.store.grad_arena.fill_(float(rank + 1))
+net.store.grad_arena[:7] = torch.arange(7, dtype=torch.float32) * (rank + 1)
+red.allreduce()
+exp = sum(r + 1 for r in range(world))
+assert torch.all(net.store.grad_arena[7:] == exp)
+assert torch.equal(net.store.grad_arena[:7], torch.arange(7, dtype=torch.float32) * exp)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+''' % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.stdout.count("ok") == 2

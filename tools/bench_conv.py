@@ -48,7 +48,10 @@ def main():
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     totflop = 0.0
     print("%-18s %9s | %8s %6s | %8s %6s | %8s %6s" % ("layer", "GFLOP", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
+    only = os.environ.get("ONLY")
     for name, H, C, Kc, R, dil, padding, cnt in LAYERS:
+        if only and only not in name:
+            continue
         x = torch.randn((B, H, H, C), device=dev)
         w = torch.randn((R, R, C, Kc), device=dev) * 0.05
         g = K.conv_geom(tuple(x.shape), tuple(w.shape), 1, dil, padding)
