@@ -47,24 +47,24 @@ struct ConvArgs {
     float drop_scale;
     int do_drop;
     int xcd_swizzle;
+    unsigned x_bytes, w_bytes;   // sizes of the tensors behind a.x / a.w (buffer descriptors)
 };
 
-// virtual coordinate -> real coordinate; returns false when the tap reads zero
-__device__ __forceinline__ bool map_coord(int v, int H, int ups, int mode, int& i) {
-    if (mode == PNP_PAD_SYMMETRIC) {
-        if (v < 0) v = -1 - v;
-        else if (v >= H) v = 2 * H - 1 - v;
-        i = v;
-        return (unsigned)v < (unsigned)H;
+// virtual coordinate -> real coordinate; returns false when the tap reads zero.  Branch-free on purpose (selects only):
+// a scalar branch here would split the main-loop body into basic blocks and pin the address arithmetic in front of the MFMAs.
+// UPS: the input is zero-upsampled by `ups` (dgrad of a strided convolution); sym: tf.pad SYMMETRIC mirror (edge included).
+template <bool UPS>
+__device__ __forceinline__ bool map_coord(int v, int H, int ups, int sym, int& i) {
+    const int vs = v < 0 ? -1 - v : (v >= H ? 2 * H - 1 - v : v);
+    const int vv = sym ? vs : v;
+    if constexpr (UPS) {
+        const int q = vv / ups;
+        i = q;
+        return (vv >= 0) & (q * ups == vv) & (q < H);
+    } else {
+        i = vv;
+        return (unsigned)vv < (unsigned)H;
     }
-    if (ups == 1) {
-        i = v;
-        return (unsigned)v < (unsigned)H;
-    }
-    if (v < 0) return false;
-    int q = v / ups;
-    i = q;
-    return (q * ups == v) && (q < H);
 }
 
 // bijective XCD-aware remap: consecutive tiles (which share the A rows / filter panel) land on one XCD's L2
@@ -89,8 +89,25 @@ struct Acc {
     }
 };
 
+// ---- global loads go through buffer descriptors ---------------------------------------------------
+// An out-of-range byte offset returns 0 in hardware, so TF zero padding, ragged tile edges, the k tail and the
+// (unused) prefetch past the last stage need neither branches nor selects: the main-loop body is ONE basic block,
+// which is what lets the MFMA / ds_read / buffer_load interleave below be scheduled at all.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFF00u;   // beyond any legal offset (host checks tensors are < 2^30 elements)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
 // ---- B tile (weights for fwd, dy for wgrad): row-major [rows][ncols] global matrix ------------
-template <int BN>
+template <int BN, bool VEC>
 struct BLoader {
     static constexpr int C4 = BN / 4;             // float4 columns per row
     static constexpr int RP = NTHREADS / C4;      // rows per pass
@@ -103,24 +120,19 @@ struct BLoader {
         brow = t / C4;
     }
     // rows [k0, k0+32) of a [nrows][ncols] matrix, columns [n0, n0+BN)
-    __device__ __forceinline__ void load(const float* __restrict__ b, int k0, int nrows, int ncols, int n0) {
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rb, int k0, int nrows, int ncols, int n0) {
         const int n = n0 + 4 * bcol;
-        const bool vec = (ncols & 3) == 0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int k = k0 + brow + RP * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < nrows) {
-                const float* p = b + (size_t)k * ncols + n;
-                if (vec) {
-                    if (n < ncols) v = *reinterpret_cast<const f32x4*>(p);
-                } else {
+            const bool rok = k < nrows;
+            const unsigned base = (unsigned)(k * ncols + n) * 4u;
+            if constexpr (VEC) {      // ncols % 4 == 0
+                reg[i] = bload4(rb, (rok && n < ncols) ? base : OOB);
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < ncols) v[e] = p[e];
-                }
+                for (int e = 0; e < 4; ++e) reg[i][e] = bload1(rb, (rok && n + e < ncols) ? base + 4u * e : OOB);
             }
-            reg[i] = v;
         }
     }
     __device__ __forceinline__ void store(float* lds) const {
@@ -132,7 +144,7 @@ struct BLoader {
 
 // ---- fwd A tile: [BM pixels][32 k] gathered from x ---------------------------------------------
 // MODE 0: C % 32 == 0 (whole stage shares one filter tap), 1: C % 4 == 0, 2: any C (scalar)
-template <int BM, int MODE>
+template <int BM, int MODE, bool UPS>
 struct FwdALoader {
     static constexpr int NR = BM / 32;   // rows per thread
     static constexpr int LD = BK + 4;
@@ -159,53 +171,39 @@ struct FwdALoader {
             if (ok) valid |= 1u << i;
         }
     }
-    __device__ __forceinline__ f32x4 gather4(const ConvArgs& a, int i, int rs, int c) const {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    // byte offset of x[pixel(i, tap rs)][c], or OOB when the tap reads padding / the row is past M
+    __device__ __forceinline__ unsigned offset(const ConvArgs& a, int i, int rs, int c, bool kok) const {
         int r = rs / a.S;
         int s = rs - r * a.S;
         int ih = 0, iw = 0;
-        bool ok = (valid >> i) & 1u;
-        ok = ok && map_coord(vh0[i] + r * a.dil, a.H, a.ups, a.pad_mode, ih);
-        ok = ok && map_coord(vw0[i] + s * a.dil, a.W, a.ups, a.pad_mode, iw);
-        if (ok) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(pixbase[i] + ih * a.W + iw) * a.C + c));
-        return v;
+        bool ok = kok && ((valid >> i) & 1u);
+        ok = map_coord<UPS>(vh0[i] + r * a.dil, a.H, a.ups, a.pad_mode, ih) & ok;
+        ok = map_coord<UPS>(vw0[i] + s * a.dil, a.W, a.ups, a.pad_mode, iw) & ok;
+        return ok ? (unsigned)((pixbase[i] + ih * a.W + iw) * a.C + c) * 4u : OOB;
     }
-    __device__ __forceinline__ float gather1(const ConvArgs& a, int i, int kf) const {
-        if (kf >= a.Kred) return 0.f;
-        int rs = kf / a.C;
-        int c = kf - rs * a.C;
-        int r = rs / a.S;
-        int s = rs - r * a.S;
-        int ih = 0, iw = 0;
-        bool ok = (valid >> i) & 1u;
-        ok = ok && map_coord(vh0[i] + r * a.dil, a.H, a.ups, a.pad_mode, ih);
-        ok = ok && map_coord(vw0[i] + s * a.dil, a.W, a.ups, a.pad_mode, iw);
-        return ok ? a.x[(size_t)(pixbase[i] + ih * a.W + iw) * a.C + c] : 0.f;
-    }
-    __device__ __forceinline__ void load(const ConvArgs& a, int k0) {
+    __device__ __forceinline__ void load(const ConvArgs& a, __amdgpu_buffer_rsrc_t rx, int k0) {
         if constexpr (MODE == 0) {
             int rs = k0 / a.C;                 // block-uniform
             int c = k0 - rs * a.C + 4 * kg;
+            const bool kok = k0 < a.Kred;
 #pragma unroll
-            for (int i = 0; i < NR; ++i) reg[i] = gather4(a, i, rs, c);
+            for (int i = 0; i < NR; ++i) reg[i] = bload4(rx, offset(a, i, rs, c, kok));
         } else if constexpr (MODE == 1) {
             int kf = k0 + 4 * kg;
             int rs = kf / a.C;
             int c = kf - rs * a.C;
-            bool kok = kf < a.Kred;            // C%4==0 => Kred%4==0 => whole float4 in range
+            const bool kok = kf < a.Kred;      // C%4==0 => Kred%4==0 => whole float4 in range
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                reg[i] = kok ? gather4(a, i, rs, c) : z;
-            }
+            for (int i = 0; i < NR; ++i) reg[i] = bload4(rx, offset(a, i, rs, c, kok));
         } else {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                f32x4 v;
+            for (int i = 0; i < NR; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gather1(a, i, k0 + 4 * kg + e);
-                reg[i] = v;
-            }
+                for (int e = 0; e < 4; ++e) {
+                    int kf = k0 + 4 * kg + e;
+                    int rs = kf / a.C;
+                    reg[i][e] = bload1(rx, offset(a, i, rs, kf - rs * a.C, kf < a.Kred));
+                }
         }
     }
     __device__ __forceinline__ void store(float* lds) const {
@@ -216,7 +214,7 @@ struct FwdALoader {
 };
 
 // ---- wgrad A tile: [32 pixels][BM m'] gathered from x, m' = (r*S+s)*C + c ----------------------
-// MODE 0: C % BM == 0 (block-uniform tap), 1: C % 4 == 0, 2: any C
+// MODE 1: C % 4 == 0 (a thread's 4 consecutive m' share the tap), 2: any C
 template <int BM, int MODE>
 struct WgradALoader {
     static constexpr int C4 = BM / 4;
@@ -225,7 +223,7 @@ struct WgradALoader {
     static constexpr int LD = BM + 4;
     f32x4 reg[NP];
     int acol, arow;
-    int rs_u, c_u;          // MODE 0/1: this thread's tap and channel (fixed for the whole kernel)
+    int rs_u, c_u;          // MODE 1: this thread's tap and channel (fixed for the whole kernel)
     bool mok;               // MODE 1: m' in range
     int mm;                 // first m' of this thread
     __device__ __forceinline__ void init(int t, int mm0, const ConvArgs& a) {
@@ -237,7 +235,7 @@ struct WgradALoader {
         rs_u = m_ / a.C;
         c_u = m_ - rs_u * a.C;
     }
-    __device__ __forceinline__ bool pixel(const ConvArgs& a, int p, int rs, int& off) const {
+    __device__ __forceinline__ unsigned offset(const ConvArgs& a, int p, int rs, int c, bool ok) const {
         int n = p / a.OHW;
         int rem = p - n * a.OHW;
         int oh = rem / a.OW;
@@ -245,35 +243,26 @@ struct WgradALoader {
         int r = rs / a.S;
         int s = rs - r * a.S;
         int ih = 0, iw = 0;
-        bool ok = map_coord(oh * a.stride - a.pad_t + r * a.dil, a.H, 1, a.pad_mode, ih);
-        ok = ok && map_coord(ow * a.stride - a.pad_l + s * a.dil, a.W, 1, a.pad_mode, iw);
-        off = (n * a.H + ih) * a.W + iw;
-        return ok;
+        ok = map_coord<false>(oh * a.stride - a.pad_t + r * a.dil, a.H, 1, a.pad_mode, ih) & ok;
+        ok = map_coord<false>(ow * a.stride - a.pad_l + s * a.dil, a.W, 1, a.pad_mode, iw) & ok;
+        return ok ? (unsigned)(((n * a.H + ih) * a.W + iw) * a.C + c) * 4u : OOB;
     }
-    __device__ __forceinline__ void load(const ConvArgs& a, int p0, int pend) {
+    __device__ __forceinline__ void load(const ConvArgs& a, __amdgpu_buffer_rsrc_t rx, int p0, int pend) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            int p = p0 + arow + RP * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < pend) {
-                if constexpr (MODE <= 1) {
-                    int off;
-                    if (mok && pixel(a, p, rs_u, off))
-                        v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)off * a.C + c_u));
-                } else {
+            const int p = p0 + arow + RP * i;
+            const bool pok = p < pend;
+            const int pp = pok ? p : 0;
+            if constexpr (MODE <= 1) {
+                reg[i] = bload4(rx, offset(a, pp, rs_u, c_u, pok && mok));
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int m_ = mm + e;
-                        if (m_ < a.Kred) {
-                            int rs = m_ / a.C;
-                            int c = m_ - rs * a.C;
-                            int off;
-                            if (pixel(a, p, rs, off)) v[e] = a.x[(size_t)off * a.C + c];
-                        }
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const int m_ = mm + e;
+                    const int rs = m_ / a.C;
+                    reg[i][e] = bload1(rx, offset(a, pp, rs, m_ - rs * a.C, pok && m_ < a.Kred));
                 }
             }
-            reg[i] = v;
         }
     }
     __device__ __forceinline__ void store(float* lds) const {
@@ -326,10 +315,48 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const f
                     acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kq][tm][j], b[kq][j][tn], acc.v[tm][tn], 0, 0, 0);
 }
 
+// ---- register-pipelined fragments: one 8-k slice (kq) of a stage ---------------------------------
+// The main loops keep two Frag sets: while the 4*TM*TN MFMAs of slice kq run, the ds_reads of slice kq+1 are in
+// flight, the global loads of the next stage are issued (slice 0) and stored to the other LDS buffer (slice 3).
+// The only LDS latency a wave exposes per stage is the first slice's reads right after the barrier.
+template <int TM, int TN, bool A_MMAJOR, int LDA, int LDB>
+struct Frag {
+    f32x4 a[TM];
+    float b[4][TN];
+    __device__ __forceinline__ void load(const float* __restrict__ As, const float* __restrict__ Bs, int kq, int wm0, int wn0,
+                                         int lane) {
+        const int l31 = lane & 31;
+        const int kb = kq * 8 + 4 * (lane >> 5);
+        if constexpr (A_MMAJOR) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(As + (wm0 + tm * 32 + l31) * LDA + kb);
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[tm][j] = As[(kb + j) * LDA + wm0 + tm * 32 + l31];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[j][tn] = Bs[(kb + j) * LDB + wn0 + tn * 32 + l31];
+    }
+    __device__ __forceinline__ void mma(Acc<TM, TN>& acc) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[j][tn], acc.v[tm][tn], 0, 0, 0);
+    }
+};
+#define PNP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 // ================================ forward / dgrad kernel ========================================
 // DGRAD only makes the data-gradient launches a distinct kernel symbol (so that rocprof separates them from the
 // forward convolutions) and lets the forward instantiation drop the zero-upsampling arithmetic (ups == 1).
-template <int BM, int BN, int WM, int WN, int MODE, bool DGRAD>
+template <int BM, int BN, int WM, int WN, int MODE, bool DGRAD, bool VECB>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BK + 4, LDB = BN + 4;
@@ -347,37 +374,84 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
     const int m0 = mt * BM, n0 = nt * BN;
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
-    FwdALoader<BM, MODE> la;
-    BLoader<BN> lb;
+    FwdALoader<BM, MODE, DGRAD> la;
+    BLoader<BN, VECB> lb;
     la.init(t, m0, a);
     lb.init(t);
 
     Acc<TM, TN> acc;
     acc.zero();
 
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
     const int nchunks = (a.Kred + BK - 1) / BK;
-    la.load(a, 0);
-    lb.load(a.w, 0, a.Kred, a.K, n0);
+    la.load(a, rx, 0);
+    lb.load(rw, 0, a.Kred, a.K, n0);
     la.store(lds);
     lb.store(lds + 2 * ASZ);
     __syncthreads();
+    Frag<TM, TN, true, LDA, LDB> f0, f1;
+    f0.load(lds, lds + 2 * ASZ, 0, wm0, wn0, lane);
+    // Main loop — ONE basic block per stage (no branches: the prefetch past the last stage reads out of range = zeros
+    // and lands in the LDS buffer nobody reads).  Per stage and wave: 64 MFMAs in 4 slices of 16; under slice q the
+    // ds_reads of slice q+1 are in flight; the next stage's global loads are issued under slice 0 and written to the
+    // other LDS buffer under slice 3; only the 6 reads of the next stage's slice 0 are exposed after the barrier.
+    // PNP_CONV_ABLATE (compile-time, timing experiments only — results are wrong when set):
+    //   1 = no global loads after the first stage, 2 = no MFMAs, 4 = no LDS stores, 8 = no barrier
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
-        const bool more = (c + 1) < nchunks;
-        // PNP_CONV_ABLATE (compile-time, timing experiments only — results are wrong when set):
-        //   1 = no global loads after the first stage, 2 = no MFMAs, 4 = no LDS stores, 8 = no barrier
-        // (a run-time flag here cost 12 % by itself: the branches defeat the MFMA/ds_read schedule)
-        if (more && !(kAblate & 1)) {
-            la.load(a, (c + 1) * BK);
-            lb.load(a.w, (c + 1) * BK, a.Kred, a.K, n0);
+        const float* As = lds + cur * ASZ;
+        const float* Bs = lds + 2 * ASZ + cur * BSZ;
+        float* An = lds + (cur ^ 1) * ASZ;
+        float* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
+        // Reduction order.  MODE 0 (C % 32 == 0): channel-group major, filter tap minor — the R*S stages that re-read the
+        // same input pixels (shifted by one tap) run back to back, so the re-reads hit the XCD's L2.  The sum is
+        // order-independent up to fp32 rounding; the filter rows are visited in the matching order.
+        int k0 = (c + 1) * BK;
+        if constexpr (MODE == 0) {
+            const int rs_n = a.R * a.S;
+            const int cc = (c + 1) / rs_n;
+            k0 = ((c + 1) - cc * rs_n) * a.C + cc * BK;
         }
-        if constexpr (!(kAblate & 2))
-            mfma_stage<TM, TN, true, LDA, LDB>(lds + cur * ASZ, lds + 2 * ASZ + cur * BSZ, wm0, wn0, lane, acc);
-        if (more && !(kAblate & 4)) {
-            la.store(lds + (cur ^ 1) * ASZ);
-            lb.store(lds + 2 * ASZ + (cur ^ 1) * BSZ);
+        k0 = (c + 1 < nchunks) ? k0 : a.Kred;        // past the end: every offset out of range -> zeros
+        // ---- slice 0
+        f1.load(As, Bs, 1, wm0, wn0, lane);
+        if constexpr (!(kAblate & 1)) {
+            la.load(a, rx, k0);
+            lb.load(rw, k0, a.Kred, a.K, n0);
         }
+        if constexpr (!(kAblate & 2)) f0.mma(acc);
+        // interleave: the 6 ds_reads first, then per MFMA a handful of the address VALU/SALU and, when its address is
+        // ready, one buffer_load — the ~130 address instructions of the next stage ride in the shadow of the 16 MFMAs
+        // (64 cycles each) instead of in front of them.
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int i = 0; i < 4 * TM * TN; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 10, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        PNP_SCHED_FENCE();
+        // ---- slice 1
+        f0.load(As, Bs, 2, wm0, wn0, lane);
+        PNP_SCHED_FENCE();
+        if constexpr (!(kAblate & 2)) f1.mma(acc);
+        PNP_SCHED_FENCE();
+        // ---- slice 2
+        f1.load(As, Bs, 3, wm0, wn0, lane);
+        PNP_SCHED_FENCE();
+        if constexpr (!(kAblate & 2)) f0.mma(acc);
+        PNP_SCHED_FENCE();
+        // ---- slice 3
+        if constexpr (!(kAblate & 4)) {
+            la.store(An);
+            lb.store(Bn);
+        }
+        PNP_SCHED_FENCE();
+        if constexpr (!(kAblate & 2)) f1.mma(acc);
+        PNP_SCHED_FENCE();
         if constexpr (!(kAblate & 8)) __syncthreads();
+        f0.load(An, Bn, 0, wm0, wn0, lane);
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -402,7 +476,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
 
 // ===================================== wgrad kernel ============================================
 // a.x = x, a.w = dy ([P][K]), a.y = dW or the split workspace.  grid.x = nblk_m*nblk_n*nsplit
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, bool VECB>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -420,7 +494,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
     WgradALoader<BM, MODE> la;
-    BLoader<BN> lb;
+    BLoader<BN, VECB> lb;
     la.init(t, mm0, a);
     lb.init(t);
 
@@ -433,25 +507,45 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
     int c_end = c_begin + a.chunks_per_split;
     if (c_end > nchunks_total) c_end = nchunks_total;
     const int nchunks = c_end - c_begin;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
     if (nchunks > 0) {
-        la.load(a, c_begin * BK, P);
-        lb.load(a.w, c_begin * BK, P, a.K, n0);
+        const int pend = (c_end * BK < P) ? c_end * BK : P;     // this split's pixel range ends here
+        la.load(a, rx, c_begin * BK, pend);
+        lb.load(rw, c_begin * BK, pend, a.K, n0);
         la.store(lds);
         lb.store(lds + 2 * ASZ);
         __syncthreads();
-        for (int c = 0; c < nchunks; ++c) {
+        Frag<TM, TN, false, LDA, LDB> f0, f1;
+        f0.load(lds, lds + 2 * ASZ, 0, wm0, wn0, lane);
+        for (int c = 0; c < nchunks; ++c) {      // same branch-free 4-slice pipeline as conv_fwd_kernel
             const int cur = c & 1;
-            const bool more = (c + 1) < nchunks;
-            if (more) {
-                la.load(a, (c_begin + c + 1) * BK, P);
-                lb.load(a.w, (c_begin + c + 1) * BK, P, a.K, n0);
-            }
-            mfma_stage<TM, TN, false, LDA, LDB>(lds + cur * ASZ, lds + 2 * ASZ + cur * BSZ, wm0, wn0, lane, acc);
-            if (more) {
-                la.store(lds + (cur ^ 1) * ASZ);
-                lb.store(lds + 2 * ASZ + (cur ^ 1) * BSZ);
-            }
+            const float* As = lds + cur * ASZ;
+            const float* Bs = lds + 2 * ASZ + cur * BSZ;
+            float* An = lds + (cur ^ 1) * ASZ;
+            float* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
+            const int p0 = (c_begin + c + 1) * BK;                 // >= pend on the last stage -> zeros
+            f1.load(As, Bs, 1, wm0, wn0, lane);
+            la.load(a, rx, p0, pend);
+            lb.load(rw, p0, pend, a.K, n0);
+            PNP_SCHED_FENCE();
+            f0.mma(acc);
+            PNP_SCHED_FENCE();
+            f0.load(As, Bs, 2, wm0, wn0, lane);
+            PNP_SCHED_FENCE();
+            f1.mma(acc);
+            PNP_SCHED_FENCE();
+            f1.load(As, Bs, 3, wm0, wn0, lane);
+            PNP_SCHED_FENCE();
+            f0.mma(acc);
+            PNP_SCHED_FENCE();
+            la.store(An);
+            lb.store(Bn);
+            PNP_SCHED_FENCE();
+            f1.mma(acc);
+            PNP_SCHED_FENCE();
             __syncthreads();
+            f0.load(An, Bn, 0, wm0, wn0, lane);
         }
     }
 
@@ -515,8 +609,8 @@ __global__ void naive_conv_kernel(ConvArgs a) {
     for (int r = 0; r < a.R; ++r)
         for (int s = 0; s < a.S; ++s) {
             int ih = 0, iw = 0;
-            if (!map_coord(oh * a.stride - a.pad_t + r * a.dil, a.H, a.ups, a.pad_mode, ih)) continue;
-            if (!map_coord(ow * a.stride - a.pad_l + s * a.dil, a.W, a.ups, a.pad_mode, iw)) continue;
+            if (!map_coord<true>(oh * a.stride - a.pad_t + r * a.dil, a.H, a.ups, a.pad_mode, ih)) continue;
+            if (!map_coord<true>(ow * a.stride - a.pad_l + s * a.dil, a.W, a.ups, a.pad_mode, iw)) continue;
             const float* xp = a.x + ((size_t)(n * a.H + ih) * a.W + iw) * a.C;
             const float* wp = a.w + (size_t)((r * a.S + s) * a.C) * a.K + k;
             for (int c = 0; c < a.C; ++c) acc = fmaf(xp[c], wp[(size_t)c * a.K], acc);
@@ -569,7 +663,8 @@ int check_geom(const pnp_conv_geom* g, const char* who) {
                     "%s: SYMMETRIC geometry reads past the mirrored border", who);
     }
     const long long xin = (long long)g->N * g->H * g->W * g->C, yout = (long long)g->N * g->OH * g->OW * g->K;
-    PNP_REQUIRE(xin < (1ll << 31) && yout < (1ll << 31), "%s: tensor exceeds 2^31 elements", who);
+    PNP_REQUIRE(xin < (1ll << 30) && yout < (1ll << 30) && (long long)g->R * g->S * g->C * g->K < (1ll << 30),
+                "%s: tensor exceeds 2^30 elements (32-bit buffer offsets)", who);
     return PNP_OK;
 }
 
@@ -587,30 +682,34 @@ ConvArgs make_args(const float* x, const float* w, float* y, const pnp_conv_geom
     a.do_drop = 0; a.drop_scale = 1.f; a.drop_key = 0; a.drop_thresh = 0;
     static const int env_noswz = getenv("PNP_CONV_NOSWIZZLE") ? 1 : 0;
     a.xcd_swizzle = env_noswz ? 0 : 1;
+    a.x_bytes = (unsigned)((size_t)g->N * g->H * g->W * g->C * sizeof(float));
+    a.w_bytes = (unsigned)((size_t)g->R * g->S * g->C * g->K * sizeof(float));
     return a;
 }
 
-template <int BM, int BN, int WM, int WN, bool DGRAD>
+template <int BM, int BN, int WM, int WN, bool DGRAD, bool VECB>
 int launch_fwd_tile(ConvArgs& a, hipStream_t st) {
     a.nblk_m = pnp_cdiv(a.M, BM);
     a.nblk_n = pnp_cdiv(a.K, BN);
     dim3 grid((unsigned)(a.nblk_m * a.nblk_n));
     const int mode = (a.C % 32 == 0) ? 0 : ((a.C % 4 == 0) ? 1 : 2);
-    if (mode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0, DGRAD>), grid, dim3(NTHREADS), 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 1, DGRAD>), grid, dim3(NTHREADS), 0, st, a);
-    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 2, DGRAD>), grid, dim3(NTHREADS), 0, st, a);
+    if (mode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0, DGRAD, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 1, DGRAD, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 2, DGRAD, VECB>), grid, dim3(NTHREADS), 0, st, a);
     PNP_CHECK_LAUNCH("conv_fwd_kernel");
     return PNP_OK;
 }
 
 template <bool DGRAD>
 int launch_fwd(ConvArgs& a, hipStream_t st) {
-    if (a.K > 64) return launch_fwd_tile<128, 128, 2, 2, DGRAD>(a, st);
-    if (a.K > 32) return launch_fwd_tile<128, 64, 2, 2, DGRAD>(a, st);
-    return launch_fwd_tile<128, 32, 4, 1, DGRAD>(a, st);
+    // filter counts that are not a multiple of 4 (K = 5 logits, K = 1 critic FC, ...) take the scalar-B variant of the narrow tile
+    if ((a.K & 3) != 0) return launch_fwd_tile<128, 32, 4, 1, DGRAD, false>(a, st);
+    if (a.K > 64) return launch_fwd_tile<128, 128, 2, 2, DGRAD, true>(a, st);
+    if (a.K > 32) return launch_fwd_tile<128, 64, 2, 2, DGRAD, true>(a, st);
+    return launch_fwd_tile<128, 32, 4, 1, DGRAD, true>(a, st);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool VECB>
 int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStream_t st) {
     a.nblk_m = pnp_cdiv(a.Kred, BM);
     a.nblk_n = pnp_cdiv(a.K, BN);
@@ -632,10 +731,8 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     a.split_stride = (long long)nout;
     a.y = (nsplit > 1) ? ws : dw;
     dim3 grid((unsigned)(nblk * nsplit));
-    const int mode = (a.C % BM == 0) ? 0 : ((a.C % 4 == 0) ? 1 : 2);
-    if (mode == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 0>), grid, dim3(NTHREADS), 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 1>), grid, dim3(NTHREADS), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 2>), grid, dim3(NTHREADS), 0, st, a);
+    if (a.C % 4 == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 1, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 2, VECB>), grid, dim3(NTHREADS), 0, st, a);
     PNP_CHECK_LAUNCH("conv_wgrad_kernel");
     if (nsplit > 1) {
         int nb = pnp_cdiv((long long)nout, 256);
@@ -742,12 +839,14 @@ int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_
     if (int e = check_geom(g, "pnp_conv2d_wgrad")) return e;
     PNP_REQUIRE(x && dy && dw, "pnp_conv2d_wgrad: null pointer");
     ConvArgs a = make_args(x, dy, dw, g);
+    a.w_bytes = (unsigned)((size_t)g->N * g->OH * g->OW * g->K * sizeof(float));   // a.w is dy [P][K] here
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     if (!ws) workspace_bytes = 0;
-    if (a.K > 64) return launch_wgrad_tile<128, 128, 2, 2>(a, dw, ws, workspace_bytes, st);
-    if (a.K > 32) return launch_wgrad_tile<128, 64, 2, 2>(a, dw, ws, workspace_bytes, st);
-    return launch_wgrad_tile<128, 32, 4, 1>(a, dw, ws, workspace_bytes, st);
+    if ((a.K & 3) != 0) return launch_wgrad_tile<128, 32, 4, 1, false>(a, dw, ws, workspace_bytes, st);
+    if (a.K > 64) return launch_wgrad_tile<128, 128, 2, 2, true>(a, dw, ws, workspace_bytes, st);
+    if (a.K > 32) return launch_wgrad_tile<128, 64, 2, 2, true>(a, dw, ws, workspace_bytes, st);
+    return launch_wgrad_tile<128, 32, 4, 1, true>(a, dw, ws, workspace_bytes, st);
 }
 
 int pnp_sympad_bwd(const float* dxp, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t p, void* stream) {
