@@ -68,7 +68,8 @@ class ConvFwdProbe(object):
             e1.record()
             flops = 2.0 * g.N * g.OH * g.OW * g.R * g.S * g.C * g.K
             nbytes = 4.0 * (g.N * g.H * g.W * g.C + g.N * g.OH * g.OW * g.K + g.R * g.S * g.C * g.K)
-            big = (g.K > 64) and (g.C % 32 == 0) and g.R == 3
+            # launches served by the 128x128-tile kernel symbol conv_fwd_kernel<128,128,2,2,0,0,true> (csrc/conv_igemm.hip::launch_fwd)
+            big = (g.K > 64) and (g.K % 4 == 0) and (g.C % 32 == 0) and (-(-g.N * g.OH * g.OW // 128) * -(-g.K // 128) >= 384)
             probe.records.append((flops, nbytes, big, e0, e1))
             return y
         self.K.conv2d_fwd = wrapped
@@ -201,7 +202,7 @@ def main():
             fl, by, ms, n = tot[True]
             if n:
                 ach = fl / (ms * 1e-3) / 1e12
-                res["roofline"] = {"bound": "mfma", "kernel": "conv_fwd_kernel<128,128,2,2,0> via pnp_conv2d_fwd (3x3 fwd convs, C%32==0, K>64)",
+                res["roofline"] = {"bound": "mfma", "kernel": "conv_fwd_kernel<128,128,2,2,0,0,true> (forward 3x3 convs on the 128x128 MFMA tile: 256->512, 512->512 (+dilated), 512->2560)",
                                    "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                                    "traffic": None, "launches": n, "avg_launch_ms": ms / n,
                                    "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mbytes_per_launch": by / n / 1e6}

@@ -354,16 +354,17 @@ struct Frag {
 #define PNP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // ================================ forward / dgrad kernel ========================================
-// DGRAD only makes the data-gradient launches a distinct kernel symbol (so that rocprof separates them from the
-// forward convolutions) and lets the forward instantiation drop the zero-upsampling arithmetic (ups == 1).
-template <int BM, int BN, int WM, int WN, int MODE, bool DGRAD, bool VECB>
+// KIND 0 = forward, 1 = data gradient of a stride-1 convolution, 2 = data gradient of a strided convolution (input = dy
+// zero-upsampled by `ups`).  0 and 1 run the same code; the distinct symbol lets rocprof separate forward from backward
+// launches.  Only KIND 2 carries the integer division of the upsampling test.
+template <int BM, int BN, int WM, int WN, int MODE, int KIND, bool VECB>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BK + 4, LDB = BN + 4;
     constexpr int ASZ = BM * LDA, BSZ = BK * LDB;
     __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
 
-    if constexpr (!DGRAD) a.ups = 1;
+    if constexpr (KIND != 2) a.ups = 1;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
     const int m0 = mt * BM, n0 = nt * BN;
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
-    FwdALoader<BM, MODE, DGRAD> la;
+    FwdALoader<BM, MODE, KIND == 2> la;
     BLoader<BN, VECB> lb;
     la.init(t, m0, a);
     lb.init(t);
@@ -687,26 +688,36 @@ ConvArgs make_args(const float* x, const float* w, float* y, const pnp_conv_geom
     return a;
 }
 
-template <int BM, int BN, int WM, int WN, bool DGRAD, bool VECB>
+template <int BM, int BN, int WM, int WN, int KIND, bool VECB>
 int launch_fwd_tile(ConvArgs& a, hipStream_t st) {
     a.nblk_m = pnp_cdiv(a.M, BM);
     a.nblk_n = pnp_cdiv(a.K, BN);
     dim3 grid((unsigned)(a.nblk_m * a.nblk_n));
     const int mode = (a.C % 32 == 0) ? 0 : ((a.C % 4 == 0) ? 1 : 2);
-    if (mode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0, DGRAD, VECB>), grid, dim3(NTHREADS), 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 1, DGRAD, VECB>), grid, dim3(NTHREADS), 0, st, a);
-    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 2, DGRAD, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    if (mode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 1, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 2, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
     PNP_CHECK_LAUNCH("conv_fwd_kernel");
     return PNP_OK;
 }
 
-template <bool DGRAD>
+// Tile choice: the widest tile that still yields >= 384 workgroups (1.5 per CU; 2 fit), else the narrowest.  The 32^2
+// layers with 128/256 filters only produce 128/256 tiles of 128x128 — half of the chip idle — but 256/512 of 128x64.
+template <int KIND>
 int launch_fwd(ConvArgs& a, hipStream_t st) {
     // filter counts that are not a multiple of 4 (K = 5 logits, K = 1 critic FC, ...) take the scalar-B variant of the narrow tile
-    if ((a.K & 3) != 0) return launch_fwd_tile<128, 32, 4, 1, DGRAD, false>(a, st);
-    if (a.K > 64) return launch_fwd_tile<128, 128, 2, 2, DGRAD, true>(a, st);
-    if (a.K > 32) return launch_fwd_tile<128, 64, 2, 2, DGRAD, true>(a, st);
-    return launch_fwd_tile<128, 32, 4, 1, DGRAD, true>(a, st);
+    if ((a.K & 3) != 0) return launch_fwd_tile<128, 32, 4, 1, KIND, false>(a, st);
+    static const int force = getenv("PNP_CONV_TILE") ? atoi(getenv("PNP_CONV_TILE")) : -1;   // experiments: 0/1/2 = 128x{128,64,32}
+    const long long mt = pnp_cdiv(a.M, 128);
+    // measured at B=16 (tools/bench_conv.py, PNP_CONV_TILE sweep): 128->128@32^2 44 TF/s with 128x128 tiles (128 workgroups) vs
+    // 70 with 128x64; 256->512@32^2 107 vs 100; 128->64 (dgrad) 34 with 128x64 vs 46 with 128x32.
+    int tile = 2;
+    if (a.K > 64 && mt * pnp_cdiv(a.K, 128) >= 384) tile = 0;
+    else if (a.K > 32 && (mt * pnp_cdiv(a.K, 64) >= 384 || a.K > 64)) tile = 1;
+    if (force >= 0 && !(force == 0 && a.K <= 64) && !(force <= 1 && a.K <= 32)) tile = force;
+    if (tile == 0) return launch_fwd_tile<128, 128, 2, 2, KIND, true>(a, st);
+    if (tile == 1) return launch_fwd_tile<128, 64, 2, 2, KIND, true>(a, st);
+    return launch_fwd_tile<128, 32, 4, 1, KIND, true>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN, bool VECB>
@@ -772,7 +783,7 @@ int pnp_conv2d_fwd(const float* x, const float* w, float* y, const pnp_conv_geom
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
     }
-    return launch_fwd<false>(a, (hipStream_t)stream);
+    return launch_fwd<0>(a, (hipStream_t)stream);
 }
 
 int pnp_conv2d_fwd_naive(const float* x, const float* w, float* y, const pnp_conv_geom* g, void* stream) {
@@ -822,7 +833,7 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
     float* out = sym ? (float*)((char*)workspace + woff) : dx;
     ConvArgs a = make_args(dy, wt, out, &d);
     a.ups = g->stride;
-    if (int e = launch_fwd<true>(a, st)) return e;
+    if (int e = (g->stride > 1 ? launch_fwd<2>(a, st) : launch_fwd<1>(a, st))) return e;
     if (sym) {
         const size_t total = (size_t)g->N * g->H * g->W * g->C;
         hipLaunchKernelGGL(sympad_bwd_kernel, dim3((unsigned)pnp_cdiv((long long)total, 256)), dim3(256), 0, st,
