@@ -45,7 +45,7 @@ int pnp_device_info(int device, int* cu_count, int* clock_khz, int* lds_bytes, c
  *   pad_mode PNP_PAD_SYMMETRIC: out-of-range taps mirror including the edge (tf.pad SYMMETRIC), pad_t=pad_l=k//2
  * Dropout (tf.nn.dropout, layers.py:25,74,93) is fused in the forward epilogue:
  *   y *= mask(seed, stream_id, flat_index) / keep_prob    (keep_prob >= 1 disables it)
- * mask is the Philox4x32-10 stream documented in pnp_dropout (below). */
+ * mask is the counter-hash stream documented at pnp_dropout (below). */
 typedef struct pnp_conv_geom {
     int32_t N, H, W, C;     /* input */
     int32_t K, R, S;        /* filter count and size */
@@ -75,8 +75,10 @@ int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_
  * cross-check for the MFMA kernels at sizes the CPU oracle cannot reach; not used by the product path. */
 int pnp_conv2d_fwd_naive(const float* x, const float* w, float* y, const pnp_conv_geom* g, void* stream);
 
-/* tf.nn.dropout (layers.py:25,74,93): y = x * floor(keep + u) / keep with u = Philox4x32-10(key=(seed_lo,seed_hi),
- * counter=(flat_index/4, stream_id, 0, 0))[flat_index%4] * 2^-32.  Used for the backward of the fused epilogue. */
+/* tf.nn.dropout (layers.py:25,74,93): y = x * keep_mask / keep.  TF's own RNG stream is not reproducible outside TF, so the
+ * mask stream is specified here (csrc/pnp_common.h; restated in numpy in oracle/tf_ops.py):
+ *   keep_mask(idx) = (fmix32((idx * 0xCC9E2D51) ^ key(seed, stream_id)) >> 8) >= round((1 - keep) * 2^24)
+ * with fmix32 = the murmur3 finaliser and idx the flat element index.  Also used for the backward of the fused epilogue. */
 int pnp_dropout(const float* x, float* y, size_t n, float keep_prob, uint64_t seed, uint32_t stream_id, void* stream);
 
 /* tf.contrib.layers.batch_norm(decay=.9, eps=1e-3, updates_collections=None) (layers.py:95-100), fused batch-norm semantics.
@@ -156,6 +158,13 @@ int pnp_critic_input_fwd(const float* a, int32_t Ca, int32_t tile_a, const float
                          const float* d, int32_t Cd, const float* logits, int32_t ncls, float* out, int64_t P, void* stream);
 int pnp_critic_input_bwd(const float* dout, float* da, int32_t Ca, int32_t tile_a, float* db, int32_t Cb, float* dc, int32_t Cc,
                          float* dd, int32_t Cd, float* dlogits, int32_t ncls, int64_t P, void* stream);
+
+/* WGAN critic losses (adversarial.py:455-459): out[0] = sum_i coef[i] * mean(logit_i[0..B)) over the (up to 4) non-NULL
+ * critic-logit vectors  {ct_cls, mr_cls, ct_mask, mr_mask};  e.g. dis_loss: coef = {+miu, -miu, +lambda*miu, -lambda*miu}. */
+int pnp_wgan_loss(const float* ct_cls, const float* mr_cls, const float* ct_mask, const float* mr_mask, int32_t B,
+                  float c_ct_cls, float c_mr_cls, float c_ct_mask, float c_mr_mask, float* out, void* stream);
+/* p[0..n) = value  (constant gradient of a mean: coef / B) */
+int pnp_fill(float* p, size_t n, float value, void* stream);
 
 /* y = a*x + b*y elementwise (gradient fan-in adds) */
 int pnp_axpby(const float* x, float* y, size_t n, float a, float b, void* stream);

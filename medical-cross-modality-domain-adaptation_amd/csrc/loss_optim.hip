@@ -310,6 +310,28 @@ __global__ void sum_final_kernel(const float* __restrict__ part, int n, float* o
     }
 }
 
+__global__ void wgan_loss_kernel(const float* a, const float* b, const float* c, const float* d, int B, float ca, float cb, float cc,
+                                 float cd, float* out) {
+    // B is the batch size (<= a few hundred): one wave, fixed order
+    const float* p[4] = {a, b, c, d};
+    const float co[4] = {ca, cb, cc, cd};
+    double tot = 0.0;
+    for (int q = 0; q < 4; ++q) {
+        if (!p[q]) continue;
+        float s = 0.f;
+        for (int i = threadIdx.x; i < B; i += 64) s += p[q][i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        tot += (double)co[q] * ((double)s / (double)B);
+    }
+    if (threadIdx.x == 0) out[0] = (float)tot;
+}
+
+__global__ void __launch_bounds__(NT) fill_kernel(float* p, size_t n, float v) {
+    const size_t gs = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += gs) p[i] = v;
+}
+
 template <int KIND>
 int run_opt(OptArgs a, hipStream_t st, const char* who) {
     if (a.n == 0) return PNP_OK;
@@ -401,6 +423,25 @@ int pnp_clip(float* w, size_t n, const uint8_t* chunk_mask, float lo, float hi, 
     PNP_REQUIRE(w && lo <= hi, "pnp_clip: bad argument");
     OptArgs a{w, nullptr, nullptr, nullptr, n, nullptr, chunk_mask, lo, hi, 0.f, 0.f, 0.f};
     return run_opt<3>(a, (hipStream_t)stream, "pnp_clip");
+}
+
+int pnp_wgan_loss(const float* ct_cls, const float* mr_cls, const float* ct_mask, const float* mr_mask, int32_t B, float c_ct_cls,
+                  float c_mr_cls, float c_ct_mask, float c_mr_mask, float* out, void* stream) {
+    PNP_REQUIRE(out && B > 0 && (ct_cls || mr_cls || ct_mask || mr_mask), "pnp_wgan_loss: bad argument");
+    hipLaunchKernelGGL(wgan_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ct_cls, mr_cls, ct_mask, mr_mask, B, c_ct_cls,
+                       c_mr_cls, c_ct_mask, c_mr_mask, out);
+    PNP_CHECK_LAUNCH("wgan_loss_kernel");
+    return PNP_OK;
+}
+
+int pnp_fill(float* p, size_t n, float value, void* stream) {
+    PNP_REQUIRE(p || n == 0, "pnp_fill: null pointer");
+    if (n == 0) return PNP_OK;
+    size_t nb = (n + NT - 1) / NT;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)nb), dim3(NT), 0, (hipStream_t)stream, p, n, value);
+    PNP_CHECK_LAUNCH("fill_kernel");
+    return PNP_OK;
 }
 
 size_t pnp_reduce_workspace_bytes(size_t n) {

@@ -161,3 +161,29 @@ class CriticInputFn(Function):
         need = tuple(ctx.needs_input_grad[:5])
         da, db, dc, dd, dl = K.critic_input_bwd(_contig(dout), ctx.shapes, ctx.tile_a, need)
         return da, db, dc, dd, dl, None
+
+
+class WganLossFn(Function):
+    """scalar = sum_i coef_i * mean(critic_logits_i)  (adversarial.py:455-459).  Must be the ROOT of backward: the upstream
+    gradient is `gscale` (1/world_size under data parallelism); each input receives the constant coef_i * gscale / B."""
+
+    @staticmethod
+    def forward(ctx, ct_cls, mr_cls, ct_mask, mr_mask, coefs, gscale):
+        ts = [None if t is None else _contig(t) for t in (ct_cls, mr_cls, ct_mask, mr_mask)]
+        ctx.shapes = [None if t is None else tuple(t.shape) for t in ts]
+        ctx.coefs, ctx.gscale = tuple(coefs), gscale
+        ctx.dev = next(t for t in ts if t is not None).device
+        return K.wgan_loss(ts[0], ts[1], ts[2], ts[3], coefs)
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads = []
+        for i, shp in enumerate(ctx.shapes):
+            if shp is None or not ctx.needs_input_grad[i]:
+                grads.append(None)
+            else:
+                n = 1
+                for d in shp:
+                    n *= d
+                grads.append(K.filled(shp, ctx.coefs[i] * ctx.gscale / n, ctx.dev))
+        return grads[0], grads[1], grads[2], grads[3], None, None

@@ -308,3 +308,18 @@ def critic_input_bwd(dout, shapes, tile_a, need=(True,) * 5):
     check(lib.pnp_critic_input_bwd(_p(dout), _p(da), sa[-1], tile_a, _p(db), sb[-1], _p(dc), sc[-1], _p(dd), sd[-1], _p(dl), sl[-1],
                                    P, _stream()), "pnp_critic_input_bwd")
     return da, db, dc, dd, dl
+
+
+def wgan_loss(ct_cls, mr_cls, ct_mask, mr_mask, coefs):
+    """adversarial.py:455-459: sum_i coef_i * mean(logits_i) over the non-None critic outputs -> 1-element tensor"""
+    ref = next(t for t in (ct_cls, mr_cls, ct_mask, mr_mask) if t is not None)
+    out = torch.empty(1, dtype=torch.float32, device=ref.device)
+    check(_lib.load().pnp_wgan_loss(_p(ct_cls), _p(mr_cls), _p(ct_mask), _p(mr_mask), ref.numel(), float(coefs[0]), float(coefs[1]),
+                                    float(coefs[2]), float(coefs[3]), _p(out), _stream()), "pnp_wgan_loss")
+    return out
+
+
+def filled(shape, value, device):
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    check(_lib.load().pnp_fill(_p(t), t.numel(), float(value), _stream()), "pnp_fill")
+    return t

@@ -1,0 +1,156 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/tf_ops.py header; PARITY UNPINNED for TF arithmetic).
+
+CPU restatement of the adaptation graph of the reference's adversarial.py:
+  zip network (MR `group_1..6` + CT `adapt_1..6`, adversarial.py:127-271), shared second half (273-318),
+  feature critic (320-400), mask critic (402-443), WGAN losses + L2 (445-476), RMSProp steps + weight clip (633-656, 852-881).
+Variables: dict {TF variable name: torch CPU tensor}, same names as the product's VariableStore.
+Dropout stream ids are consumed in graph-construction order (one per conv call), like the product.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import tf_ops as T
+
+CRITIC_KEEP = 0.75
+
+
+class _Ctx(object):
+    def __init__(self, V, keep_prob, seed):
+        self.V, self.keep, self.seed, self.sid = V, keep_prob, seed, 0
+
+    def conv(self, x, w, stride=1, dil=1, padding="SAME", keep=None):
+        y = T.conv2d(x, w, stride, dil, padding)
+        s = self.sid
+        self.sid += 1
+        return T.dropout(y, self.keep if keep is None else keep, self.seed, s)
+
+    def bn(self, x, scope, train):
+        V = self.V
+        return T.batch_norm(x, V[scope + "/gamma"], V[scope + "/beta"], V[scope + "/moving_mean"], V[scope + "/moving_variance"], train)
+
+    def cbr(self, x, w, scope, train, stride=1, dil=1, padding="SAME", keep=None):
+        return T.leaky_relu(self.bn(self.conv(x, w, stride, dil, padding, keep), scope, train))
+
+    def rb(self, x, w1, w2, scope, train, dil=1, keep=None):
+        inner = T.leaky_relu(self.bn(self.conv(x, w1, 1, dil, keep=keep), scope + "_1", train))
+        inner = self.bn(self.conv(inner, w2, 1, dil, keep=keep), scope + "_2", train)
+        cin, cout = x.shape[-1], w2.shape[-1]
+        sc = T.pad_channels(x, cin // 2) if cout != cin else x
+        return T.leaky_relu(sc + inner)
+
+
+def _front(c, x, mr, train):
+    """group_1..6 (mr=True) or adapt_1..6: returns (conv4_2, conv6_2)"""
+    V = c.V
+    g = (lambda k: "group_%d" % k) if mr else (lambda k: "adapt_%d" % k)
+    bn = (lambda k, j: "%s/pred_%d_%d" % (g(k), k, j)) if mr else (lambda k, j: "%s/adapt_%d_%d" % (g(k), k, j))
+    w = lambda k, i: V[g(k) + "/Variable" + ("" if i == 0 else "_%d" % i)]
+    h = c.conv(x, w(1, 0))
+    h = c.rb(h, w(1, 1), w(1, 2), bn(1, 1) if mr else "adapt_1/adapt_1", train)
+    h = T.max_pool2(h)
+    h = c.rb(h, w(2, 0), w(2, 1), bn(2, 1) if mr else "adapt_2/adapt_2", train)
+    h = T.max_pool2(h)
+    c4 = None
+    for k in (3, 4, 5, 6):
+        h = c.rb(h, w(k, 0), w(k, 1), bn(k, 1), train)
+        h = c.rb(h, w(k, 2), w(k, 3), bn(k, 2), train)
+        if k == 3:
+            h = T.max_pool2(h)
+        if k == 4:
+            c4 = h
+    return c4, h
+
+
+def _second_half(c, x, train, n_class=5):
+    V = c.V
+    w = lambda k, i: V["group_%d/Variable" % k + ("" if i == 0 else "_%d" % i)]
+    h = c.rb(x, w(7, 0), w(7, 1), "group_7/pred_7_1", train)
+    b7 = c.rb(h, w(7, 2), w(7, 3), "group_7/pred_7_2", train)
+    h = c.rb(b7, w(8, 0), w(8, 1), "group_8/pred_8_1", train, dil=2)
+    b8 = c.rb(h, w(8, 2), w(8, 3), "group_8/pred_8_2", train, dil=2)
+    h = c.cbr(b8, w(9, 0), "group_9/pred_9_1", train)
+    c9 = c.cbr(h, w(9, 1), "group_9/pred_9_2", train)
+    h = c.conv(c9, V["group_10/Variable"], padding="SYMMETRIC")
+    h = T.PS(h, 8, n_class * 8)
+    logits = c.conv(h, V["output/Variable"], padding="SYMMETRIC", keep=1.0)
+    return c9, b8, b7, logits
+
+
+def _classifier(c, c4, c6, b7, c9, logits):
+    V = c.V
+    p = "cls_scope/"
+    am = torch.argmax(logits.detach(), dim=-1, keepdim=True).to(logits.dtype)
+    x = torch.cat([T.PS(c4, 8, 2).repeat(1, 1, 1, 3), T.PS(c6, 8, 4), T.PS(b7, 8, 8), T.PS(c9, 8, 8), logits, am], dim=3)
+    spec = [(1, 3, 2), (2, 5, 2), (3, 3, 2), (4, 3, 2), (5, 5, 4)]
+    h = x
+    for k, kd, sd in spec:
+        s = p + "cls_%d/" % k
+        h = c.rb(h, V[s + "Variable"], V[s + "Variable_1"], s + "cls_%d" % k, True, keep=CRITIC_KEEP)
+        h = c.cbr(h, V[s + "Variable_2"], s + "cls_%d_3" % k, True, stride=sd, keep=CRITIC_KEEP)
+    h = c.cbr(h, V[p + "cls_6/Variable"], p + "cls_6/cls_6", True, stride=2, padding="SYMMETRIC", keep=CRITIC_KEEP)
+    return h.reshape(h.shape[0], -1) @ V[p + "cls_out/Variable"]
+
+
+def _mask_critic(c, logits):
+    V = c.V
+    p = "mask_cls_scope/"
+    h = c.cbr(logits, V[p + "mask_cls_1/Variable"], p + "mask_cls_1/mask_cls_1", True, stride=2, keep=CRITIC_KEEP)
+    s = p + "mask_cls_2/"
+    h = c.rb(h, V[s + "Variable"], V[s + "Variable_1"], s + "m_cls_2", True, keep=CRITIC_KEEP)
+    h = c.cbr(h, V[s + "Variable_2"], s + "m_cls_2_3", True, stride=4, keep=CRITIC_KEEP)
+    s = p + "mask_cls_3/"
+    h = c.rb(h, V[s + "Variable"], V[s + "Variable_1"], s + "m_cls_3", True, keep=CRITIC_KEEP)
+    h = c.cbr(h, V[s + "Variable_2"], s + "m_cls_3_3", True, stride=4, keep=CRITIC_KEEP)
+    h = c.cbr(h, V[p + "mask_cls_4/Variable"], p + "mask_cls_4/m_cls_4", True, stride=4, padding="SYMMETRIC", keep=CRITIC_KEEP)
+    return h.reshape(h.shape[0], -1) @ V[p + "m_cls_out/Variable"]
+
+
+def adv_forward(V, mr, ct, keep_prob, mr_front_bn=False, joint_bn=False, ct_front_bn=False, seed=0, segmenter_no_grad=False):
+    """the graph of adversarial.py:82-119 for the fed branches (mr or ct may be None)"""
+    c = _Ctx(V, keep_prob, seed)
+    out = {}
+    ctx = torch.no_grad() if segmenter_no_grad else torch.enable_grad()
+    with ctx:
+        z = {}
+        if mr is not None:
+            z["mr"] = _front(c, mr, True, mr_front_bn)
+        if ct is not None:
+            z["ct"] = _front(c, ct, False, ct_front_bn)
+        feats = {}
+        for br in ("ct", "mr"):
+            if br in z:
+                feats[br] = _second_half(c, z[br][1], joint_bn)
+    for br in ("ct", "mr"):
+        if br in z:
+            c9, b8, b7, lg = feats[br]
+            out[br + "_cls"] = _classifier(c, z[br][0], z[br][1], b7, c9, lg)
+            out[br + "_logits"] = lg
+    for br in ("ct", "mr"):
+        if br in z:
+            out[br + "_mask"] = _mask_critic(c, feats[br][3])
+    return out
+
+
+def wgan_losses(o, miu_dis=0.002, miu_gen=0.002, lam=0.3):
+    """adversarial.py:455-474 (without the L2 terms)"""
+    dis = gen = None
+    if "mr_cls" in o:
+        dis = -miu_dis * (o["mr_cls"] - o["ct_cls"]).mean() + lam * (-miu_dis * (o["mr_mask"] - o["ct_mask"]).mean())
+    gen = -miu_gen * o["ct_cls"].mean() + lam * (-miu_gen * o["ct_mask"].mean())
+    return dis, gen
+
+
+def l2_coefficient(name, which, miu=0.002, gan_reg=1e-4, lam=0.3, sub_iter=1):
+    """effective L2 coefficient on `name` inside dis_reg / gen_reg (adversarial.py:467-474, 644, 650): critic weight lists are
+    appended once per builder call (CT and MR) -> multiplicity 2; ct_front_weights once; BN variables never."""
+    if "Variable" not in name:
+        return 0.0
+    if which == "dis":
+        if name.startswith("cls_scope/"):
+            return gan_reg * miu * 2.0 / sub_iter
+        if name.startswith("mask_cls_scope/"):
+            return gan_reg * miu * 2.0 * lam / sub_iter
+        return 0.0
+    return gan_reg * miu / sub_iter if name.startswith("adapt_") else 0.0

@@ -1,0 +1,85 @@
+"""not gpu: the adaptation model's graph construction on CPU (symbolic pass): TF variable names against the lists the reference
+authors recorded (lists/half_zip_*_vars, lists/pred_bn_list via tests/golden/golden.json), variable grouping, optimiser tables."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+COST = {"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.3}
+NETCFG = {"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True, "cls_trainable": True, "m_cls_trainable": True}
+
+
+@pytest.fixture(scope="module")
+def net():
+    adv = pkg("adversarial")
+    return adv.Full_DRN(channels=3, n_class=5, batch_size=2, cost_kwargs=dict(COST), network_config=dict(NETCFG), device="cpu")
+
+
+def test_variable_names_match_reference_lists(net):
+    meta = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+    names = list(net.store.vars.keys())
+    strip = lambda l: [n.split(":")[0] for n in l]
+    mri, ct = strip(meta["list_half_zip_mri_vars"]), strip(meta["list_half_zip_ct_vars"])
+    assert len(mri) == len(ct) == 101
+    for n in mri + ct:
+        assert n in net.store.vars, n
+    # positional correspondence used by the MR -> CT weight copy (adversarial.py:706-717): same shapes, same order of creation
+    for m, c in zip(mri, ct):
+        assert net.store.vars[m].shape == net.store.vars[c].shape, (m, c)
+    ours_mr = [n for n in names if n.startswith("group_") and int(n.split("/")[0].split("_")[1]) <= 6]
+    ours_ct = [n for n in names if n.startswith("adapt_")]
+    assert sorted(ours_mr) == sorted(mri) and sorted(ours_ct) == sorted(ct)
+    # BN scopes of the MR path + shared half: pred_bn_list (120 names, recorded without the group_k/ prefix)
+    pred = strip(meta["list_pred_bn_list"])
+    ours_pred = [n.split("/", 1)[1] for n in names if "/pred_" in n]
+    assert sorted(ours_pred) == sorted(pred)
+    assert len([n for n in names if n.endswith("/gamma")]) == 30 + 20 + 16 + 8      # segmenter + adapt + cls + mask critic BN layers
+
+
+def test_variable_groups_and_parameter_counts(net):
+    cnt = lambda vs: sum(v.numel for v in vs if "Variable" in v.name)
+    assert cnt(net.adapt_vars) == 5087664                                       # early layers 5.09 M
+    assert cnt([v for v in net.cls_vars if v.name.startswith("cls_scope")]) == 21729280
+    assert cnt([v for v in net.cls_vars if v.name.startswith("mask_cls_scope")]) == 1098448
+    assert cnt(net.mri_seg_vars) == 39302456
+    assert all(not v.trainable for v in net.mri_seg_vars)                       # mr_front / joint frozen
+    assert all(v.trainable for v in net.adapt_vars if not v.name.endswith(("moving_mean", "moving_variance")))
+    # weight lists: critics appended once per builder call (CT, MR) -> every name twice; joint_weights stays empty (reference bug)
+    wl = net._weight_lists
+    assert all(wl["cls_weights"].count(n) == 2 for n in set(wl["cls_weights"])) and len(set(wl["cls_weights"])) == 17
+    assert all(wl["m_cls_weights"].count(n) == 2 for n in set(wl["m_cls_weights"])) and len(set(wl["m_cls_weights"])) == 9
+    assert all(wl["ct_front_weights"].count(n) == 1 for n in wl["ct_front_weights"]) and len(wl["ct_front_weights"]) == 21
+    assert wl["joint_weights"] == []
+
+
+def test_optimiser_tables(net):
+    adv = pkg("adversarial")
+    tr = adv.Trainer(net, None, None, None, None, num_cls=5, batch_size=2, opt_kwargs={"learning_rate": 3e-4},
+                     train_config={"dis_sub_iter": 20, "gen_sub_iter": 1})
+    dis, gen = tr._get_optimizer()
+    st = net.store
+    chunk = lambda name: st.vars[name].offset // 1024
+    l2d, l2g = dis.l2.numpy(), gen.l2.numpy()
+    assert np.isclose(l2d[chunk("cls_scope/cls_1/Variable")], 1e-4 * 0.002 * 2 / 20)
+    assert np.isclose(l2d[chunk("mask_cls_scope/mask_cls_1/Variable")], 1e-4 * 0.002 * 2 * 0.3 / 20)
+    assert l2d[chunk("adapt_1/Variable")] == 0 and l2d[chunk("cls_scope/cls_1/cls_1_1/gamma")] == 0
+    assert np.isclose(l2g[chunk("adapt_3/Variable_2")], 1e-4 * 0.002) and l2g[chunk("cls_scope/cls_1/Variable")] == 0
+    md, mg, mc = dis.mask.numpy(), gen.mask.numpy(), tr.clip_mask.numpy()
+    assert md[chunk("cls_scope/cls_out/Variable")] == 1 and md[chunk("adapt_1/Variable")] == 0
+    assert mg[chunk("adapt_1/adapt_1_1/gamma")] == 1 and mg[chunk("mask_cls_scope/m_cls_out/Variable")] == 0
+    assert mc[chunk("cls_scope/cls_out/Variable")] == 1 and mc[chunk("mask_cls_scope/mask_cls_4/Variable")] == 1
+    assert mc[chunk("cls_scope/cls_1/cls_1_1/gamma")] == 0                      # BN variables are not clipped
+    assert float(dis.ms.min()) == 1.0                                           # RMSProp slot initialised to ONE
+
+
+def test_pretrain_phase_freezes_adaptation_module():
+    adv = pkg("adversarial")
+    cfg = dict(NETCFG, ct_front_trainable=False)
+    n = adv.Full_DRN(channels=3, n_class=5, batch_size=2, cost_kwargs=dict(COST, lambda_mask_loss=0), network_config=cfg, device="cpu")
+    assert all(not v.trainable for v in n.adapt_vars)
+    assert n.lambda_mask_loss == 0.0
+    assert {v.name.split("/")[0] for v in n.store.trainable()} == {"cls_scope", "mask_cls_scope"}

@@ -1,0 +1,158 @@
+"""-m gpu: parity of the GAN steps (BASELINE configs 3/4 at reduced batch) against the CPU oracle (oracle/nets_adv.py):
+critic logits of both domains, dis / gen losses, gradients of every `cls` / `adapt` variable (fp64-adjudicated like the segmenter
+test), RMSProp update, weight clip, and which variables are allowed to move."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import nets_adv
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+COST = {"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.3}
+NETCFG = {"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True, "cls_trainable": True, "m_cls_trainable": True}
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _cos(a, b):
+    a = torch.as_tensor(a).double().reshape(-1)
+    b = torch.as_tensor(b).double().reshape(-1)
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+
+
+def he_state(net, seed):
+    """He-scaled conv weights (so that activations do not vanish), FC weights ~ N(0, 1/D); BN stats perturbed so that inference-mode BN is
+    not the identity"""
+    rng = np.random.default_rng(seed)
+    sd = net.store.state_dict()
+    for k, a in sd.items():
+        if "Variable" in k:
+            fan = np.prod(a.shape[:-1])
+            sd[k] = (rng.standard_normal(a.shape) * np.sqrt(2.0 / fan) * 0.9).astype(np.float32)
+        elif k.endswith("moving_mean"):
+            sd[k] = (0.05 * rng.standard_normal(a.shape)).astype(np.float32)
+        elif k.endswith("moving_variance"):
+            sd[k] = (1.0 + 0.2 * rng.random(a.shape)).astype(np.float32)
+        elif k.endswith("gamma"):
+            sd[k] = (1.0 + 0.05 * rng.standard_normal(a.shape)).astype(np.float32)
+    return sd
+
+
+def make_vars(sd, dtype, grad_names):
+    V = {}
+    for k, a in sd.items():
+        t = torch.from_numpy(np.array(a)).to(dtype)
+        if grad_names(k) and not k.endswith(("moving_mean", "moving_variance")):
+            t.requires_grad_(True)
+        V[k] = t
+    return V
+
+
+def grad_report(tag, got, ref64, ref32):
+    rows = [(k, _rel(got[k], ref64[k]), _rel(ref32[k], ref64[k]), _cos(got[k], ref64[k])) for k in ref64]
+    eh, ec = np.array([r[1] for r in rows]), np.array([r[2] for r in rows])
+    print("%s: gradient error vs fp64 over %d variables: hip median %.3e max %.3e | cpu-fp32 median %.3e max %.3e | min cosine %.8f" % (
+        tag, len(rows), np.median(eh), eh.max(), np.median(ec), ec.max(), min(r[3] for r in rows)))
+    assert np.median(eh) < 3.0 * np.median(ec) + 1e-4
+    assert eh.max() < max(3.0 * ec.max(), 1e-3)
+    assert min(r[3] for r in rows) > 0.9999
+
+
+def test_discriminator_and_generator_steps(dev):
+    adv = pkg("adversarial")
+    B = 2
+    rng = np.random.default_rng(0)
+    mr = rng.standard_normal((B, 256, 256, 3)).astype(np.float32)
+    ct = (rng.standard_normal((B, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32)
+    net = adv.Full_DRN(channels=3, n_class=5, batch_size=B, cost_kwargs=dict(COST), network_config=dict(NETCFG), device=dev, seed=1)
+    sd = he_state(net, 7)
+    net.store.load_state_dict(sd)
+    tr = adv.Trainer(net, None, None, None, None, num_cls=5, batch_size=B, opt_kwargs={"learning_rate": 3e-4},
+                     train_config={"dis_sub_iter": 20, "gen_sub_iter": 1})
+    tr._get_optimizer()
+    mrd, ctd = torch.from_numpy(mr).to(dev), torch.from_numpy(ct).to(dev)
+    keep = 0.75
+
+    # ------------------------------------------------ discriminator step -------------------------------------------------------
+    loss = net.dis_loss_and_grads(mrd, ctd, keep, drop_seed=11)
+    g_hip = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if "cls" in v.name}
+    assert all(float(v.tensor.grad.abs().max()) == 0.0 for v in net.store.trainable() if "cls" not in v.name)   # adapt_* untouched
+    is_cls = lambda k: "cls" in k
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        V = make_vars(sd, dt, is_cls)
+        o = nets_adv.adv_forward(V, torch.from_numpy(mr).to(dt), torch.from_numpy(ct).to(dt), keep, seed=11, segmenter_no_grad=True)
+        dis, _ = nets_adv.wgan_losses(o)
+        dis.backward()
+        res[dt] = (o, dis.detach(), {k: v.grad.clone() for k, v in V.items() if v.requires_grad}, V)
+    o64, dis64, g64, V64 = res[torch.float64]
+    o32, dis32, g32, _ = res[torch.float32]
+    print("dis loss hip %.9f cpu32 %.9f fp64 %.9f" % (float(loss), float(dis32), float(dis64)))
+    assert _rel(net.ct_logits, o64["ct_logits"]) < 1e-4 and _rel(net.mr_logits, o64["mr_logits"]) < 1e-4
+    assert abs(float(loss) - float(dis64)) < 1e-4 * abs(float(dis64)) + 1e-8
+    grad_report("dis", g_hip, g64, g32)
+    # RMSProp (+ L2 inside the kernel) + clip, from the HIP path's own gradients
+    before = net.store.state_dict()
+    tr.dis_optimizer.step()
+    pnpk = pkg("kernels")
+    pnpk.clip(net.store.arena, tr.clip_mask, -0.03, 0.03)
+    after = net.store.state_dict()
+    worst = 0.0
+    for k in g_hip:
+        w = torch.from_numpy(before[k].copy())
+        g = g_hip[k] + nets_adv.l2_coefficient(k, "dis", sub_iter=20) * w
+        T.rmsprop_update(w, g, torch.ones_like(w), 3e-4)
+        if "Variable" in k:
+            w = torch.clamp(w, -0.03, 0.03)
+        worst = max(worst, float((w - torch.from_numpy(after[k])).abs().max()))
+    print("dis update: worst weight error %.3e" % worst)
+    assert worst < 1e-7
+    for k in before:
+        if "cls" not in k:
+            assert np.array_equal(before[k], after[k]), k        # nothing outside cls_vars moves in a discriminator step
+    assert max(float(np.abs(after[k]).max()) for k in after if "cls" in k and "Variable" in k) <= 0.03 + 1e-9
+
+    # ------------------------------------------------ generator step -----------------------------------------------------------
+    net.store.load_state_dict(sd)
+    loss = net.gen_loss_and_grads(ctd, keep, drop_seed=12)
+    g_hip = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if "adapt" in v.name}
+    assert all(float(v.tensor.grad.abs().max()) == 0.0 for v in net.store.trainable() if "cls" in v.name)       # critics frozen
+    is_adapt = lambda k: k.startswith("adapt_")
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        V = make_vars(sd, dt, is_adapt)
+        o = nets_adv.adv_forward(V, None, torch.from_numpy(ct).to(dt), keep, ct_front_bn=True, seed=12)
+        _, gen = nets_adv.wgan_losses(o)
+        gen.backward()
+        res[dt] = (o, gen.detach(), {k: v.grad.clone() for k, v in V.items() if v.requires_grad}, V)
+    o64, gen64, g64, V64 = res[torch.float64]
+    _, gen32, g32, _ = res[torch.float32]
+    print("gen loss hip %.9f cpu32 %.9f fp64 %.9f" % (float(loss), float(gen32), float(gen64)))
+    assert _rel(net.ct_logits, o64["ct_logits"]) < 1e-4
+    assert abs(float(loss) - float(gen64)) < 1e-4 * abs(float(gen64)) + 1e-8
+    grad_report("gen", g_hip, g64, g32)
+    # CT-front BN moving statistics moved (ct_front_bn=True), shared-half ones did not (joint_bn=False)
+    after = net.store.state_dict()
+    assert _rel(after["adapt_1/adapt_1_1/moving_mean"], V64["adapt_1/adapt_1_1/moving_mean"]) < 1e-4
+    assert np.array_equal(after["group_7/pred_7_1_1/moving_mean"], sd["group_7/pred_7_1_1/moving_mean"])
+    before = net.store.state_dict()
+    tr.gen_optimizer.step()
+    after = net.store.state_dict()
+    worst = 0.0
+    for k in g_hip:
+        w = torch.from_numpy(before[k].copy())
+        g = g_hip[k] + nets_adv.l2_coefficient(k, "gen") * w
+        T.rmsprop_update(w, g, torch.ones_like(w), 3e-4)
+        worst = max(worst, float((w - torch.from_numpy(after[k])).abs().max()))
+    print("gen update: worst weight error %.3e" % worst)
+    assert worst < 1e-7
+    for k in before:
+        if not k.startswith("adapt_"):
+            assert np.array_equal(before[k], after[k]), k
