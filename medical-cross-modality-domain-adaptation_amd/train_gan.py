@@ -1,0 +1,103 @@
+"""Entry point mirroring the reference's train_gan.py (config dicts and --phase switch, train_gan.py:27-157).
+  --phase pre-train : warm up the feature critic (dis only, 1 sub-iteration, lambda_mask_loss = 0, CT front frozen)
+  --phase train-gan : joint training (20 dis : 1 gen, lambda_mask_loss = rate, dis_sub_iter += 1 every 300 steps)
+  --phase fine-tune : continue from a breakpoint (the reference's `training_config` NameError at train_gan.py:121 is fixed)
+Extra flags: --synthetic N, --batch-size, --iters, --epochs, --output, --baseline (source-segmenter .npz for the pre-train hand-off).
+"""
+import argparse
+import datetime
+import logging
+import os
+
+import numpy as np
+
+from . import adversarial as drn
+from .lib import _read_lists
+
+logging.basicConfig(level=logging.INFO)
+rate = 0.3
+date = datetime.datetime.now().strftime('%m%d')
+
+cost_kwargs = {"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": None}
+opt_kwargs = {"learning_rate": 3e-4}
+network_config = {"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": None, "cls_trainable": True,
+                  "m_cls_trainable": True, "restore_skip_kwd": ["Adam", "RMS", "cls"]}
+train_config = {"restore_from_baseline": None, "copy_main": None, "clear_rms": None, "lr_update": None, "dis_interval": 1, "gen_interval": 1,
+                "dis_sub_iter": 20, "gen_sub_iter": 1, "tag": "gan-" + str(rate) + "_" + date, "iter_upd_interval": 300, "dis_sub_iter_inc": 1,
+                "gen_sub_iter_inc": 0, "lr_decay_factor": 0.98, "checkpoint_space": 100, "training_iters": 200, "epochs": 600}
+
+
+def configure(phase):
+    """train_gan.py:85-126"""
+    ck, nc, tc = dict(cost_kwargs), dict(network_config), dict(train_config)
+    if phase == 'pre-train':
+        nc["ct_front_trainable"] = False
+        tc.update(restore_from_baseline=True, copy_main=True, clear_rms=True, lr_update=True, gen_interval=0, dis_sub_iter=1,
+                  dis_sub_iter_inc=0, checkpoint_space=2000, training_iters=201, epochs=100)
+        ck["lambda_mask_loss"] = 0
+    elif phase == 'train-gan':
+        nc["ct_front_trainable"] = True
+        tc.update(restore_from_baseline=False, copy_main=False, clear_rms=False, lr_update=True, tag=tc["tag"] + "-gan")
+        ck["lambda_mask_loss"] = rate
+    elif phase == 'fine-tune':
+        nc["ct_front_trainable"] = True
+        tc.update(restore_from_baseline=False, copy_main=False, clear_rms=False, lr_update=False, gen_interval=1, dis_sub_iter=30,
+                  tag=tc["tag"] + "-fine_tune")
+        ck["lambda_mask_loss"] = rate
+    else:
+        raise Exception("Please set a training phase!")
+    return ck, nc, tc
+
+
+def main(phase, argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--phase", default=phase)
+    ap.add_argument("--synthetic", type=int, default=0)
+    ap.add_argument("--batch-size", type=int, default=6)
+    ap.add_argument("--iters", type=int, default=None)
+    ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--output", default="./tmp_exps/mr2ct" + date)
+    ap.add_argument("--baseline", default=None)
+    ap.add_argument("--device", default="cuda")
+    args = ap.parse_args(argv)
+    ck, nc, tc = configure(args.phase)
+    num_cls, batch_size = 5, args.batch_size
+    output_path = args.output
+    os.makedirs(output_path, exist_ok=True)
+    if args.synthetic:
+        from .synthetic import write_dataset
+        mr_train = write_dataset(os.path.join(output_path, "syn_mr_train"), args.synthetic, seed=0, prefix="mr")
+        ct_train = write_dataset(os.path.join(output_path, "syn_ct_train"), args.synthetic, seed=1, prefix="ct")
+        mr_val = write_dataset(os.path.join(output_path, "syn_mr_val"), batch_size, seed=100, prefix="mr")
+        ct_val = write_dataset(os.path.join(output_path, "syn_ct_val"), batch_size, seed=101, prefix="ct")
+    else:
+        mr_train, mr_val = _read_lists("./lists/mr_train_list"), _read_lists("./lists/mr_val_list")
+        ct_train, ct_val = _read_lists("./lists/ct_train_list"), _read_lists("./lists/ct_val_list")
+        if not mr_train or not ct_train:
+            raise SystemExit("no ./lists/*_train_list found (use --synthetic N)")
+    adapt_var_list, mr_var_list = _read_lists("./lists/half_zip_ct_vars"), _read_lists("./lists/half_zip_mri_vars")
+    old_bn_list, new_bn_list = _read_lists("./lists/old_bn_list"), _read_lists("./lists/pred_bn_list")
+
+    net = drn.Full_DRN(channels=3, batch_size=batch_size, n_class=num_cls, cost_kwargs=ck, network_config=nc, device=args.device)
+    print("Network has been built ...")
+    if tc["restore_from_baseline"] and args.baseline:
+        with np.load(args.baseline) as z:
+            seg = {k.replace("|", "/"): z[k] for k in z.files}
+        net.load_baseline(seg, old_bn_list, new_bn_list, adapt_var_list, mr_var_list)
+        print("initializing from baseline model!")
+    trainer = drn.Trainer(net, mr_train, mr_val, ct_train, ct_val, adapt_var_list=adapt_var_list, mr_var_list=mr_var_list,
+                          old_bn_list=old_bn_list, new_bn_list=new_bn_list, num_cls=num_cls, batch_size=batch_size, opt_kwargs=dict(opt_kwargs),
+                          train_config=tc)
+    print("Now start training...")
+    trainer.train(output_path=output_path, restored_path=output_path, restore=not tc["restore_from_baseline"],
+                  training_iters=args.iters or tc["training_iters"], epochs=args.epochs or tc["epochs"])
+    return trainer
+
+
+if __name__ == "__main__":
+    import sys
+    ph = "train-gan"
+    for i, a in enumerate(sys.argv):
+        if a == "--phase" and i + 1 < len(sys.argv):
+            ph = sys.argv[i + 1]
+    main(phase=ph)

@@ -1,0 +1,69 @@
+"""not gpu: tfrecord framing + tf.train.Example codec round trips (config 1 "identical tfrecord inputs"), SliceQueue batches,
+entry-script phase configuration (train_gan.py:85-126)."""
+import os
+
+import numpy as np
+
+from conftest import pkg
+
+
+def test_crc32c_and_mask_kats():
+    t = pkg("tfrecord")
+    assert t.crc32c(b"123456789") == 0xE3069283              # the standard CRC-32C check value
+    assert t.crc32c(b"") == 0
+    c = t.crc32c(b"\x00" * 8)
+    assert t.masked_crc(b"\x00" * 8) == ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_example_roundtrip_and_slice_layout(tmp_path):
+    t = pkg("tfrecord")
+    rng = np.random.default_rng(0)
+    img = rng.standard_normal((16, 16, 3)).astype(np.float32)
+    lab = rng.integers(0, 5, size=(16, 16, 3)).astype(np.float32)
+    p = str(tmp_path / "a.tfrecords")
+    t.write_slice(p, img, lab)
+    recs = t.read_records(p, verify=True)
+    assert len(recs) == 1
+    ex = t.decode_example(recs[0])
+    assert sorted(ex) == ["data_vol", "dsize_dim0", "dsize_dim1", "dsize_dim2", "label_vol", "lsize_dim0", "lsize_dim1", "lsize_dim2"]
+    assert ex["dsize_dim0"] == 16 and ex["lsize_dim2"] == 3
+    s = t.read_slice(p, raw_size=(16, 16, 3), verify=True)
+    assert s.shape == (16, 16, 4) and np.array_equal(s[:, :, :3], img) and np.array_equal(s[:, :, 3], lab[:, :, 1])   # middle label slice
+    raw = bytearray(open(p, "rb").read())
+    raw[40] ^= 0xFF
+    open(p, "wb").write(raw)
+    try:
+        t.read_records(p, verify=True)
+        assert False, "corruption not detected"
+    except IOError:
+        pass
+
+
+def test_slice_queue_batches(tmp_path):
+    syn, t = pkg("synthetic"), pkg("tfrecord")
+    files = syn.write_dataset(str(tmp_path / "d"), 5, seed=0, size=32)
+    assert os.path.exists(str(tmp_path / "d" / "slice_list"))
+    q = t.SliceQueue(files, 4, capacity=8, raw_size=(32, 32, 3), threaded=True)
+    seen = set()
+    for _ in range(4):
+        b, ids = q.next_batch(4)
+        assert b.shape == (4, 32, 32, 4) and b.dtype == np.float32 and len(ids) == 4
+        assert set(np.unique(b[..., 3])) <= {0.0, 1.0, 2.0, 3.0, 4.0}
+        seen |= set(ids)
+    q.close()
+    assert seen == set(files)
+    q2 = t.SliceQueue(files, 2, raw_size=(32, 32, 3), threaded=False)
+    assert q2.next_batch()[0].shape == (2, 32, 32, 4)
+
+
+def test_train_gan_phase_configuration():
+    tg = pkg("train_gan")
+    ck, nc, tc = tg.configure("pre-train")
+    assert nc["ct_front_trainable"] is False and ck["lambda_mask_loss"] == 0
+    assert (tc["gen_interval"], tc["dis_sub_iter"], tc["dis_sub_iter_inc"], tc["training_iters"], tc["epochs"]) == (0, 1, 0, 201, 100)
+    ck, nc, tc = tg.configure("train-gan")
+    assert nc["ct_front_trainable"] is True and ck["lambda_mask_loss"] == 0.3
+    assert (tc["dis_sub_iter"], tc["gen_sub_iter"], tc["iter_upd_interval"], tc["dis_sub_iter_inc"]) == (20, 1, 300, 1)
+    ck, nc, tc = tg.configure("fine-tune")
+    assert tc["dis_sub_iter"] == 30 and tc["lr_update"] is False
+    assert tg.opt_kwargs["learning_rate"] == 3e-4 and ck["miu_dis"] == 0.002
