@@ -135,8 +135,12 @@ def main():
     args = ap.parse_args()
 
     par = importlib.import_module(PKG + ".parallel")
+    if os.environ.get("PNP_SAME_DEVICE"):        # test mode: every rank on GPU 0 (with PNP_DIST_BACKEND=gloo); never used for results
+        os.environ["LOCAL_RANK_ORIG"] = os.environ.get("LOCAL_RANK", "0")
     rank, local, world = par.init_distributed()
     assert world == max(args.gpus, 1) or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if os.environ.get("PNP_SAME_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

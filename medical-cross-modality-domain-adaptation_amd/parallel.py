@@ -23,7 +23,9 @@ def init_distributed(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # PNP_DIST_BACKEND=gloo lets the overlapped reducer be exercised with several ranks sharing ONE GPU (RCCL refuses
+            # duplicate devices); production is always nccl (= RCCL over xGMI)
+            backend = os.environ.get("PNP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1,0 +1,34 @@
+"""-m gpu: data-parallel gradient reduction with 2 ranks sharing the one GPU of the test box (gloo transport): the overlapped,
+bucketed, side-stream all-reduce must equal a plain all-reduce of the same gradients; bench.py's N=2 launch line works end to end."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, extra_env, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29741"] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_overlapped_allreduce_equals_plain(dev):
+    p = _run([os.path.join(ROOT, "tests", "dp_worker.py")], {})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.stdout.count(" ok ") == 2
+
+
+def test_bench_two_rank_launch_line(dev):
+    p = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"],
+             {"PNP_DIST_BACKEND": "gloo", "PNP_SAME_DEVICE": "1"})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["scaling"] == "weak" and r["value"] > 0
