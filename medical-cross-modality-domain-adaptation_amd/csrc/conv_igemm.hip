@@ -48,6 +48,7 @@ struct ConvArgs {
     int do_drop;
     int xcd_swizzle;
     unsigned x_bytes, w_bytes;   // sizes of the tensors behind a.x / a.w (buffer descriptors)
+    int stagger;                 // s_sleep units (64 clk) by which every second dispatch wave of workgroups starts late
 };
 
 // virtual coordinate -> real coordinate; returns false when the tap reads zero.  Branch-free on purpose (selects only):
@@ -365,11 +366,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
 
     if constexpr (KIND != 2) a.ups = 1;
+    // Two workgroups share a CU (one wave each per SIMD).  Their stage loops run at the same rate, so whatever phase offset they
+    // start with persists; dispatched together they stay aligned and the matrix pipe idles whenever both are in the non-MFMA part of
+    // a stage (barrier, first fragment reads, LDS stores).  Starting every second dispatch wave late by about that part's length
+    // de-phases them for the whole kernel.  (Speed only: nothing depends on which workgroups share a CU.)
+    if (a.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    int bid = blockIdx.x;
     const int nblk = a.nblk_m * a.nblk_n;
+    const int z = blockIdx.x / nblk;               // reduction split (data gradients only; a.nsplit == 1 otherwise)
+    int bid = blockIdx.x - z * nblk;
     if (a.xcd_swizzle) bid = xcd_remap(bid, nblk);
     const int mt = bid / a.nblk_n, nt = bid - mt * a.nblk_n;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -385,9 +394,27 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
-    const int nchunks = (a.Kred + BK - 1) / BK;
-    la.load(a, rx, 0);
-    lb.load(rw, 0, a.Kred, a.K, n0);
+    const int nchunks_total = (a.Kred + BK - 1) / BK;
+    const int c_begin = z * a.chunks_per_split;
+    const int c_end = (c_begin + a.chunks_per_split < nchunks_total) ? c_begin + a.chunks_per_split : nchunks_total;
+    const int nchunks = c_end - c_begin;
+    // Reduction order.  MODE 0 (C % 32 == 0): channel-group major, filter tap minor — the R*S stages that re-read the same input
+    // pixels (shifted by one tap) run back to back, so the re-reads hit the XCD's L2.  The sum is order-independent up to fp32
+    // rounding; the filter rows are visited in the matching order.  Stage index past c_end: every offset out of range -> zeros.
+    auto stage_k0 = [&](int ci) {
+        int k0 = ci * BK;
+        if constexpr (MODE == 0) {
+            const int rs_n = a.R * a.S;
+            const int cc = ci / rs_n;
+            k0 = (ci - cc * rs_n) * a.C + cc * BK;
+        }
+        return (ci < c_end) ? k0 : a.Kred;
+    };
+    {
+        const int k0 = stage_k0(c_begin);
+        la.load(a, rx, k0);
+        lb.load(rw, k0, a.Kred, a.K, n0);
+    }
     la.store(lds);
     lb.store(lds + 2 * ASZ);
     __syncthreads();
@@ -405,16 +432,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
         const float* Bs = lds + 2 * ASZ + cur * BSZ;
         float* An = lds + (cur ^ 1) * ASZ;
         float* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
-        // Reduction order.  MODE 0 (C % 32 == 0): channel-group major, filter tap minor — the R*S stages that re-read the
-        // same input pixels (shifted by one tap) run back to back, so the re-reads hit the XCD's L2.  The sum is
-        // order-independent up to fp32 rounding; the filter rows are visited in the matching order.
-        int k0 = (c + 1) * BK;
-        if constexpr (MODE == 0) {
-            const int rs_n = a.R * a.S;
-            const int cc = (c + 1) / rs_n;
-            k0 = ((c + 1) - cc * rs_n) * a.C + cc * BK;
-        }
-        k0 = (c + 1 < nchunks) ? k0 : a.Kred;        // past the end: every offset out of range -> zeros
+        const int k0 = stage_k0(c_begin + c + 1);
         // ---- slice 0
         f1.load(As, Bs, 1, wm0, wn0, lane);
         if constexpr (!(kAblate & 1)) {
@@ -443,13 +461,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
         PNP_SCHED_FENCE();
         if constexpr (!(kAblate & 2)) f0.mma(acc);
         PNP_SCHED_FENCE();
-        // ---- slice 3
+        // ---- slice 3: MFMAs first, THEN the LDS stores of the next stage.  The stores need the global loads issued under slice 0;
+        // measured load-to-use latency under this traffic is ~3000 cycles (ablation: load->LDS->barrier chain alone 2.3 us per
+        // stage), so waiting for them before the slice-3 MFMAs (2100 cycles after issue) stalled the matrix pipe ~20 %.
+        if constexpr (!(kAblate & 2)) f1.mma(acc);
+        PNP_SCHED_FENCE();
         if constexpr (!(kAblate & 4)) {
             la.store(An);
             lb.store(Bn);
         }
-        PNP_SCHED_FENCE();
-        if constexpr (!(kAblate & 2)) f1.mma(acc);
         PNP_SCHED_FENCE();
         if constexpr (!(kAblate & 8)) __syncthreads();
         f0.load(An, Bn, 0, wm0, wn0, lane);
@@ -457,6 +477,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int l31 = lane & 31, h = lane >> 5;
+    float* __restrict__ yout = a.y + (size_t)z * a.split_stride;     // split partials (z > 0 only for data gradients)
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -469,7 +490,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
                     float v = acc.v[tm][tn][r];
                     const size_t idx = (size_t)m * a.K + n;
                     if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-                    a.y[idx] = v;
+                    yout[idx] = v;
                 }
             }
         }
@@ -529,8 +550,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
             f1.load(As, Bs, 1, wm0, wn0, lane);
             la.load(a, rx, p0, pend);
             lb.load(rw, p0, pend, a.K, n0);
-            PNP_SCHED_FENCE();
             f0.mma(acc);
+            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);      // slice-1 fragment reads first
+#pragma unroll
+            for (int i = 0; i < 4 * TM * TN; ++i) {                     // then address arithmetic + loads under the MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
             PNP_SCHED_FENCE();
             f0.load(As, Bs, 2, wm0, wn0, lane);
             PNP_SCHED_FENCE();
@@ -540,10 +567,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
             PNP_SCHED_FENCE();
             f0.mma(acc);
             PNP_SCHED_FENCE();
-            la.store(An);
-            lb.store(Bn);
-            PNP_SCHED_FENCE();
             f1.mma(acc);
+            PNP_SCHED_FENCE();
+            la.store(An);      // after the last MFMAs: gives the global loads a whole stage of latency cover (see conv_fwd_kernel)
+            lb.store(Bn);
             PNP_SCHED_FENCE();
             __syncthreads();
             f0.load(An, Bn, 0, wm0, wn0, lane);
@@ -685,39 +712,79 @@ ConvArgs make_args(const float* x, const float* w, float* y, const pnp_conv_geom
     a.xcd_swizzle = env_noswz ? 0 : 1;
     a.x_bytes = (unsigned)((size_t)g->N * g->H * g->W * g->C * sizeof(float));
     a.w_bytes = (unsigned)((size_t)g->R * g->S * g->C * g->K * sizeof(float));
+    static const int env_stagger = getenv("PNP_CONV_STAGGER") ? atoi(getenv("PNP_CONV_STAGGER")) : 0;
+    a.stagger = env_stagger;
     return a;
 }
 
+// ---- tile and reduction-split planning for the forward / data-gradient kernel -----------------------------------------------
+// Tile: the widest tile that still yields >= 384 workgroups (1.5 per CU; 2 fit), else the next narrower one.  Measured at B=16
+// (tools/bench_conv.py, PNP_CONV_TILE sweep): 128->128@32^2 44 TF/s with 128x128 tiles (128 workgroups) vs 70 with 128x64;
+// 256->512@32^2 107 vs 100; 128->64 (dgrad) 34 with 128x64 vs 46 with 128x32.
+int choose_tile(long long M, int K) {
+    static const int force = getenv("PNP_CONV_TILE") ? atoi(getenv("PNP_CONV_TILE")) : -1;   // experiments: 0/1/2 = 128x{128,64,32}
+    if ((K & 3) != 0) return 3;      // scalar-B variant of the narrow tile (K = 5 logits, K = 1 critic FC, ...)
+    const long long mt = pnp_cdiv(M, 128);
+    int tile = 2;
+    if (K > 64 && mt * pnp_cdiv(K, 128) >= 384) tile = 0;
+    else if (K > 32 && (mt * pnp_cdiv(K, 64) >= 384 || K > 64)) tile = 1;
+    if (force >= 0 && !(force == 0 && K <= 64) && !(force <= 1 && K <= 32)) tile = force;
+    return tile;
+}
+// Split of the reduction (data gradients only — they have a workspace for the partials): 512 workgroup slots per dispatch round
+// (2 per CU).  Fewer workgroups than slots, or a nearly empty last round (g10's dgrad: 580 workgroups = 1.13 rounds, i.e. the time of
+// 2), waste the chip; shorter, more numerous workgroups fill it.  Partials are summed by splitk_reduce_kernel (deterministic).
+int choose_split(long long M, int K, int Kred, int tile) {
+    static const int off = getenv("PNP_CONV_NOSPLIT") ? 1 : 0;
+    if (off) return 1;
+    const int bn = tile == 0 ? 128 : (tile == 1 ? 64 : 32);
+    const long long nblk = (long long)pnp_cdiv(M, 128) * pnp_cdiv(K, bn);
+    const int nch = pnp_cdiv(Kred, BK);
+    const double rounds = (double)nblk / 512.0;
+    int nsplit = 1;
+    if (rounds <= 0.5) nsplit = (int)(512 / nblk);
+    else if (rounds < 3.0 && (ceil(rounds) - rounds) > 0.3) nsplit = 2;
+    if (nsplit > 4) nsplit = 4;
+    if (nsplit > nch / 8) nsplit = nch / 8;
+    return nsplit < 1 ? 1 : nsplit;
+}
+
 template <int BM, int BN, int WM, int WN, int KIND, bool VECB>
-int launch_fwd_tile(ConvArgs& a, hipStream_t st) {
+int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
     a.nblk_m = pnp_cdiv(a.M, BM);
     a.nblk_n = pnp_cdiv(a.K, BN);
-    dim3 grid((unsigned)(a.nblk_m * a.nblk_n));
+    const int nch = pnp_cdiv(a.Kred, BK);
+    if (!split_ws) nsplit = 1;
+    a.chunks_per_split = pnp_cdiv(nch, nsplit);
+    nsplit = pnp_cdiv(nch, a.chunks_per_split);
+    a.nsplit = nsplit;
+    a.split_stride = (long long)a.M * a.K;
+    float* final_out = a.y;
+    if (nsplit > 1) a.y = split_ws;
+    dim3 grid((unsigned)(a.nblk_m * a.nblk_n * nsplit));
     const int mode = (a.C % 32 == 0) ? 0 : ((a.C % 4 == 0) ? 1 : 2);
     if (mode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
     else if (mode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 1, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
     else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 2, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
     PNP_CHECK_LAUNCH("conv_fwd_kernel");
+    if (nsplit > 1) {
+        const size_t nout = (size_t)a.M * a.K;
+        int nb = pnp_cdiv((long long)nout, 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, final_out, nout, nsplit, nout);
+        PNP_CHECK_LAUNCH("splitk_reduce_kernel");
+    }
     return PNP_OK;
 }
 
-// Tile choice: the widest tile that still yields >= 384 workgroups (1.5 per CU; 2 fit), else the narrowest.  The 32^2
-// layers with 128/256 filters only produce 128/256 tiles of 128x128 — half of the chip idle — but 256/512 of 128x64.
 template <int KIND>
-int launch_fwd(ConvArgs& a, hipStream_t st) {
-    // filter counts that are not a multiple of 4 (K = 5 logits, K = 1 critic FC, ...) take the scalar-B variant of the narrow tile
-    if ((a.K & 3) != 0) return launch_fwd_tile<128, 32, 4, 1, KIND, false>(a, st);
-    static const int force = getenv("PNP_CONV_TILE") ? atoi(getenv("PNP_CONV_TILE")) : -1;   // experiments: 0/1/2 = 128x{128,64,32}
-    const long long mt = pnp_cdiv(a.M, 128);
-    // measured at B=16 (tools/bench_conv.py, PNP_CONV_TILE sweep): 128->128@32^2 44 TF/s with 128x128 tiles (128 workgroups) vs
-    // 70 with 128x64; 256->512@32^2 107 vs 100; 128->64 (dgrad) 34 with 128x64 vs 46 with 128x32.
-    int tile = 2;
-    if (a.K > 64 && mt * pnp_cdiv(a.K, 128) >= 384) tile = 0;
-    else if (a.K > 32 && (mt * pnp_cdiv(a.K, 64) >= 384 || a.K > 64)) tile = 1;
-    if (force >= 0 && !(force == 0 && a.K <= 64) && !(force <= 1 && a.K <= 32)) tile = force;
-    if (tile == 0) return launch_fwd_tile<128, 128, 2, 2, KIND, true>(a, st);
-    if (tile == 1) return launch_fwd_tile<128, 64, 2, 2, KIND, true>(a, st);
-    return launch_fwd_tile<128, 32, 4, 1, KIND, true>(a, st);
+int launch_fwd(ConvArgs& a, hipStream_t st, float* split_ws = nullptr) {
+    const int tile = choose_tile(a.M, a.K);
+    const int nsplit = split_ws ? choose_split(a.M, a.K, a.Kred, tile) : 1;
+    if (tile == 3) return launch_fwd_tile<128, 32, 4, 1, KIND, false>(a, split_ws, nsplit, st);
+    if (tile == 0) return launch_fwd_tile<128, 128, 2, 2, KIND, true>(a, split_ws, nsplit, st);
+    if (tile == 1) return launch_fwd_tile<128, 64, 2, 2, KIND, true>(a, split_ws, nsplit, st);
+    return launch_fwd_tile<128, 32, 4, 1, KIND, true>(a, split_ws, nsplit, st);
 }
 
 template <int BM, int BN, int WM, int WN, bool VECB>
@@ -801,8 +868,15 @@ size_t pnp_conv2d_dgrad_workspace_bytes(const pnp_conv_geom* g) {
     if (!g) return 0;
     size_t b = (size_t)g->R * g->S * g->C * g->K * sizeof(float);
     b = (b + 255) & ~(size_t)255;
-    if (g->pad_mode == PNP_PAD_SYMMETRIC)
-        b += (size_t)g->N * (g->H + 2 * g->pad_t) * (g->W + 2 * g->pad_l) * g->C * sizeof(float);
+    size_t outb = (size_t)g->N * g->H * g->W * g->C * sizeof(float);
+    if (g->pad_mode == PNP_PAD_SYMMETRIC) {
+        outb = (size_t)g->N * (g->H + 2 * g->pad_t) * (g->W + 2 * g->pad_l) * g->C * sizeof(float);
+        b += (outb + 255) & ~(size_t)255;
+    }
+    // reduction-split partials of the data-gradient GEMM (M = output pixels of the dgrad, N = C, reduction R*S*K)
+    const long long Md = (long long)(outb / sizeof(float)) / g->C;
+    const int ns = choose_split(Md, g->C, g->R * g->S * g->K, choose_tile(Md, g->C));
+    if (ns > 1) b += (size_t)ns * outb;
     return b;
 }
 
@@ -833,7 +907,10 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
     float* out = sym ? (float*)((char*)workspace + woff) : dx;
     ConvArgs a = make_args(dy, wt, out, &d);
     a.ups = g->stride;
-    if (int e = (g->stride > 1 ? launch_fwd<2>(a, st) : launch_fwd<1>(a, st))) return e;
+    size_t poff = woff;
+    if (sym) poff += ((size_t)d.N * d.OH * d.OW * d.K * sizeof(float) + 255) & ~(size_t)255;
+    float* split_ws = (workspace_bytes > poff) ? (float*)((char*)workspace + poff) : nullptr;
+    if (int e = (g->stride > 1 ? launch_fwd<2>(a, st, split_ws) : launch_fwd<1>(a, st, split_ws))) return e;
     if (sym) {
         const size_t total = (size_t)g->N * g->H * g->W * g->C;
         hipLaunchKernelGGL(sympad_bwd_kernel, dim3((unsigned)pnp_cdiv((long long)total, 256)), dim3(256), 0, st,
