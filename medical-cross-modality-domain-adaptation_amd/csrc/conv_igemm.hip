@@ -787,17 +787,33 @@ int launch_fwd(ConvArgs& a, hipStream_t st, float* split_ws = nullptr) {
     return launch_fwd_tile<128, 32, 4, 1, KIND, true>(a, split_ws, nsplit, st);
 }
 
+// wgrad reduction split: enough workgroups for >= 1 dispatch round (512 slots), as few nearly-empty last rounds as possible
+// (512->512: 144 tiles x 8 splits = 2.25 rounds costs 3; x 7 = 1.97 rounds costs 2), few splits preferred (partials are re-read).
+int wgrad_plan_split(int nblk, int nchunks) {
+    int max_split = nchunks / 8;
+    if (max_split < 1) max_split = 1;
+    const int ns_lo = pnp_cdiv(512, nblk);                      // splits needed to fill one dispatch round
+    if (ns_lo >= max_split) return max_split;
+    int ns_hi = ns_lo * 3 + 2;                                  // look up to ~3 rounds
+    if (ns_hi > max_split) ns_hi = max_split;
+    int best = ns_lo;
+    double best_score = -1.0;
+    for (int ns = ns_lo; ns <= ns_hi; ++ns) {
+        const double rounds = (double)nblk * ns / 512.0;
+        const double eff = rounds / ceil(rounds);               // fill of the dispatch rounds
+        const double score = eff - 0.02 * rounds;               // mild preference for fewer, longer workgroups
+        if (score > best_score) { best_score = score; best = ns; }
+    }
+    return best;
+}
+
 template <int BM, int BN, int WM, int WN, bool VECB>
 int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStream_t st) {
     a.nblk_m = pnp_cdiv(a.Kred, BM);
     a.nblk_n = pnp_cdiv(a.K, BN);
     const int nblk = a.nblk_m * a.nblk_n;
     const int nchunks = pnp_cdiv(a.M, BK);
-    int nsplit = pnp_cdiv(1024, nblk);
-    int max_split = nchunks / 8;
-    if (max_split < 1) max_split = 1;
-    if (nsplit > max_split) nsplit = max_split;
-    if (nsplit < 1) nsplit = 1;
+    int nsplit = wgrad_plan_split(nblk, nchunks);
     const size_t nout = (size_t)a.Kred * a.K;
     if (nsplit > 1 && ws_bytes < nsplit * nout * sizeof(float)) {
         nsplit = (int)(ws_bytes / (nout * sizeof(float)));
@@ -822,16 +838,12 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
 }
 
 size_t wgrad_ws(const pnp_conv_geom* g) {
-    // worst case: up to 1024/nblk splits, bounded by 64 MiB of partials beyond one copy
     const size_t nout = (size_t)g->R * g->S * g->C * g->K;
     const long long P = (long long)g->N * g->OH * g->OW;
-    int nblk = pnp_cdiv((long long)g->R * g->S * g->C, 128) * pnp_cdiv(g->K, g->K > 64 ? 128 : (g->K > 32 ? 64 : 32));
-    int nsplit = pnp_cdiv(1024, nblk);
-    int max_split = (int)(pnp_cdiv(P, BK) / 8);
-    if (max_split < 1) max_split = 1;
-    if (nsplit > max_split) nsplit = max_split;
-    if (nsplit <= 1) return 0;
-    return (size_t)nsplit * nout * sizeof(float);
+    const int bn = ((g->K & 3) != 0 || g->K <= 32) ? 32 : (g->K > 64 ? 128 : 64);
+    const int nblk = pnp_cdiv((long long)g->R * g->S * g->C, 128) * pnp_cdiv(g->K, bn);
+    const int nsplit = wgrad_plan_split(nblk, pnp_cdiv(P, BK));
+    return nsplit <= 1 ? 0 : (size_t)nsplit * nout * sizeof(float);
 }
 
 }  // namespace
