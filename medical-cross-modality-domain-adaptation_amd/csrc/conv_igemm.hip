@@ -496,6 +496,171 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
         }
 }
 
+// ============ forward / stride-1 data gradient, zero padding, C % 32 == 0, square RSxRS filter: taps unrolled ============
+// The common case on the reference path (every 3x3 SAME conv from group_2 on, and their dgrads).  With the filter taps unrolled at
+// compile time the per-stage address work collapses:
+//   A:  voffset = pixel_base(row) + tap_shift   (1 v_add + 1 v_cndmask per row; validity = one bit per (row, tap), set up once)
+//       soffset = channel-group * 128 bytes      (scalar)
+//   B:  voffset = constant per thread, soffset = (tap*C + channel-group*32) * K * 4   (scalar)
+// i.e. ~16 VALU per stage instead of ~130 (the general kernel re-derives tap, mirror/zero test and pixel offset per row per stage).
+constexpr unsigned OOB2 = 0x80000000u;     // host guarantees both tensors are < 2 GiB on this path
+
+__device__ __forceinline__ f32x4 bload4s(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+template <int BM, int BN, int WM, int WN, int KIND, int RS>
+__global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
+    constexpr int S = RS, NTAP = RS * RS;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int LDA = BK + 4, LDB = BN + 4;
+    constexpr int ASZ = BM * LDA, BSZ = BK * LDB;
+    constexpr int NR = BM / 32;
+    constexpr int C4 = BN / 4, RPB = NTHREADS / C4, NPB = BK / RPB;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nblk = a.nblk_m * a.nblk_n;
+    const int z = blockIdx.x / nblk;
+    int bid = blockIdx.x - z * nblk;
+    if (a.xcd_swizzle) bid = xcd_remap(bid, nblk);
+    const int mt = bid / a.nblk_n, nt = bid - mt * a.nblk_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+    // ---- per-thread A rows: byte offset of (pixel shifted by -pad) and the validity bit of every tap -------------------
+    const int kg = t & 7, mrow = t >> 3;
+    int abase[NR];
+    unsigned amask[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        int m = m0 + mrow + 32 * i;
+        const bool ok = m < a.M;
+        if (!ok) m = 0;
+        const int n = m / a.OHW;
+        const int rem = m - n * a.OHW;
+        const int oh = rem / a.OW;
+        const int ow = rem - oh * a.OW;
+        const int vh0 = oh - a.pad_t, vw0 = ow - a.pad_l;
+        abase[i] = (((n * a.H + vh0) * a.W + vw0) * a.C + 4 * kg) * 4;
+        unsigned mk = 0;
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int ih = vh0 + (tap / S) * a.dil, iw = vw0 + (tap % S) * a.dil;
+            const bool v = ok & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            mk |= (v ? 1u : 0u) << tap;
+        }
+        amask[i] = mk;
+    }
+    // ---- per-thread B rows ------------------------------------------------------------------------------------------
+    const int bcol = t % C4, brow = t / C4;
+    unsigned boff[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+        boff[i] = (n0 + 4 * bcol < a.K) ? (unsigned)(((brow + RPB * i) * a.K + n0 + 4 * bcol) * 4) : OOB2;
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
+    f32x4 areg[NR], breg[NPB];
+    auto gload = [&](int cc, int tap) {     // tap is a compile-time constant at every call site (unrolled)
+        const int tshift = (((tap / S) * a.dil * a.W + (tap % S) * a.dil) * a.C) * 4;
+        const int sa = cc * (BK * 4);
+        const int sb = ((tap * a.C + cc * BK) * a.K) * 4;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const unsigned vo = ((amask[i] >> tap) & 1u) ? (unsigned)(abase[i] + tshift) : OOB2;
+            areg[i] = bload4s(rx, vo, sa);
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) breg[i] = bload4s(rw, boff[i], sb);
+    };
+    auto lstore = [&](float* An, float* Bn) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) *reinterpret_cast<f32x4*>(An + (mrow + 32 * i) * LDA + 4 * kg) = areg[i];
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) *reinterpret_cast<f32x4*>(Bn + (brow + RPB * i) * LDB + 4 * bcol) = breg[i];
+    };
+
+    Acc<TM, TN> acc;
+    acc.zero();
+
+    // reduction range of this workgroup in channel groups (a.chunks_per_split is a multiple of NTAP on this path)
+    const int ncc_total = a.C / BK;
+    const int cc_begin = z * (a.chunks_per_split / NTAP);
+    int cc_end = cc_begin + a.chunks_per_split / NTAP;
+    if (cc_end > ncc_total) cc_end = ncc_total;
+
+    gload(cc_begin, 0);
+    lstore(lds, lds + 2 * ASZ);
+    __syncthreads();
+    Frag<TM, TN, true, LDA, LDB> f0, f1;
+    f0.load(lds, lds + 2 * ASZ, 0, wm0, wn0, lane);
+    int sc = 0;   // stage counter (LDS buffer parity)
+    for (int cc = cc_begin; cc < cc_end; ++cc) {
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int cur = sc & 1;
+            ++sc;
+            const float* As = lds + cur * ASZ;
+            const float* Bs = lds + 2 * ASZ + cur * BSZ;
+            float* An = lds + (cur ^ 1) * ASZ;
+            float* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
+            // next stage: next tap of this channel group, or tap 0 of the next group; past the end the last group is simply
+            // fetched again (valid addresses, lands in the LDS buffer nobody reads)
+            const int ntap = (tap + 1 < NTAP) ? tap + 1 : 0;
+            int ncc = (tap + 1 < NTAP) ? cc : cc + 1;
+            ncc = (ncc < cc_end) ? ncc : cc;
+            // ---- slice 0 (same 4-slice register pipeline as conv_fwd_kernel)
+            f1.load(As, Bs, 1, wm0, wn0, lane);
+            gload(ncc, ntap);
+            f0.mma(acc);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i = 0; i < 4 * TM * TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            PNP_SCHED_FENCE();
+            f0.load(As, Bs, 2, wm0, wn0, lane);
+            PNP_SCHED_FENCE();
+            f1.mma(acc);
+            PNP_SCHED_FENCE();
+            f1.load(As, Bs, 3, wm0, wn0, lane);
+            PNP_SCHED_FENCE();
+            f0.mma(acc);
+            PNP_SCHED_FENCE();
+            f1.mma(acc);
+            PNP_SCHED_FENCE();
+            lstore(An, Bn);
+            PNP_SCHED_FENCE();
+            __syncthreads();
+            f0.load(An, Bn, 0, wm0, wn0, lane);
+        }
+    }
+
+    const int l31 = lane & 31, h = lane >> 5;
+    float* __restrict__ yout = a.y + (size_t)z * a.split_stride;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn0 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < a.M && n < a.K) {
+                    float v = acc.v[tm][tn][r];
+                    const size_t idx = (size_t)m * a.K + n;
+                    if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                    yout[idx] = v;
+                }
+            }
+        }
+}
+
 // ===================================== wgrad kernel ============================================
 // a.x = x, a.w = dy ([P][K]), a.y = dW or the split workspace.  grid.x = nblk_m*nblk_n*nsplit
 template <int BM, int BN, int WM, int WN, int MODE, bool VECB>
@@ -755,15 +920,33 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
     a.nblk_n = pnp_cdiv(a.K, BN);
     const int nch = pnp_cdiv(a.Kred, BK);
     if (!split_ws) nsplit = 1;
-    a.chunks_per_split = pnp_cdiv(nch, nsplit);
-    nsplit = pnp_cdiv(nch, a.chunks_per_split);
+    // tap-unrolled fast path: 3x3, stride 1, zero padding, C % 32 == 0, K % 4 == 0, both tensors < 2 GiB
+    static const int env_notaps = getenv("PNP_CONV_NOTAPS") ? 1 : 0;
+    const bool taps = !env_notaps && VECB && KIND != 2 && a.pad_mode == PNP_PAD_ZERO && a.stride == 1 && a.R == 3 && a.S == 3 &&
+                      (a.C % 32) == 0 && a.x_bytes < 0x80000000u && a.w_bytes < 0x80000000u;
+    if (taps) {
+        const int ncc = a.C / BK;                                    // split in whole channel groups (9 stages each)
+        const int cc_per = pnp_cdiv(ncc, nsplit);
+        nsplit = pnp_cdiv(ncc, cc_per);
+        a.chunks_per_split = cc_per * 9;
+    } else {
+        a.chunks_per_split = pnp_cdiv(nch, nsplit);
+        nsplit = pnp_cdiv(nch, a.chunks_per_split);
+    }
     a.nsplit = nsplit;
     a.split_stride = (long long)a.M * a.K;
     float* final_out = a.y;
     if (nsplit > 1) a.y = split_ws;
     dim3 grid((unsigned)(a.nblk_m * a.nblk_n * nsplit));
     const int mode = (a.C % 32 == 0) ? 0 : ((a.C % 4 == 0) ? 1 : 2);
-    if (mode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    if constexpr (VECB && KIND != 2) {
+        if (taps) {
+            hipLaunchKernelGGL((conv_taps_kernel<BM, BN, WM, WN, KIND, 3>), grid, dim3(NTHREADS), 0, st, a);
+            PNP_CHECK_LAUNCH("conv_taps_kernel");
+        }
+    }
+    if (taps) {
+    } else if (mode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
     else if (mode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 1, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
     else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 2, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
     PNP_CHECK_LAUNCH("conv_fwd_kernel");
