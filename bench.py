@@ -68,8 +68,10 @@ class ConvFwdProbe(object):
             e1.record()
             flops = 2.0 * g.N * g.OH * g.OW * g.R * g.S * g.C * g.K
             nbytes = 4.0 * (g.N * g.H * g.W * g.C + g.N * g.OH * g.OW * g.K + g.R * g.S * g.C * g.K)
-            # launches served by the 128x128-tile kernel symbol conv_fwd_kernel<128,128,2,2,0,0,true> (csrc/conv_igemm.hip::launch_fwd)
-            big = (g.K > 64) and (g.K % 4 == 0) and (g.C % 32 == 0) and (-(-g.N * g.OH * g.OW // 128) * -(-g.K // 128) >= 384)
+            # launches served by the kernel symbol conv_taps_kernel<128,128,2,2,0,3> (csrc/conv_igemm.hip::launch_fwd_tile):
+            # 3x3, stride 1, zero/VALID padding, C % 32 == 0, K % 4 == 0, >= 384 tiles of 128x128
+            big = (g.R == 3 and g.S == 3 and g.stride == 1 and g.pad_mode == 0 and g.K > 64 and g.K % 4 == 0 and g.C % 32 == 0
+                   and (-(-g.N * g.OH * g.OW // 128) * -(-g.K // 128) >= 384))
             probe.records.append((flops, nbytes, big, e0, e1))
             return y
         self.K.conv2d_fwd = wrapped
@@ -206,7 +208,7 @@ def main():
             fl, by, ms, n = tot[True]
             if n:
                 ach = fl / (ms * 1e-3) / 1e12
-                res["roofline"] = {"bound": "mfma", "kernel": "conv_fwd_kernel<128,128,2,2,0,0,true> (forward 3x3 convs on the 128x128 MFMA tile: 256->512, 512->512 (+dilated), 512->2560)",
+                res["roofline"] = {"bound": "mfma", "kernel": "conv_taps_kernel<128,128,2,2,0,3> (forward 3x3 convs on the 128x128 fp32-MFMA tile: 256->512, 512->512 (+dilated), 512->2560)",
                                    "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                                    "traffic": None, "launches": n, "avg_launch_ms": ms / n,
                                    "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mbytes_per_launch": by / n / 1e6}

@@ -115,6 +115,10 @@ int pnp_maxpool2_bwd(const float* x, const float* dy, float* dx, int32_t N, int3
 int pnp_ps_fwd(const float* x, float* y, int32_t N, int32_t A, int32_t B, int32_t r, int32_t nc, void* stream);
 int pnp_ps_bwd(const float* dy, float* dx, int32_t N, int32_t A, int32_t B, int32_t r, int32_t nc, void* stream);
 
+/* tf.pad(x, [[0,0],[p,p],[p,p],[0,0]], 'SYMMETRIC') (layers.py:23,72,91): xp[N,H+2p,W+2p,C], mirror including the edge.
+ * The host path pre-pads SYMMETRIC convolutions with this and runs them as VALID convolutions on the tap-unrolled kernel
+ * (pnp_conv2d_* also accept PNP_PAD_SYMMETRIC directly and fold the mirror into the gather). */
+int pnp_sympad_fwd(const float* x, float* xp, int32_t N, int32_t H, int32_t W, int32_t C, int32_t p, void* stream);
 /* backward of tf.pad(x, p, 'SYMMETRIC') in H and W: dx[N,H,W,C] from dxp[N,H+2p,W+2p,C] */
 int pnp_sympad_bwd(const float* dxp, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t p, void* stream);
 

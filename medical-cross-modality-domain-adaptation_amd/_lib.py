@@ -53,6 +53,7 @@ PROTOTYPES = {
     "pnp_maxpool2_bwd": (c_int, [_F, _F, _F, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pnp_ps_fwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pnp_ps_bwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "pnp_sympad_fwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pnp_sympad_bwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pnp_seg_loss_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "pnp_seg_loss_fwd": (c_int, [_F, _F, _F, c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),

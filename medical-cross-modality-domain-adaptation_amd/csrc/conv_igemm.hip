@@ -811,6 +811,28 @@ __global__ void naive_conv_kernel(ConvArgs a) {
     a.y[idx] = acc;
 }
 
+// tf.pad(x, p, 'SYMMETRIC') in H and W (mirror including the edge): xp[N,H+2p,W+2p,C]; one float4 (or float) per thread
+__global__ void sympad_fwd_kernel(const float* __restrict__ x, float* __restrict__ xp, int N, int H, int W, int C, int p, int vec) {
+    const int CV = vec ? (C >> 2) : C;
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    const size_t total = (size_t)N * Hp * Wp * CV;
+    const size_t gs = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+        const int cv = (int)(i % CV);
+        size_t q = i / CV;
+        const int wp = (int)(q % Wp);
+        q /= Wp;
+        const int hp = (int)(q % Hp);
+        const int n = (int)(q / Hp);
+        int h = hp - p, w = wp - p;
+        h = h < 0 ? -1 - h : (h >= H ? 2 * H - 1 - h : h);
+        w = w < 0 ? -1 - w : (w >= W ? 2 * W - 1 - w : w);
+        const size_t src = (((size_t)n * H + h) * W + w) * C;
+        if (vec) *reinterpret_cast<f32x4*>(xp + i * 4) = *reinterpret_cast<const f32x4*>(x + src + 4 * cv);
+        else xp[i] = x[src + cv];
+    }
+}
+
 // sympad backward: dx[n,h,w,c] = sum of dxp over every padded position that mirrors onto (h,w)
 __global__ void sympad_bwd_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int N, int H, int W, int C,
                                   int p) {
@@ -1130,6 +1152,17 @@ int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_
     if (a.K > 64) return launch_wgrad_tile<128, 128, 2, 2, true>(a, dw, ws, workspace_bytes, st);
     if (a.K > 32) return launch_wgrad_tile<128, 64, 2, 2, true>(a, dw, ws, workspace_bytes, st);
     return launch_wgrad_tile<128, 32, 4, 1, true>(a, dw, ws, workspace_bytes, st);
+}
+
+int pnp_sympad_fwd(const float* x, float* xp, int32_t N, int32_t H, int32_t W, int32_t C, int32_t p, void* stream) {
+    PNP_REQUIRE(x && xp && N > 0 && H > 0 && W > 0 && C > 0 && p >= 0 && p <= H && p <= W, "pnp_sympad_fwd: bad argument");
+    const int vec = (C % 4 == 0) ? 1 : 0;
+    const size_t total = (size_t)N * (H + 2 * p) * (W + 2 * p) * (vec ? C / 4 : C);
+    long long nb = (long long)((total + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(sympad_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, xp, N, H, W, C, p, vec);
+    PNP_CHECK_LAUNCH("sympad_fwd_kernel");
+    return PNP_OK;
 }
 
 int pnp_sympad_bwd(const float* dxp, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t p, void* stream) {

@@ -114,6 +114,20 @@ class MaxPool2Fn(Function):
         return K.maxpool2_bwd(x, _contig(dy))
 
 
+class SymPadFn(Function):
+    """tf.pad(x, k//2, 'SYMMETRIC') (layers.py:19-24): materialised once so that the convolution behind it runs as a VALID
+    convolution on the tap-unrolled MFMA kernel (and its wgrad / dgrad on plain zero-pad geometry)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        ctx.p = p
+        return K.sympad_fwd(_contig(x), p)
+
+    @staticmethod
+    def backward(ctx, dxp):
+        return K.sympad_bwd(_contig(dxp), ctx.p), None
+
+
 class PSFn(Function):
     @staticmethod
     def forward(ctx, x, r, nc):

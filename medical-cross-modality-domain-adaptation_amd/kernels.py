@@ -198,6 +198,15 @@ def ps_bwd(dy, r, nc):
     return dx
 
 
+def sympad_fwd(x, p):
+    """tf.pad(x, p, 'SYMMETRIC') in H and W (layers.py:23,72,91)"""
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    xp = torch.empty((N, H + 2 * p, W + 2 * p, C), dtype=torch.float32, device=x.device)
+    check(lib.pnp_sympad_fwd(_p(x), _p(xp), N, H, W, C, p, _stream()), "pnp_sympad_fwd")
+    return xp
+
+
 def sympad_bwd(dxp, p):
     lib = _lib.load()
     N, Hp, Wp, C = dxp.shape

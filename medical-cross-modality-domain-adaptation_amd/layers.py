@@ -12,7 +12,7 @@ from math import floor  # noqa: F401  (the reference imports it; kept for parity
 import torch
 
 from . import kernels as K
-from .functional import BNActFn, Conv2dDropFn, ConvBNActFn, LEAK, MaxPool2Fn
+from .functional import BNActFn, Conv2dDropFn, ConvBNActFn, LEAK, MaxPool2Fn, SymPadFn
 from .variables import current_store, truncated_normal
 
 
@@ -45,7 +45,16 @@ def _meta_out(g):
     return torch.empty((g.N, g.OH, g.OW, g.K), device="meta")
 
 
+def _prepad(x, W, padding):
+    """'SYMMETRIC' = tf.pad(x, floor(k/2), 'SYMMETRIC') + VALID conv (layers.py:19-24): do exactly that — one mirror-pad kernel,
+    then a VALID convolution (the MFMA kernels also accept the mirror folded into their gather; pre-padding is faster)."""
+    if padding == 'SYMMETRIC' and not x.is_meta and W.shape[0] == W.shape[1]:
+        return SymPadFn.apply(x, int(W.shape[0]) // 2), 'VALID'
+    return x, padding
+
+
 def conv2d(x, W, keep_prob_, strides=[1, 1, 1, 1], padding='SAME'):
+    x, padding = _prepad(x, W, padding)
     g = K.conv_geom(tuple(x.shape), tuple(W.shape), _stride_of(strides), 1, padding)
     keep, seed, sid = _drop_ids(keep_prob_)
     if x.is_meta:           # symbolic build pass (graph construction): shapes and variables only
@@ -55,6 +64,7 @@ def conv2d(x, W, keep_prob_, strides=[1, 1, 1, 1], padding='SAME'):
 
 # ---- layers.py:84-93 ---------------------------------------------------------------------------------
 def dilate_conv2d(x, W, keep_prob_, rate=2, padding='SAME'):
+    x, padding = _prepad(x, W, padding)
     g = K.conv_geom(tuple(x.shape), tuple(W.shape), 1, int(rate), padding)
     keep, seed, sid = _drop_ids(keep_prob_)
     if x.is_meta:
@@ -63,6 +73,7 @@ def dilate_conv2d(x, W, keep_prob_, rate=2, padding='SAME'):
 
 
 def _conv_bn(x, W, keep_prob, padding, stride, dil, is_train, scope, bn_trainable, alpha, shortcut=None):
+    x, padding = _prepad(x, W, padding)
     g = K.conv_geom(tuple(x.shape), tuple(W.shape), stride, dil, padding)
     gamma, beta, mm, mv = _bn_vars(scope, g.K, bn_trainable)
     keep, seed, sid = _drop_ids(keep_prob)

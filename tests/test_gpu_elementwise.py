@@ -110,6 +110,7 @@ def test_sympad_bwd(dev):
     for (N, H, W, C, p) in [(2, 6, 5, 8, 1), (1, 7, 7, 4, 2), (1, 2, 2, 3, 1)]:
         x = torch.from_numpy(rng.standard_normal((N, H, W, C)).astype(np.float32)).requires_grad_(True)
         xp = T.pad_symmetric(x, p, p)
+        assert torch.equal(K.sympad_fwd(x.detach().to(dev), p).cpu(), xp.detach())      # forward: pure data movement, bit exact
         g = rng.standard_normal(tuple(xp.shape)).astype(np.float32)
         xp.backward(torch.from_numpy(g))
         dx = K.sympad_bwd(torch.from_numpy(g).to(dev), p).cpu()
