@@ -227,7 +227,12 @@ struct WgradALoader {
     int rs_u, c_u;          // MODE 1: this thread's tap and channel (fixed for the whole kernel)
     bool mok;               // MODE 1: m' in range
     int mm;                 // first m' of this thread
-    __device__ __forceinline__ void init(int t, int mm0, const ConvArgs& a) {
+    // MODE 3 (stride 1, zero padding, OW >= 32, C % 4 == 0): the reduction index p (output pixel) advances by 32 per stage, so the
+    // pixel coordinates and the input byte offset are carried incrementally — no integer division and ~12 VALU per row per stage
+    // instead of ~70 (three divisions) in the general path.
+    int l_ow[NP], l_oh[NP], l_p[NP], l_off[NP];
+    int l_dh, l_dw;         // tap displacement: r*dil - pad_t, s*dil - pad_l
+    __device__ __forceinline__ void init(int t, int mm0, const ConvArgs& a, int p_first = 0) {
         acol = t % C4;
         arow = t / C4;
         mm = mm0 + 4 * acol;
@@ -235,6 +240,40 @@ struct WgradALoader {
         int m_ = mok ? mm : 0;
         rs_u = m_ / a.C;
         c_u = m_ - rs_u * a.C;
+        if constexpr (MODE == 3) {
+            const int r = rs_u / a.S, s = rs_u - r * a.S;
+            l_dh = r * a.dil - a.pad_t;
+            l_dw = s * a.dil - a.pad_l;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int p = p_first + arow + RP * i;
+                const int n = p / a.OHW;
+                const int rem = p - n * a.OHW;
+                l_oh[i] = rem / a.OW;
+                l_ow[i] = rem - l_oh[i] * a.OW;
+                l_p[i] = p;
+                l_off[i] = (((n * a.H + l_oh[i] + l_dh) * a.W + l_ow[i] + l_dw) * a.C + c_u) * 4;
+            }
+        }
+    }
+    // MODE 3: fetch the rows at the current position, then advance every row by 32 output pixels
+    __device__ __forceinline__ void load_advance(const ConvArgs& a, __amdgpu_buffer_rsrc_t rx, int pend) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const bool ok = mok & (l_p[i] < pend) & ((unsigned)(l_oh[i] + l_dh) < (unsigned)a.H) &
+                            ((unsigned)(l_ow[i] + l_dw) < (unsigned)a.W);
+            reg[i] = bload4(rx, ok ? (unsigned)l_off[i] : OOB);
+            l_p[i] += BK;
+            l_ow[i] += BK;
+            l_off[i] += BK * a.C * 4;
+            const bool ww = l_ow[i] >= a.OW;                    // at most one wrap per step because OW >= 32
+            l_ow[i] -= ww ? a.OW : 0;
+            l_oh[i] += ww ? 1 : 0;
+            l_off[i] += ww ? (a.W - a.OW) * a.C * 4 : 0;
+            const bool hw = l_oh[i] >= a.OH;
+            l_oh[i] -= hw ? a.OH : 0;
+            l_off[i] += hw ? (a.H - a.OH) * a.W * a.C * 4 : 0;
+        }
     }
     __device__ __forceinline__ unsigned offset(const ConvArgs& a, int p, int rs, int c, bool ok) const {
         int n = p / a.OHW;
@@ -249,12 +288,16 @@ struct WgradALoader {
         return ok ? (unsigned)(((n * a.H + ih) * a.W + iw) * a.C + c) * 4u : OOB;
     }
     __device__ __forceinline__ void load(const ConvArgs& a, __amdgpu_buffer_rsrc_t rx, int p0, int pend) {
+        if constexpr (MODE == 3) {          // stages are visited in order: the carried state IS p0
+            load_advance(a, rx, pend);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int p = p0 + arow + RP * i;
             const bool pok = p < pend;
             const int pp = pok ? p : 0;
-            if constexpr (MODE <= 1) {
+            if constexpr (MODE <= 1 || MODE == 3) {
                 reg[i] = bload4(rx, offset(a, pp, rs_u, c_u, pok && mok));
             } else {
 #pragma unroll
@@ -682,7 +725,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
 
     WgradALoader<BM, MODE> la;
     BLoader<BN, VECB> lb;
-    la.init(t, mm0, a);
+    la.init(t, mm0, a, (blockIdx.x / (a.nblk_m * a.nblk_n)) * a.chunks_per_split * BK);
     lb.init(t);
 
     Acc<TM, TN> acc;
@@ -1030,7 +1073,11 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     a.split_stride = (long long)nout;
     a.y = (nsplit > 1) ? ws : dw;
     dim3 grid((unsigned)(nblk * nsplit));
-    if (a.C % 4 == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 1, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    static const int env_nolin = getenv("PNP_CONV_NOLIN") ? 1 : 0;
+    const bool lin = !env_nolin && a.stride == 1 && a.pad_mode == PNP_PAD_ZERO && (a.C % 4) == 0 && a.OW >= BK &&
+                     a.x_bytes < 0x80000000u;
+    if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 3, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    else if (a.C % 4 == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 1, VECB>), grid, dim3(NTHREADS), 0, st, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 2, VECB>), grid, dim3(NTHREADS), 0, st, a);
     PNP_CHECK_LAUNCH("conv_wgrad_kernel");
     if (nsplit > 1) {
