@@ -88,6 +88,17 @@ class ConvFwdProbe(object):
         return tot
 
 
+def pmc_traffic_bytes(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC summary (collected offline with rocprofv3 --pmc in separate
+    passes, corrected as MI355X_MICROARCH.md prescribes); None when the summary is not there."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
+    try:
+        k = json.load(open(p))["kernels"][kernel]
+        return (k["hbm_read_MB_per_launch_corrected_x2"] + k["hbm_write_MB_per_launch"]) * 1e6
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds_budget=30.0):
     """The CPU oracle (a port: TF-1.4 cannot run here) timed on this host's cores on a bounded sample of the same workload:
     ONE segmenter train step (fwd+bwd+Adam) at B=2 slices, all cores."""
@@ -210,8 +221,10 @@ def main():
                 ach = fl / (ms * 1e-3) / 1e12
                 res["roofline"] = {"bound": "mfma", "kernel": "conv_taps_kernel<128,128,2,2,0,3> (forward 3x3 convs on the 128x128 fp32-MFMA tile: 256->512, 512->512 (+dilated), 512->2560)",
                                    "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                                   "traffic": None, "launches": n, "avg_launch_ms": ms / n,
-                                   "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mbytes_per_launch": by / n / 1e6}
+                                   "traffic": pmc_traffic_bytes("conv_taps_kernel<128, 128, 2, 2, 0, 3>"), "launches": n, "avg_launch_ms": ms / n,
+                                   "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mbytes_per_launch": by / n / 1e6,
+                                   "traffic_note": "HBM-side bytes per launch of this kernel symbol from the committed rocprofv3 PMC passes "
+                                                   "(profiles/r01_pmc_counters.json: 2*FETCH_SIZE + WRITE_SIZE, separate passes); null if absent"}
             fl2, by2, ms2, n2 = tot[False]
             if n2:
                 res["roofline_small_convs"] = {"launches": n2, "avg_launch_ms": ms2 / n2, "achieved_tflops": fl2 / (ms2 * 1e-3) / 1e12,
