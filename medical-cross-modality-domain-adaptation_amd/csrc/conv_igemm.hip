@@ -182,7 +182,48 @@ struct FwdALoader {
         ok = map_coord<UPS>(vw0[i] + s * a.dil, a.W, a.ups, a.pad_mode, iw) & ok;
         return ok ? (unsigned)((pixbase[i] + ih * a.W + iw) * a.C + c) * 4u : OOB;
     }
+    // MODE 4 (C % 4 == 0, C >= 16, zero padding, no upsampling): (tap row, tap col, channel) of this thread's 4 k's are carried
+    // from stage to stage (k advances by 32: at most two channel wraps because C >= 16) instead of being re-derived by two integer
+    // divisions, and the zero-padding test is two unsigned compares — ~40 VALU per stage instead of ~150.  The C = 16 layers at
+    // 256^2 and the 40 -> 5 output convolution are VALU-bound on this arithmetic, not on the MFMAs.
+    int i_k, i_c, i_s, i_r;
+    int rowoff[NR];
+    __device__ __forceinline__ void init4(const ConvArgs& a, int k_first) {
+        i_k = k_first + 4 * kg;
+        const int rs = i_k / a.C;
+        i_c = i_k - rs * a.C;
+        i_r = rs / a.S;
+        i_s = rs - i_r * a.S;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) rowoff[i] = (pixbase[i] + vh0[i] * a.W + vw0[i]) * a.C;
+    }
+    __device__ __forceinline__ void load4(const ConvArgs& a, __amdgpu_buffer_rsrc_t rx) {
+        const bool kok = i_k < a.Kred;
+        const int dh = i_r * a.dil, dw = i_s * a.dil;
+        const int tsh = (dh * a.W + dw) * a.C + i_c;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const bool ok = kok & (((valid >> i) & 1u) != 0) & ((unsigned)(vh0[i] + dh) < (unsigned)a.H) &
+                            ((unsigned)(vw0[i] + dw) < (unsigned)a.W);
+            reg[i] = bload4(rx, ok ? (unsigned)((rowoff[i] + tsh) * 4) : OOB);
+        }
+        i_k += BK;
+        i_c += BK;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const bool c1 = i_c >= a.C;
+            i_c -= c1 ? a.C : 0;
+            i_s += c1 ? 1 : 0;
+            const bool c2 = i_s >= a.S;
+            i_s -= c2 ? a.S : 0;
+            i_r += c2 ? 1 : 0;
+        }
+    }
     __device__ __forceinline__ void load(const ConvArgs& a, __amdgpu_buffer_rsrc_t rx, int k0) {
+        if constexpr (MODE == 4) {          // stages are visited in order: the carried state IS k0
+            load4(a, rx);
+            return;
+        }
         if constexpr (MODE == 0) {
             int rs = k0 / a.C;                 // block-uniform
             int c = k0 - rs * a.C + 4 * kg;
@@ -430,6 +471,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
     FwdALoader<BM, MODE, KIND == 2> la;
     BLoader<BN, VECB> lb;
     la.init(t, m0, a);
+    if constexpr (MODE == 4) la.init4(a, z * a.chunks_per_split * BK);
     lb.init(t);
 
     Acc<TM, TN> acc;
@@ -717,15 +759,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nblk = a.nblk_m * a.nblk_n;
-    const int z = blockIdx.x / nblk;
-    int bid = blockIdx.x - z * nblk;
+    // XCD-aware order: all (tap, channel, filter) tiles of one pixel range z re-read the same x and dy rows, so they are given
+    // consecutive logical ids = one XCD's L2 (the 40->5 output conv's wgrad fetched 2 GB per launch for 190 MB of operands when its 8
+    // tiles per range were sprayed over the 8 XCDs).
+    const int lid = a.xcd_swizzle ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int z = lid / nblk;
+    int bid = lid - z * nblk;
     const int mt = bid / a.nblk_n, nt = bid - mt * a.nblk_n;
     const int mm0 = mt * BM, n0 = nt * BN;
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
     WgradALoader<BM, MODE> la;
     BLoader<BN, VECB> lb;
-    la.init(t, mm0, a, (blockIdx.x / (a.nblk_m * a.nblk_n)) * a.chunks_per_split * BK);
+    la.init(t, mm0, a, z * a.chunks_per_split * BK);
     lb.init(t);
 
     Acc<TM, TN> acc;
@@ -1012,6 +1058,8 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
     }
     if (taps) {
     } else if (mode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    else if (mode == 1 && KIND != 2 && a.pad_mode == PNP_PAD_ZERO && a.C >= 16 && !getenv("PNP_CONV_NOINCR"))
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 4, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
     else if (mode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 1, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
     else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 2, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
     PNP_CHECK_LAUNCH("conv_fwd_kernel");

@@ -54,6 +54,9 @@ def main():
             continue
         x = torch.randn((B, H, H, C), device=dev)
         w = torch.randn((R, R, C, Kc), device=dev) * 0.05
+        if padding == "SYMMETRIC":      # the model path: mirror-pad once (pnp_sympad_fwd), then a VALID convolution
+            x = K.sympad_fwd(x, R // 2)
+            padding = "VALID"
         g = K.conv_geom(tuple(x.shape), tuple(w.shape), 1, dil, padding)
         dy = torch.randn((B, g.OH, g.OW, Kc), device=dev)
         flop = 2.0 * B * g.OH * g.OW * R * R * C * Kc
