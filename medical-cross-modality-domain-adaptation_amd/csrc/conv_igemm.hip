@@ -9,15 +9,21 @@
 //   wgrad: dW[R*S*C][K]      = At[R*S*C][P=N*OH*OW] * dY[P][K]  split over P across workgroups
 //
 // Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD = the 157 TF fp32 peak).
-// Workgroup = 4 waves (256 threads); BK = 32 reduction elements per LDS stage; LDS double-buffered,
-// next stage prefetched into registers while the current one feeds the MFMAs (1 barrier / stage).
+// Workgroup = 4 waves (256 threads); BK = 32 reduction elements per LDS stage; LDS double-buffered; global loads go through
+// buffer descriptors (out-of-range offset = hardware zero: no branches for padding / ragged edges); a stage is a 4-slice register
+// pipeline (Frag): ds_reads of slice q+1, the next stage's global loads and its LDS stores all fly under MFMAs; 1 barrier / stage.
+//
+// Kernels:
+//   conv_taps_kernel   3x3, stride 1, zero/VALID padding, C % 32 == 0 (forward and data gradient): taps unrolled, scalar offsets
+//   conv_fwd_kernel    everything else (any C, 5x5, strides, in-kernel SYMMETRIC mirror, zero-upsampled dy for strided dgrads)
+//   conv_wgrad_kernel  filter gradient; reduction over pixels split across workgroups + splitk_reduce_kernel
 //
 // LDS layouts (dwords):
 //   fwd  A tile  [BM][36]     row = output pixel, 32 k's contiguous (+4 pad). A fragments are read with
 //                             ONE ds_read_b128 per 4 MFMAs: lane l takes k = 8q+4*(l>>5)+{0..3}; MFMA j of the
 //                             group then contracts k-pair {8q+j, 8q+4+j} (a k-permutation, legal because the
 //                             B fragment uses the same pairing).  Stride 36 dwords => 16-B slot = 9*row mod 16,
-//                             a bijection over each b128 lane group => conflict-free.
+//                             a bijection over each b128 lane group => conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured).
 //   B tile       [32][BN+4]   row = k, n contiguous; fragment = ds_read_b32, lanes 0-31 consecutive => conflict-free.
 //   wgrad A tile [32][BM+4]   row = pixel (reduction index), m' contiguous; ds_read_b32 like B.
 #include "pnp_common.h"
@@ -356,49 +362,6 @@ struct WgradALoader {
             *reinterpret_cast<f32x4*>(lds + (arow + RP * i) * LD + 4 * acol) = reg[i];
     }
 };
-
-// ---- MFMA stage: 32 k's of A(LDS) x B(LDS) into the wave's TM x TN accumulators ----------------
-// A_MMAJOR: A tile is [m][36] (fwd) else [k][LDA] (wgrad)
-template <int TM, int TN, bool A_MMAJOR, int LDA, int LDB>
-__device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const float* __restrict__ Bs,
-                                           int wm0, int wn0, int lane, Acc<TM, TN>& acc) {
-    const int l31 = lane & 31;
-    const int h = lane >> 5;
-    constexpr int NQ = BK / 8;
-    // Every fragment of the stage is requested up front, in consumption order (40 ds_reads in flight for the
-    // 128x128 tile, 64 VGPRs): the MFMAs then only wait on counted lgkmcnt's, so the LDS latency is paid once
-    // per stage instead of once per 4 MFMAs (which left the matrix pipe ~30 % idle).
-    f32x4 a[NQ][TM];
-    float b[NQ][4][TN];
-#pragma unroll
-    for (int kq = 0; kq < NQ; ++kq) {
-        const int kb = kq * 8 + 4 * h;
-        if constexpr (A_MMAJOR) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-                a[kq][tm] = *reinterpret_cast<const f32x4*>(As + (wm0 + tm * 32 + l31) * LDA + kb);
-        } else {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[kq][tm][j] = As[(kb + j) * LDA + wm0 + tm * 32 + l31];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) b[kq][j][tn] = Bs[(kb + j) * LDB + wn0 + tn * 32 + l31];
-    }
-    __builtin_amdgcn_sched_barrier(0);   // keep the machine scheduler from sinking the reads back next to their MFMAs
-#pragma unroll
-    for (int kq = 0; kq < NQ; ++kq)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kq][tm][j], b[kq][j][tn], acc.v[tm][tn], 0, 0, 0);
-}
 
 // ---- register-pipelined fragments: one 8-k slice (kq) of a stage ---------------------------------
 // The main loops keep two Frag sets: while the 4*TM*TN MFMAs of slice kq run, the ds_reads of slice kq+1 are in
