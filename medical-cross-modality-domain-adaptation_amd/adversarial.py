@@ -23,6 +23,7 @@ from .functional import Conv2dDropFn, CriticInputFn, WganLossFn
 from .layers import (DR_block, conv2d, conv_bn_relu2d, max_pool2d, residual_block, sharable_weight_variable, weight_variable)
 from .lib import _dice_eval, _label_decomp
 from .ops import PS
+from .parallel import barrier, rank_seed
 from .variables import VariableStore
 
 raw_size = [256, 256, 3]
@@ -440,8 +441,11 @@ class Trainer(object):
 
     def __init__(self, net, mr_train_list, mr_val_list, ct_train_list, ct_val_list, adapt_var_list=None, mr_var_list=None, old_bn_list=None,
                  new_bn_list=None, test_label_list=None, test_nii_list=None, num_cls=None, batch_size=6, opt_kwargs={}, train_config={},
-                 reducer=None):
+                 reducer=None, shard=None):
         self.net = net
+        self.shard = shard              # (rank, world_size) under data parallelism
+        self.rank = shard[0] if shard else 0
+        self.test_label_list, self.test_nii_list = test_label_list, test_nii_list
         self.batch_size = batch_size
         self.num_cls = num_cls
         self.opt_kwargs = dict(opt_kwargs)
@@ -460,7 +464,11 @@ class Trainer(object):
         from .tfrecord import SliceQueue
         if hasattr(source, "next_batch"):
             return source
-        return SliceQueue(source, self.batch_size)
+        return SliceQueue(source, self.batch_size, shard=self.shard)
+
+    def _feeder(self, source):
+        from .feeder import DeviceFeeder
+        return DeviceFeeder(self.next_batch(source), self.batch_size, self.num_cls, self.net.device)
 
     def _get_optimizer(self):
         """adversarial.py:633-656"""
@@ -516,25 +524,25 @@ class Trainer(object):
             ck = os.path.join(restored_path, "checkpoint.npz")
             if os.path.exists(ck):
                 self.net.restore(None, ck, no_gan=bool(tc.get("restore_from_baseline")), clear_rms=bool(tc.get("clear_rms")))
-        ct_feed, mr_feed = self.next_batch(self.ct_train_list), self.next_batch(self.mr_train_list)
-        ct_val, mr_val = self.next_batch(self.ct_val_list), self.next_batch(self.mr_val_list)
+        ct_feed, mr_feed = self._feeder(self.ct_train_list), self._feeder(self.mr_train_list)
+        ct_val, mr_val = self._feeder(self.ct_val_list), self._feeder(self.mr_val_list)
         dis_interval, gen_interval = tc.get('dis_interval', 1), tc.get('gen_interval', 1)
         dis_sub_iter, gen_sub_iter = tc.get('dis_sub_iter', 1), tc.get('gen_sub_iter', 1)
         dis_inc, gen_inc = tc.get('dis_sub_iter_inc', 0), tc.get('gen_sub_iter_inc', 0)
         upd = tc.get('iter_upd_interval', 999999999999)
-        seed = 1
+        seed = 1 + rank_seed(self.rank)
         for epoch in range(epochs):
             for step in range(epoch * training_iters, (epoch + 1) * training_iters):
                 start = time.time()
                 if dis_interval != 0 and (step % dis_interval == 0) and step != 0:
                     for _ in range(dis_sub_iter):
-                        ct_x, _ = self._to_dev(ct_feed.next_batch(self.batch_size)[0])
-                        mr_x, _ = self._to_dev(mr_feed.next_batch(self.batch_size)[0])
+                        ct_x = ct_feed.next()[0]
+                        mr_x = mr_feed.next()[0]
                         self.dis_step(mr_x, ct_x, dropout, seed)
                         seed += 1
                 if gen_interval != 0 and (step % gen_interval == 0) and step != 0:
                     for _ in range(gen_sub_iter):
-                        ct_x, _ = self._to_dev(ct_feed.next_batch(self.batch_size)[0])
+                        ct_x = ct_feed.next()[0]
                         self.gen_step(ct_x, dropout, seed)
                         seed += 1
                 if (step % upd == 0) and step != 0:
@@ -543,13 +551,18 @@ class Trainer(object):
                 self.step_times.append(time.time() - start)
                 logging.info("Training step %s epoch %s has been finished! Time elapsed %s seconds" % (step, epoch, time.time() - start))
                 if step % display_step == 0:
-                    ct_x, ct_y = self._to_dev(ct_val.next_batch(self.batch_size)[0])
-                    mr_x, mr_y = self._to_dev(mr_val.next_batch(self.batch_size)[0])
+                    ct_x, ct_y, _ = ct_val.next()
+                    mr_x, mr_y, _ = mr_val.next()
                     self.net.evaluate(ct_x, ct_y, mr_x, mr_y)
                 if step % tc.get("checkpoint_space", 100) == 0 and step != 0:
-                    self.net.save(os.path.join(output_path, "checkpoint.npz"))
+                    if self.rank == 0:
+                        self.net.save(os.path.join(output_path, "checkpoint.npz"))
                     f = tc.get('lr_decay_factor', 1.0)
                     self.dis_optimizer.lr *= f
                     self.gen_optimizer.lr *= f
-        self.net.save(os.path.join(output_path, "checkpoint.npz"))
+        for f in (ct_feed, mr_feed, ct_val, mr_val):
+            f.close()
+        if self.rank == 0:
+            self.net.save(os.path.join(output_path, "checkpoint.npz"))
+        barrier()
         return save_path

@@ -34,6 +34,16 @@ def init_distributed(backend=None):
     return rank, local, world
 
 
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def rank_seed(rank):
+    """offset added to the per-step dropout seed so that replicas draw decorrelated masks ("seed + r")"""
+    return (int(rank) * 0x9E3779B1) & 0x3FFFFFFF
+
+
 class GradReducer(object):
     """Bucketed, backward-overlapped gradient all-reduce over a VariableStore's flat gradient arena."""
 

@@ -21,6 +21,7 @@ from .functional import SegLossFn
 from .layers import (DR_block, conv2d, conv_bn_relu2d, max_pool2d, pixel_wise_softmax_2, residual_block, weight_variable)
 from .lib import _dice_eval, _indicator_eval, _label_decomp
 from .ops import PS
+from .parallel import barrier, rank_seed
 from .variables import VariableStore
 
 raw_size = [256, 256, 3]     # source_segmenter.py:34-36
@@ -316,8 +317,11 @@ class Trainer(object):
 
     def __init__(self, net, train_list, val_list, num_cls, batch_size, test_nii_list=None, test_label_list=None,
                  optimizer="momentum", opt_kwargs={}, num_epochs=100, checkpoint_space=500, lr_update_flag=False,
-                 reducer=None):
+                 reducer=None, shard=None):
         self.net = net
+        self.shard = shard              # (rank, world_size) under data parallelism: this rank's share of the file lists
+        self.rank = shard[0] if shard else 0
+        self.seed_offset = rank_seed(self.rank)
         self.batch_size = batch_size
         self.num_cls = num_cls
         self.checkpoint_space = checkpoint_space
@@ -339,7 +343,24 @@ class Trainer(object):
         from .tfrecord import SliceQueue
         if hasattr(source, "next_batch"):
             return source
-        return SliceQueue(source, self.batch_size, capacity=capacity, min_after_dequeue=min_after_dequeue)
+        return SliceQueue(source, self.batch_size, capacity=capacity, min_after_dequeue=min_after_dequeue, num_threads=num_threads,
+                          shard=self.shard)
+
+    def _feeder(self, source):
+        """dequeue -> pinned staging -> async H2D -> on-device one-hot, one batch ahead of the step (feeder.DeviceFeeder)"""
+        from .feeder import DeviceFeeder
+        return DeviceFeeder(self.next_batch(source), self.batch_size, self.num_cls, self.net.device)
+
+    def _log_step(self, pending):
+        """the reference fetches `cost` with every sess.run; here the host reads step k's loss after step k+1 has been queued,
+        so the read never drains the GPU"""
+        step, epoch, loss, start = pending
+        lv = float(loss)
+        now = time.time()
+        self.step_times.append(now - max(start, self._last_done))
+        self._last_done = now
+        logging.info("Training at step %s epoch %s , loss is %0.4f" % (str(step), str(epoch), lv))
+        logging.info("Time elapsed %s seconds" % (str(self.step_times[-1])))
 
     def _get_optimizer(self, training_iters):
         """source_segmenter.py:357-381"""
@@ -359,7 +380,7 @@ class Trainer(object):
     def train_step(self, batch_x, batch_y, dropout, step):
         """the accelerated unit: sess.run((optimizer, cost, lr), feed_dict) of source_segmenter.py:484-489"""
         net = self.net
-        loss = net.loss_and_grads(batch_x, batch_y, dropout, main_bn=True, adapt_bn=True, drop_seed=step + 1)
+        loss = net.loss_and_grads(batch_x, batch_y, dropout, main_bn=True, adapt_bn=True, drop_seed=step + 1 + self.seed_offset)
         if self.reducer is not None:
             self.reducer.allreduce(net.store.grad_arena)
         self.opt.step()
@@ -373,9 +394,10 @@ class Trainer(object):
         if epochs == 0:
             return save_path
         output_path = os.path.abspath(output_path)
-        if not restore:
+        if not restore and self.rank == 0:
             shutil.rmtree(output_path, ignore_errors=True)
         os.makedirs(output_path, exist_ok=True)
+        barrier()
         if self.opt is None:
             self.opt = self._get_optimizer(training_iters)
         if restore:
@@ -388,34 +410,41 @@ class Trainer(object):
                 print("Unable to restore, start from beginning")
             if self.lr_update_flag is True:
                 self.opt.lr = self._new_LR
-        feed_all = self.next_batch(self.train_list)
-        feed_val = self.next_batch(self.val_list)
-        dev = self.net.device
-        for epoch in range(epochs):
-            for step in range((epoch * training_iters), ((epoch + 1) * training_iters)):
-                start = time.time()
-                batch, fid = feed_all.next_batch(self.batch_size)
-                batch_x = torch.from_numpy(np.ascontiguousarray(batch[:, :, :, 0:3])).to(dev)
-                raw_y = batch[:, :, :, 3]
-                batch_y = torch.from_numpy(_label_decomp(self.num_cls, raw_y)).to(dev)
-                loss = self.train_step(batch_x, batch_y, dropout, step)
-                if verbose:
-                    lv = float(loss)   # host sync, like the reference's fetch of `cost`
-                    self.step_times.append(time.time() - start)
-                    logging.info("Training at step %s epoch %s , loss is %0.4f" % (str(step), str(epoch), lv))
-                    logging.info("Time elapsed %s seconds" % (str(time.time() - start)))
-                if step % display_step == 0:
-                    self.output_minibatch_stats(step, batch_x, batch_y)
-                    vb, _ = feed_val.next_batch(self.batch_size)
-                    val_x = torch.from_numpy(np.ascontiguousarray(vb[:, :, :, 0:3])).to(dev)
-                    val_y = torch.from_numpy(_label_decomp(self.num_cls, vb[:, :, :, 3])).to(dev)
-                    self.val_stats(step, val_x, val_y, True)
-                if step % self.checkpoint_space == 0 and step > 10000:
-                    self.net.save(os.path.join(output_path, "checkpoint.npz"))
-                    self.opt.lr = self.opt.lr * 0.9
-            logging.info("Global step %s" % str(self.global_step))
+        feed_all = self._feeder(self.train_list)
+        feed_val = self._feeder(self.val_list)
+        self._last_done = 0.0
+        pending = None
+        try:
+            for epoch in range(epochs):
+                for step in range((epoch * training_iters), ((epoch + 1) * training_iters)):
+                    start = time.time()
+                    batch_x, batch_y, fid = feed_all.next()
+                    loss = self.train_step(batch_x, batch_y, dropout, step)
+                    if pending is not None:
+                        self._log_step(pending)
+                    pending = (step, epoch, loss, start) if verbose else None
+                    if step % display_step == 0:
+                        if pending is not None:
+                            self._log_step(pending)
+                            pending = None
+                        self.output_minibatch_stats(step, batch_x, batch_y)
+                        val_x, val_y, _ = feed_val.next()
+                        self.val_stats(step, val_x, val_y, True)
+                    if step % self.checkpoint_space == 0 and step > 10000:
+                        if self.rank == 0:
+                            self.net.save(os.path.join(output_path, "checkpoint.npz"))
+                        self.opt.lr = self.opt.lr * 0.9
+                if pending is not None:
+                    self._log_step(pending)
+                    pending = None
+                logging.info("Global step %s" % str(self.global_step))
+        finally:
+            feed_all.close()
+            feed_val.close()
         logging.info("Optimization Finished!")
-        self.net.save(os.path.join(output_path, "checkpoint.npz"))
+        if self.rank == 0:      # replicas hold identical weights; BN moving statistics are rank 0's (per-replica statistics)
+            self.net.save(os.path.join(output_path, "checkpoint.npz"))
+        barrier()
         return save_path
 
     def output_minibatch_stats(self, step, batch_x, batch_y):

@@ -12,7 +12,7 @@ def blob_labels(rng, n_class=5, size=256):
     lab = np.zeros((size, size), np.float32)
     for c in range(1, n_class):
         cy, cx = rng.integers(size // 6, size - size // 6, 2)
-        ry, rx = rng.integers(size // 20, size // 6, 2)
+        ry, rx = rng.integers(max(size // 20, 1), max(size // 6, 2), 2)
         lab[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1] = c
     return lab
 

@@ -187,25 +187,37 @@ def read_slice(path, raw_size=(256, 256, 3), verify=False):
 
 class SliceQueue(object):
     """string_input_producer(shuffle=True) + TFRecordReader + shuffle_batch stand-in: an endless shuffled stream of slices.
-    A background thread keeps `capacity` decoded slices ready (the reference uses 4 reader threads and capacity 120)."""
+    Background threads keep `capacity` decoded slices ready on `num_threads` reader threads (the reference: 4 threads, capacity 120)."""
 
-    def __init__(self, files, batch_size, capacity=120, min_after_dequeue=30, seed=0, raw_size=(256, 256, 3), threaded=True):
+    def __init__(self, files, batch_size, capacity=120, min_after_dequeue=30, seed=0, raw_size=(256, 256, 3), threaded=True,
+                 num_threads=4, shard=None):
         if not files:
             raise ValueError("SliceQueue: empty file list")
-        self.files, self.batch_size, self.raw_size = list(files), batch_size, raw_size
+        files = list(files)
+        if shard is not None:                    # data parallelism: rank r of W reads files r, r+W, ... (SURVEY.md §8e)
+            rank, world = shard
+            if len(files) >= world:
+                files = files[rank::world]
+            seed = seed + rank
+        self.files, self.batch_size, self.raw_size = files, batch_size, raw_size
         self.rng = np.random.default_rng(seed)
+        self._pick = np.random.default_rng(seed + 7919)     # consumer-side shuffle (the file-order rng belongs to the readers)
         self.capacity = max(capacity, batch_size)
-        self._buf, self._lock, self._cv = [], threading.Lock(), threading.Condition()
-        self._order, self._stop = [], False
-        self._thread = None
+        self._buf, self._cv = [], threading.Condition()
+        self._order, self._order_lock, self._stop = [], threading.Lock(), False
+        self._threads = []
         if threaded:
-            self._thread = threading.Thread(target=self._fill, daemon=True)
-            self._thread.start()
+            for _ in range(max(int(num_threads), 1)):
+                t = threading.Thread(target=self._fill, daemon=True)
+                t.start()
+                self._threads.append(t)
+        self._thread = self._threads[0] if self._threads else None
 
     def _next_file(self):
-        if not self._order:
-            self._order = list(self.rng.permutation(len(self.files)))
-        return self.files[self._order.pop()]
+        with self._order_lock:
+            if not self._order:
+                self._order = list(self.rng.permutation(len(self.files)))
+            return self.files[self._order.pop()]
 
     def _fill(self):
         try:
@@ -236,7 +248,7 @@ class SliceQueue(object):
                     if getattr(self, "_error", None) is not None:
                         raise IOError("SliceQueue reader thread failed: %r" % (self._error,))
                     self._cv.wait(0.05)
-                idx = sorted(self.rng.choice(len(self._buf), size=B, replace=False), reverse=True)
+                idx = sorted(self._pick.choice(len(self._buf), size=B, replace=False), reverse=True)
                 items = [self._buf.pop(i) for i in idx]
                 self._cv.notify_all()
         return np.stack([a for a, _ in items]), [f for _, f in items]

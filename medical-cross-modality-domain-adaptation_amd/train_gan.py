@@ -13,6 +13,7 @@ import numpy as np
 
 from . import adversarial as drn
 from .lib import _read_lists
+from .parallel import GradReducer, barrier, init_distributed
 
 logging.basicConfig(level=logging.INFO)
 rate = 0.3
@@ -63,13 +64,20 @@ def main(phase, argv=None):
     ck, nc, tc = configure(args.phase)
     num_cls, batch_size = 5, args.batch_size
     output_path = args.output
+    rank, local, world = init_distributed()     # >1 only under torch.distributed.run: data-parallel, --batch-size slices per rank
+    if os.environ.get("PNP_SAME_DEVICE"):       # test mode: several gloo ranks on one GPU (tests/test_gpu_dp.py)
+        local = 0
+    device = "cuda:%d" % local if (world > 1 and args.device == "cuda") else args.device
     os.makedirs(output_path, exist_ok=True)
     if args.synthetic:
         from .synthetic import write_dataset
-        mr_train = write_dataset(os.path.join(output_path, "syn_mr_train"), args.synthetic, seed=0, prefix="mr")
-        ct_train = write_dataset(os.path.join(output_path, "syn_ct_train"), args.synthetic, seed=1, prefix="ct")
-        mr_val = write_dataset(os.path.join(output_path, "syn_mr_val"), batch_size, seed=100, prefix="mr")
-        ct_val = write_dataset(os.path.join(output_path, "syn_ct_val"), batch_size, seed=101, prefix="ct")
+        sets = (("syn_mr_train", args.synthetic, 0, "mr"), ("syn_ct_train", args.synthetic, 1, "ct"),
+                ("syn_mr_val", batch_size, 100, "mr"), ("syn_ct_val", batch_size, 101, "ct"))
+        if rank == 0:
+            for folder, n, seed, prefix in sets:
+                write_dataset(os.path.join(output_path, folder), n, seed=seed, prefix=prefix)
+        barrier()
+        mr_train, ct_train, mr_val, ct_val = [_read_lists(os.path.join(output_path, folder, prefix + "_list")) for folder, _, _, prefix in sets]
     else:
         mr_train, mr_val = _read_lists("./lists/mr_train_list"), _read_lists("./lists/mr_val_list")
         ct_train, ct_val = _read_lists("./lists/ct_train_list"), _read_lists("./lists/ct_val_list")
@@ -78,7 +86,7 @@ def main(phase, argv=None):
     adapt_var_list, mr_var_list = _read_lists("./lists/half_zip_ct_vars"), _read_lists("./lists/half_zip_mri_vars")
     old_bn_list, new_bn_list = _read_lists("./lists/old_bn_list"), _read_lists("./lists/pred_bn_list")
 
-    net = drn.Full_DRN(channels=3, batch_size=batch_size, n_class=num_cls, cost_kwargs=ck, network_config=nc, device=args.device)
+    net = drn.Full_DRN(channels=3, batch_size=batch_size, n_class=num_cls, cost_kwargs=ck, network_config=nc, device=device, world_size=world)
     print("Network has been built ...")
     if tc["restore_from_baseline"] and args.baseline:
         with np.load(args.baseline) as z:
@@ -87,7 +95,7 @@ def main(phase, argv=None):
         print("initializing from baseline model!")
     trainer = drn.Trainer(net, mr_train, mr_val, ct_train, ct_val, adapt_var_list=adapt_var_list, mr_var_list=mr_var_list,
                           old_bn_list=old_bn_list, new_bn_list=new_bn_list, num_cls=num_cls, batch_size=batch_size, opt_kwargs=dict(opt_kwargs),
-                          train_config=tc)
+                          train_config=tc, reducer=GradReducer(net.store) if world > 1 else None, shard=(rank, world) if world > 1 else None)
     print("Now start training...")
     trainer.train(output_path=output_path, restored_path=output_path, restore=not tc["restore_from_baseline"],
                   training_iters=args.iters or tc["training_iters"], epochs=args.epochs or tc["epochs"])

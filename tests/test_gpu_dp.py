@@ -32,3 +32,13 @@ def test_bench_two_rank_launch_line(dev):
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["scaling"] == "weak" and r["value"] > 0
+
+
+def test_train_segmenter_two_ranks(dev, tmp_path):
+    """the entry point itself under torch.distributed.run: sharded file lists, per-rank feeders, overlapped reduction, rank-0 checkpoint"""
+    out = str(tmp_path / "seg_dp")
+    p = _run(["-m", "medical-cross-modality-domain-adaptation_amd.train_segmenter", "--synthetic", "8", "--batch-size", "2", "--iters", "3",
+              "--epochs", "1", "--output", out], {"PNP_DIST_BACKEND": "gloo", "PNP_SAME_DEVICE": "1"})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert os.path.exists(os.path.join(out, "checkpoint.npz"))
+    assert (p.stdout + p.stderr).count("Optimization Finished!") == 2

@@ -67,3 +67,58 @@ def test_train_gan_phase_configuration():
     ck, nc, tc = tg.configure("fine-tune")
     assert tc["dis_sub_iter"] == 30 and tc["lr_update"] is False
     assert tg.opt_kwargs["learning_rate"] == 3e-4 and ck["miu_dis"] == 0.002
+
+
+def test_slice_queue_shards_and_reader_threads(tmp_path):
+    """rank r of W reads its own share of the list; several reader threads feed one queue"""
+    syn, t = pkg("synthetic"), pkg("tfrecord")
+    files = syn.write_dataset(str(tmp_path / "d"), 8, seed=0, size=16)
+    seen = []
+    for r in range(2):
+        q = t.SliceQueue(files, 2, capacity=4, raw_size=(16, 16, 3), num_threads=3, shard=(r, 2))
+        s = set()
+        for _ in range(6):
+            s |= set(q.next_batch(2)[1])
+        q.close()
+        seen.append(s)
+    assert seen[0] == set(files[0::2]) and seen[1] == set(files[1::2])
+    q = t.SliceQueue(files[:1], 1, raw_size=(16, 16, 3), shard=(1, 2), threaded=False)     # fewer files than ranks: not sharded
+    assert q.files == files[:1]
+
+
+def test_device_feeder_matches_host_one_hot(tmp_path):
+    """feeder.DeviceFeeder: the staged batch equals the dequeued one and its on-device one-hot equals lib._label_decomp (lib.py:75-92)"""
+    import torch
+    F, L = pkg("feeder"), pkg("lib")
+
+    class Src(object):
+        def __init__(self):
+            self.k = 0
+            self.rng = np.random.default_rng(0)
+            self.batches = []
+
+        def next_batch(self, B):
+            b = self.rng.standard_normal((B, 8, 8, 4)).astype(np.float32)
+            b[..., 3] = self.rng.integers(0, 7, (B, 8, 8))      # labels 5, 6 >= num_cls -> all-zero rows
+            self.batches.append(b.copy())
+            self.k += 1
+            return b, ["id%d" % self.k] * B
+
+    src = Src()
+    f = F.DeviceFeeder(src, 3, 5, "cpu", depth=2)
+    for i in range(5):
+        x, y, ids = f.next()
+        ref = src.batches[i]
+        assert ids == ["id%d" % (i + 1)] * 3
+        assert torch.equal(x, torch.from_numpy(ref[..., 0:3]))
+        assert np.array_equal(y.numpy(), L._label_decomp(5, ref[..., 3]))
+    f.close()
+
+    class Bad(object):
+        def next_batch(self, B):
+            raise RuntimeError("disk on fire")
+
+    fb = F.DeviceFeeder(Bad(), 2, 5, "cpu")
+    import pytest
+    with pytest.raises(IOError):
+        fb.next()
