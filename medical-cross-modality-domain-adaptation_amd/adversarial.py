@@ -267,7 +267,7 @@ class Full_DRN(object):
         return m_cls_logits
 
     # ---- the graph of adversarial.py:82-119, executed eagerly ---------------------------------------------------------------
-    def _graph(self, mr, ct, keep_prob, mr_front_bn, joint_bn, ct_front_bn, record=False, segmenter_no_grad=False, drop_seed=0):
+    def _graph(self, mr, ct, keep_prob, mr_front_bn, joint_bn, ct_front_bn, record=False, segmenter_no_grad=False, drop_seed=0, critics=True):
         """mr / ct: [B,256,256,3] (either may be None: pruned branch).  Returns dict of critic logits and segmenter logits."""
         st = self.store
         self._lists = {"mr_front_weights": [], "ct_front_weights": [], "cls_weights": [], "m_cls_weights": [], "joint_weights": []}
@@ -285,6 +285,10 @@ class Full_DRN(object):
                     if br + "_c6" in z:
                         feats[br] = self.create_second_half(z[br + "_c6"], feature_base=self.feature_base, input_channel=3, num_cls=nc,
                                                             keep_prob=keep_prob, joint_bn=joint_bn, joint_trainable=self.joint_trainable)
+            for br in feats:
+                out[br + "_logits"] = feats[br][3]
+            if not critics:         # fetches that do not reach the critics (test_eval): TF prunes them, incl. their BN moving-average updates
+                return out
             with st.variable_scope("cls_scope"):
                 for br in ("ct", "mr"):
                     if br in feats:
@@ -370,6 +374,16 @@ class Full_DRN(object):
             self.mr_dice_eval, self.mr_dice_eval_arr = _dice_eval(self.compact_mr_valid, mr_y, self.n_class)
         return float(self.ct_dice_eval), float(self.mr_dice_eval)
 
+    def predict_ct(self, ct, ct_y):
+        """sess.run([compact_pred, confusion_matrix], {ct, ct_y, keep_prob: 1, *_bn: False}) of adversarial.py:1035-1037"""
+        from . import lib
+        with torch.no_grad():
+            o = self._graph(None, ct, 1.0, mr_front_bn=False, joint_bn=False, ct_front_bn=False, critics=False)
+            self.predicter, self.compact_pred = K.softmax_argmax(o["ct_logits"].contiguous())
+            self.compact_y = torch.argmax(ct_y, 3)
+            self.confusion_matrix = lib.confusion_matrix(self.compact_y, self.compact_pred, self.n_class)
+        return self.compact_pred, self.confusion_matrix
+
     # ---- checkpoints / phase hand-off (own .npz format keyed by the TF names; SURVEY.md §8f-3) -------------------------------------
     def save(self, path):
         np.savez(path, **{k.replace("/", "|"): v for k, v in self.store.state_dict().items()})
@@ -412,6 +426,9 @@ class Full_DRN(object):
             adapt_var_list = [k for k in st.vars if k.startswith("adapt_")]
         cur = st.state_dict()
         st.load_state_dict({strip(a): cur[strip(m)] for m, a in zip(mr_var_list, adapt_var_list)}, strict=False)
+
+
+contour_map = {"bg": 0, "la_myo": 1, "la_blood": 2, "lv_blood": 3, "aa": 4}     # adversarial.py:19-25
 
 
 class _Null(object):
@@ -566,3 +583,26 @@ class Trainer(object):
             self.net.save(os.path.join(output_path, "checkpoint.npz"))
         barrier()
         return save_path
+
+    # -- volume inference -------------------------------------------------------------------------------
+    def _predict_batch(self, vol, slice_y):
+        from .lib import label_decomp_device
+        dev = self.net.device
+        y = label_decomp_device(self.num_cls, torch.from_numpy(slice_y).to(dev))
+        pred, cm = self.net.predict_ct(torch.from_numpy(vol).to(dev), y)
+        return pred.cpu().numpy(), cm
+
+    def test_eval(self, sess=None, output_path=".", flip_correction=True):
+        """adversarial.py:993-1052: CT test volumes through adapt_* front + shared second half; writes cm.csv"""
+        from . import volume_eval as ve
+        os.makedirs(os.path.join(output_path, "dense_pred"), exist_ok=True)
+        self.test_pair_list = list(zip(self.test_label_list, self.test_nii_list))
+        sample_eval_list, all_cm = ve.test_eval(self._predict_batch, self.test_label_list, self.test_nii_list, self.net.batch_size,
+                                                self.num_cls, flip_correction, shuffle=True)
+        np.savetxt(os.path.join(output_path, "cm.csv"), all_cm)
+        return self.sample_metric_stddev(sample_eval_list)
+
+    def sample_metric_stddev(self, sample_eval_list):
+        """adversarial.py:1054-1084"""
+        from . import volume_eval as ve
+        return ve.sample_metric_stddev(sample_eval_list, self.num_cls, contour_map)

@@ -1,5 +1,7 @@
 """Drop-in for the step-path helpers of the reference's lib.py (label one-hot, Dice / Jaccard bookkeeping,
-list reading).  NIfTI I/O and TF checkpoint helpers (lib.py:23-72) are out of scope.
+list reading, NIfTI volume I/O).  The NIfTI helpers (lib.py:31-72) run on this package's own reader/writer (nifti.py) because
+nibabel is not available; the TF checkpoint helper `_save` (lib.py:23-29) is replaced by Full_DRN.save / .restore (.npz keyed by the
+TF variable names).
 """
 import os
 
@@ -21,6 +23,44 @@ def _read_lists(fid):
             continue
         out.append(item.split('\n')[0])
     return out
+
+
+def write_nii(array_data, filename, path="", affine=None):
+    """lib.py:47-62: write a numpy array into a nii file; returns the path"""
+    from . import nifti
+    if affine is None:
+        print("No information about the global coordinate system")
+        affine = np.diag([1, 1, 1, 1])
+    save_fid = os.path.join(path, filename)
+    try:
+        nifti.Nifti1Image(array_data, affine).to_filename(save_fid)
+        print("Nii object %s has been saved!" % save_fid)
+    except Exception:
+        raise Exception("file %s cannot be saved!" % save_fid)
+    return save_fid
+
+
+def read_nii_image(input_fid):
+    """lib.py:64-67: the voxel array of a nii file"""
+    from . import nifti
+    return nifti.load(input_fid).get_data()
+
+
+def read_nii_object(input_fid):
+    """lib.py:69-72: the nii object itself (get_data(), get_affine())"""
+    from . import nifti
+    return nifti.load(input_fid)
+
+
+def _save_nii_prediction(gth, comp_pred, ref_fid, out_folder, out_bname, debug=False, num_cls=5):
+    """lib.py:31-45: save prediction and ground truth as nii.gz with the reference volume's affine.  (The reference body reads
+    `self.num_cls` inside a module-level function — a NameError; num_cls is an argument here.)"""
+    ref_affine = read_nii_object(ref_fid).get_affine()
+    out_bname = out_bname.split(".")[0] + ".nii.gz"
+    write_nii(comp_pred, out_bname, out_folder, affine=ref_affine)
+    _local_gth = gth.copy()
+    _local_gth[_local_gth > num_cls - 1] = 0
+    write_nii(_local_gth, "gth_" + out_bname, out_folder, affine=ref_affine)
 
 
 def _label_decomp(num_cls, label_vol):

@@ -458,3 +458,31 @@ class Trainer(object):
         if detail:
             _indicator_eval(self.net.confusion_matrix, verbose=verbose)
         self.loss_dict["val"] = (step, float(self.net.cost), float(self.net.dice_eval))
+
+    # -- volume inference -------------------------------------------------------------------------------
+    def _predict_batch(self, vol, slice_y):
+        dev = self.net.device
+        x = torch.from_numpy(vol).to(dev)
+        y = lib.label_decomp_device(self.num_cls, torch.from_numpy(slice_y).to(dev))
+        self.net.evaluate(x, y, keep_prob=1.0, main_bn=False, adapt_bn=False, want_confusion=True)
+        return self.net.compact_pred.cpu().numpy(), self.net.confusion_matrix
+
+    def test_eval(self, sess=None, output_path=".", flip_correction=True, save_result=False):
+        """source_segmenter.py:572-632: inference on the .nii test volumes -> (per-class mean Dice, see volume_eval for the 2nd value)"""
+        from . import volume_eval as ve
+        pred_folder = os.path.join(output_path, "test_pred")
+        os.makedirs(pred_folder, exist_ok=True)
+        self.test_pair_list = list(zip(self.test_label_list, self.test_nii_list))
+
+        def on_sample(raw_y, tmp_y, nii_fid):
+            if save_result is True:
+                lib._save_nii_prediction(raw_y, tmp_y, nii_fid, pred_folder, out_bname="dense_pred_" + os.path.basename(nii_fid),
+                                         num_cls=self.num_cls)
+        sample_eval_list, _ = ve.test_eval(self._predict_batch, self.test_label_list, self.test_nii_list, self.net.batch_size, self.num_cls,
+                                           flip_correction, shuffle=False, on_sample=on_sample)
+        return self.sample_metric_stddev(sample_eval_list)
+
+    def sample_metric_stddev(self, sample_eval_list):
+        """source_segmenter.py:634-664"""
+        from . import volume_eval as ve
+        return ve.sample_metric_stddev(sample_eval_list, self.num_cls, contour_map, quiet=not verbose)
