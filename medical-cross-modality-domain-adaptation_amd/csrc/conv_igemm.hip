@@ -56,7 +56,19 @@ struct ConvArgs {
     int xcd_swizzle;
     unsigned x_bytes, w_bytes;   // sizes of the tensors behind a.x / a.w (buffer descriptors)
     int stagger;                 // s_sleep units (64 clk) by which every second dispatch wave of workgroups starts late
+    // output scatter of one stride-phase of a strided data gradient (o_s = 0: plain [M][K] rows): GEMM row (n, i, j) is the
+    // image pixel (n, o_h0 + i*o_s, o_w0 + j*o_s) of an o_H x o_W image
+    int o_s, o_H, o_W, o_h0, o_w0;
 };
+
+__device__ __forceinline__ size_t out_row(const ConvArgs& a, int m, bool scatter) {
+    if (!scatter) return (size_t)m * a.K;
+    const int n = m / a.OHW;
+    const int rem = m - n * a.OHW;
+    const int oh = rem / a.OW;
+    const int ow = rem - oh * a.OW;
+    return ((size_t)(n * a.o_H + a.o_h0 + oh * a.o_s) * a.o_W + a.o_w0 + ow * a.o_s) * a.K;
+}
 
 // virtual coordinate -> real coordinate; returns false when the tap reads zero.  Branch-free on purpose (selects only):
 // a scalar branch here would split the main-loop body into basic blocks and pin the address arithmetic in front of the MFMAs.
@@ -541,6 +553,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int l31 = lane & 31, h = lane >> 5;
     float* __restrict__ yout = a.y + (size_t)z * a.split_stride;     // split partials (z > 0 only for data gradients)
+    const bool scatter = a.o_s != 0 && a.nsplit == 1;                  // partials stay row-major; splitk_reduce scatters them
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -553,7 +566,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
                     float v = acc.v[tm][tn][r];
                     const size_t idx = (size_t)m * a.K + n;
                     if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-                    yout[idx] = v;
+                    yout[out_row(a, m, scatter) + n] = v;
                 }
             }
         }
@@ -707,6 +720,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
 
     const int l31 = lane & 31, h = lane >> 5;
     float* __restrict__ yout = a.y + (size_t)z * a.split_stride;
+    const bool scatter = a.o_s != 0 && a.nsplit == 1;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -719,7 +733,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
                     float v = acc.v[tm][tn][r];
                     const size_t idx = (size_t)m * a.K + n;
                     if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-                    yout[idx] = v;
+                    yout[out_row(a, m, scatter) + n] = v;
                 }
             }
         }
@@ -834,6 +848,40 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
         float s = 0.f;
         for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * stride + i];
         out[i] = s;
+    }
+}
+
+// split partials of one stride-phase ([nsplit][M][K] row-major) -> summed and scattered to the phase's pixels of dx
+__global__ void splitk_reduce_scatter_kernel(const float* __restrict__ part, ConvArgs a, int nsplit, size_t stride) {
+    const size_t n = (size_t)a.M * a.K;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gs = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += gs) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * stride + i];
+        const int m = (int)(i / a.K);
+        a.y[out_row(a, m, true) + (i - (size_t)m * a.K)] = s;
+    }
+}
+
+// stride-phase (pa, pb) of w [R][S][C][K] -> wt [T][U][K][C]: taps r = pa + st*t, s = pb + st*u, both axes flipped
+__global__ void flip_transpose_phase_kernel(const float* __restrict__ w, float* __restrict__ wt, int R, int S, int C, int K, int pa,
+                                            int pb, int st, int T, int U) {
+    __shared__ float tile[32][33];
+    const int tf = blockIdx.z / U, uf = blockIdx.z - tf * U;          // flipped tap of the phase filter
+    const int r = pa + st * (T - 1 - tf), sx = pb + st * (U - 1 - uf);
+    const float* src = w + (size_t)(r * S + sx) * C * K;
+    float* dst = wt + (size_t)blockIdx.z * K * C;
+    const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, k = k0 + tx;
+        tile[i][tx] = (c < C && k < K) ? src[(size_t)c * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int k = k0 + i, c = c0 + tx;
+        if (k < K && c < C) dst[(size_t)k * C + c] = tile[tx][i];
     }
 }
 
@@ -1050,7 +1098,13 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
         const size_t nout = (size_t)a.M * a.K;
         int nb = pnp_cdiv((long long)nout, 256);
         if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, final_out, nout, nsplit, nout);
+        if (a.o_s != 0) {
+            ConvArgs ar = a;
+            ar.y = final_out;
+            hipLaunchKernelGGL(splitk_reduce_scatter_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, ar, nsplit, nout);
+        } else {
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, final_out, nout, nsplit, nout);
+        }
         PNP_CHECK_LAUNCH("splitk_reduce_kernel");
     }
     return PNP_OK;
@@ -1129,6 +1183,58 @@ size_t wgrad_ws(const pnp_conv_geom* g) {
     return nsplit <= 1 ? 0 : (size_t)nsplit * nout * sizeof(float);
 }
 
+// ---- strided data gradient, one stride-phase at a time ---------------------------------------------------------------------
+// dx[h] only receives filter taps r with r = (h + pad) mod stride (mod stride), so the pixels of one residue class ("phase") form an
+// ordinary stride-1 convolution of dy with the sub-filter {r = a, a+stride, ...}:
+//     dx[h0 + stride*i] = sum_t dy[i + q - t] * W[a + stride*t],   q = (h0 + pad - a) / stride
+// i.e. T = ceil((R-a)/stride) taps, zero padding T-1-q, output scattered with pixel stride `stride`.  The stride^2 phases together
+// perform exactly the useful multiply-adds; the zero-upsampled formulation (KIND 2) multiplies stride^2 - 1 zeros for every product.
+struct DgradPhase {
+    int pa, pb, T, U, h0, w0, I, J, pad_t, pad_l;
+    size_t wt_off;      // float offset of this phase's flipped filter [T][U][K][C] in the workspace
+};
+
+// -> number of phases (0: decomposition not applicable, use the zero-upsampled kernel)
+int plan_phases(const pnp_conv_geom* g, DgradPhase* ph) {
+    static const int off = getenv("PNP_CONV_NOPHASE") ? 1 : 0;
+    const int st = g->stride;
+    if (off || st < 2 || st > 4 || g->dil != 1 || g->R < st || g->S < st) return 0;
+    const bool sym = g->pad_mode == PNP_PAD_SYMMETRIC;
+    const int Ho = sym ? g->H + 2 * g->pad_t : g->H, Wo = sym ? g->W + 2 * g->pad_l : g->W;
+    const int fpt = sym ? 0 : g->pad_t, fpl = sym ? 0 : g->pad_l;
+    int n = 0;
+    size_t off_f = 0;
+    for (int a = 0; a < st; ++a)
+        for (int b = 0; b < st; ++b) {
+            DgradPhase p{};
+            p.pa = a; p.pb = b;
+            p.T = (g->R - a + st - 1) / st;
+            p.U = (g->S - b + st - 1) / st;
+            p.h0 = (((a - fpt) % st) + st) % st;
+            p.w0 = (((b - fpl) % st) + st) % st;
+            const int qa = (p.h0 + fpt - a) / st, qb = (p.w0 + fpl - b) / st;
+            p.pad_t = p.T - 1 - qa;
+            p.pad_l = p.U - 1 - qb;
+            if (p.pad_t < 0 || p.pad_l < 0) return 0;
+            p.I = p.h0 < Ho ? (Ho - 1 - p.h0) / st + 1 : 0;
+            p.J = p.w0 < Wo ? (Wo - 1 - p.w0) / st + 1 : 0;
+            p.wt_off = off_f;
+            off_f += (size_t)p.T * p.U * g->K * g->C;
+            ph[n++] = p;
+        }
+    return n;
+}
+
+pnp_conv_geom phase_geom(const pnp_conv_geom* g, const DgradPhase& p) {
+    pnp_conv_geom d{};
+    d.N = g->N; d.H = g->OH; d.W = g->OW; d.C = g->K; d.K = g->C; d.R = p.T; d.S = p.U;
+    d.OH = p.I; d.OW = p.J;
+    d.stride = 1; d.dil = 1;
+    d.pad_t = p.pad_t; d.pad_l = p.pad_l;
+    d.pad_mode = PNP_PAD_ZERO;
+    return d;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1169,6 +1275,18 @@ size_t pnp_conv2d_dgrad_workspace_bytes(const pnp_conv_geom* g) {
         b += (outb + 255) & ~(size_t)255;
     }
     // reduction-split partials of the data-gradient GEMM (M = output pixels of the dgrad, N = C, reduction R*S*K)
+    DgradPhase ph[16];
+    const int nph = plan_phases(g, ph);
+    if (nph > 0) {                                       // one stride-phase at a time: the largest phase's partials
+        size_t mx = 0;
+        for (int i = 0; i < nph; ++i) {
+            const long long Mp = (long long)g->N * ph[i].I * ph[i].J;
+            if (Mp == 0) continue;
+            const int ns = choose_split(Mp, g->C, ph[i].T * ph[i].U * g->K, choose_tile(Mp, g->C));
+            if (ns > 1 && (size_t)ns * Mp * g->C * sizeof(float) > mx) mx = (size_t)ns * Mp * g->C * sizeof(float);
+        }
+        return b + mx;
+    }
     const long long Md = (long long)(outb / sizeof(float)) / g->C;
     const int ns = choose_split(Md, g->C, g->R * g->S * g->K, choose_tile(Md, g->C));
     if (ns > 1) b += (size_t)ns * outb;
@@ -1184,6 +1302,35 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
     hipStream_t st = (hipStream_t)stream;
     float* wt = (float*)workspace;
     size_t woff = ((size_t)g->R * g->S * g->C * g->K * sizeof(float) + 255) & ~(size_t)255;
+    DgradPhase ph[16];
+    const int nph = plan_phases(g, ph);
+    if (nph > 0) {
+        const bool symp = g->pad_mode == PNP_PAD_SYMMETRIC;
+        const int Ho = symp ? g->H + 2 * g->pad_t : g->H, Wo = symp ? g->W + 2 * g->pad_l : g->W;
+        float* outp = symp ? (float*)((char*)workspace + woff) : dx;
+        size_t poff = woff;
+        if (symp) poff += ((size_t)g->N * Ho * Wo * g->C * sizeof(float) + 255) & ~(size_t)255;
+        float* split_ws = (workspace_bytes > poff) ? (float*)((char*)workspace + poff) : nullptr;
+        for (int i = 0; i < nph; ++i) {
+            const DgradPhase& p = ph[i];
+            if (p.I == 0 || p.J == 0) continue;
+            dim3 tgp((unsigned)pnp_cdiv(g->K, 32), (unsigned)pnp_cdiv(g->C, 32), (unsigned)(p.T * p.U));
+            hipLaunchKernelGGL(flip_transpose_phase_kernel, tgp, dim3(256), 0, st, w, wt + p.wt_off, g->R, g->S, g->C, g->K, p.pa, p.pb,
+                               g->stride, p.T, p.U);
+            PNP_CHECK_LAUNCH("flip_transpose_phase_kernel");
+            const pnp_conv_geom d = phase_geom(g, p);
+            ConvArgs a = make_args(dy, wt + p.wt_off, outp, &d);
+            a.o_s = g->stride; a.o_H = Ho; a.o_W = Wo; a.o_h0 = p.h0; a.o_w0 = p.w0;
+            if (int e = launch_fwd<1>(a, st, split_ws)) return e;
+        }
+        if (symp) {
+            const size_t total = (size_t)g->N * g->H * g->W * g->C;
+            hipLaunchKernelGGL(sympad_bwd_kernel, dim3((unsigned)pnp_cdiv((long long)total, 256)), dim3(256), 0, st,
+                               (const float*)outp, dx, g->N, g->H, g->W, g->C, g->pad_t);
+            PNP_CHECK_LAUNCH("sympad_bwd_kernel");
+        }
+        return PNP_OK;
+    }
     dim3 tg((unsigned)pnp_cdiv(g->K, 32), (unsigned)pnp_cdiv(g->C, 32), (unsigned)(g->R * g->S));
     hipLaunchKernelGGL(flip_transpose_kernel, tg, dim3(256), 0, st, w, wt, g->R, g->S, g->C, g->K);
     PNP_CHECK_LAUNCH("flip_transpose_kernel");

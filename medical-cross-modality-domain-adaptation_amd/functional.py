@@ -55,7 +55,8 @@ class ConvBNActFn(Function):
             mean, var = K.bn_stats(xc)
             K.bn_update_moving(moving_mean, moving_var, mean, var, P, BN_DECAY)
         else:
-            mean, var = moving_mean.clone(), moving_var.clone()
+            # inference statistics; snapshot only if a backward pass will read them after the moving averages may have moved
+            mean, var = (moving_mean.clone(), moving_var.clone()) if any(ctx.needs_input_grad) else (moving_mean, moving_var)
         sc = _contig(shortcut) if shortcut is not None else None
         out = K.bn_apply(xc, mean, var, gamma, beta, sc, BN_EPS, alpha)
         ctx.save_for_backward(x, w_, xc, out, mean, var, gamma)
@@ -88,7 +89,8 @@ class BNActFn(Function):
             mean, var = K.bn_stats(xc)
             K.bn_update_moving(moving_mean, moving_var, mean, var, P, BN_DECAY)
         else:
-            mean, var = moving_mean.clone(), moving_var.clone()
+            # inference statistics; snapshot only if a backward pass will read them after the moving averages may have moved
+            mean, var = (moving_mean.clone(), moving_var.clone()) if any(ctx.needs_input_grad) else (moving_mean, moving_var)
         out = K.bn_apply(xc, mean, var, gamma, beta, None, BN_EPS, alpha)
         ctx.save_for_backward(xc, out, mean, var, gamma)
         ctx.is_train, ctx.alpha = is_train, alpha

@@ -28,6 +28,12 @@ LAYERS = [  # name, H, C, K, R, dil, padding, count in segmenter fwd
     ("g10 512->2560", 32, 512, 2560, 3, 1, "SYMMETRIC", 1),
     ("out 40->5 k5", 256, 40, 5, 5, 1, "SYMMETRIC", 1),
     ("cls1 64->64", 256, 64, 64, 3, 1, "SAME", 0),
+    # strided critic convolutions (adversarial.py:342-391); 9th field = stride
+    ("cls k3s2 64@256", 256, 64, 64, 3, 1, "SAME", 0, 2),
+    ("cls k5s2 128@128", 128, 128, 128, 5, 1, "SAME", 0, 2),
+    ("cls k3s2 256@64", 64, 256, 256, 3, 1, "SAME", 0, 2),
+    ("cls k3s2 512@32", 32, 512, 512, 3, 1, "SAME", 0, 2),
+    ("cls k5s4 512@16", 16, 512, 512, 5, 1, "SAME", 0, 4),
 ]
 
 
@@ -49,7 +55,8 @@ def main():
     totflop = 0.0
     print("%-18s %9s | %8s %6s | %8s %6s | %8s %6s" % ("layer", "GFLOP", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
     only = os.environ.get("ONLY")
-    for name, H, C, Kc, R, dil, padding, cnt in LAYERS:
+    for name, H, C, Kc, R, dil, padding, cnt, *rest in LAYERS:
+        stride = rest[0] if rest else 1
         if only and only not in name:
             continue
         x = torch.randn((B, H, H, C), device=dev)
@@ -57,7 +64,7 @@ def main():
         if padding == "SYMMETRIC":      # the model path: mirror-pad once (pnp_sympad_fwd), then a VALID convolution
             x = K.sympad_fwd(x, R // 2)
             padding = "VALID"
-        g = K.conv_geom(tuple(x.shape), tuple(w.shape), 1, dil, padding)
+        g = K.conv_geom(tuple(x.shape), tuple(w.shape), stride, dil, padding)
         dy = torch.randn((B, g.OH, g.OW, Kc), device=dev)
         flop = 2.0 * B * g.OH * g.OW * R * R * C * Kc
         tf = timeit(lambda: K.conv2d_fwd(x, w, g))
