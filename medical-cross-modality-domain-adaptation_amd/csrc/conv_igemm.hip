@@ -572,9 +572,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
         }
 }
 
-// ============ forward / stride-1 data gradient, zero padding, C % 32 == 0, square RSxRS filter: taps unrolled ============
-// The common case on the reference path (every 3x3 SAME conv from group_2 on, and their dgrads).  With the filter taps unrolled at
-// compile time the per-stage address work collapses:
+// ============ forward (any stride) / stride-1 data gradient, zero padding, C % 32 == 0, RxS filter: taps unrolled ============
+// The common case on the reference path (every 3x3 SAME conv from group_2 on and their dgrads, the strided 3x3 / 5x5 critic convs,
+// and the stride-phase sub-filters 1x1 ... 3x3 of their data gradients).  With the filter taps unrolled at compile time the per-stage
+// address work collapses:
 //   A:  voffset = pixel_base(row) + tap_shift   (1 v_add + 1 v_cndmask per row; validity = one bit per (row, tap), set up once)
 //       soffset = channel-group * 128 bytes      (scalar)
 //   B:  voffset = constant per thread, soffset = (tap*C + channel-group*32) * K * 4   (scalar)
@@ -585,9 +586,10 @@ __device__ __forceinline__ f32x4 bload4s(__amdgpu_buffer_rsrc_t r, unsigned voff
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <int BM, int BN, int WM, int WN, int KIND, int RS>
+template <int BM, int BN, int WM, int WN, int KIND, int R, int S>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
-    constexpr int S = RS, NTAP = RS * RS;
+    constexpr int NTAP = R * S;
+    static_assert(NTAP <= 32, "one validity bit per tap");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BK + 4, LDB = BN + 4;
     constexpr int ASZ = BM * LDA, BSZ = BK * LDB;
@@ -620,7 +622,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
         const int rem = m - n * a.OHW;
         const int oh = rem / a.OW;
         const int ow = rem - oh * a.OW;
-        const int vh0 = oh - a.pad_t, vw0 = ow - a.pad_l;
+        const int vh0 = oh * a.stride - a.pad_t, vw0 = ow * a.stride - a.pad_l;
         abase[i] = (((n * a.H + vh0) * a.W + vw0) * a.C + 4 * kg) * 4;
         unsigned mk = 0;
 #pragma unroll
@@ -1056,21 +1058,43 @@ int choose_split(long long M, int K, int Kred, int tile) {
     return nsplit < 1 ? 1 : nsplit;
 }
 
+// filter shapes the tap-unrolled kernel is instantiated for: forward 3x3 / 5x5; data gradient 3x3 and the stride-phase sub-filters
+constexpr bool taps_shape(int kind, int R, int S) {
+    if (R == 3 && S == 3) return true;
+    if (kind == 0) return R == 5 && S == 5;
+    if (kind == 1) return R >= 1 && R <= 3 && S >= 1 && S <= 3 && !(R == 3 && S == 1) && !(R == 1 && S == 3);
+    return false;
+}
+
+template <int BM, int BN, int WM, int WN, int KIND>
+bool launch_taps(const ConvArgs& a, dim3 grid, hipStream_t st) {
+#define PNP_TAPS(RR, SS)                                                                                                   \
+    if (a.R == RR && a.S == SS) {                                                                                          \
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, WM, WN, KIND, RR, SS>), grid, dim3(NTHREADS), 0, st, a);               \
+        return true;                                                                                                       \
+    }
+    PNP_TAPS(3, 3)
+    if constexpr (KIND == 0) { PNP_TAPS(5, 5) }
+    if constexpr (KIND == 1) { PNP_TAPS(1, 1) PNP_TAPS(1, 2) PNP_TAPS(2, 1) PNP_TAPS(2, 2) PNP_TAPS(2, 3) PNP_TAPS(3, 2) }
+#undef PNP_TAPS
+    return false;
+}
+
 template <int BM, int BN, int WM, int WN, int KIND, bool VECB>
 int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
     a.nblk_m = pnp_cdiv(a.M, BM);
     a.nblk_n = pnp_cdiv(a.K, BN);
     const int nch = pnp_cdiv(a.Kred, BK);
     if (!split_ws) nsplit = 1;
-    // tap-unrolled fast path: 3x3, stride 1, zero padding, C % 32 == 0, K % 4 == 0, both tensors < 2 GiB
+    // tap-unrolled fast path: instantiated filter shape, zero padding, C % 32 == 0, K % 4 == 0, both tensors < 2 GiB
     static const int env_notaps = getenv("PNP_CONV_NOTAPS") ? 1 : 0;
-    const bool taps = !env_notaps && VECB && KIND != 2 && a.pad_mode == PNP_PAD_ZERO && a.stride == 1 && a.R == 3 && a.S == 3 &&
+    const bool taps = !env_notaps && VECB && KIND != 2 && a.pad_mode == PNP_PAD_ZERO && taps_shape(KIND, a.R, a.S) &&
                       (a.C % 32) == 0 && a.x_bytes < 0x80000000u && a.w_bytes < 0x80000000u;
     if (taps) {
-        const int ncc = a.C / BK;                                    // split in whole channel groups (9 stages each)
+        const int ncc = a.C / BK;                                    // split in whole channel groups (R*S stages each)
         const int cc_per = pnp_cdiv(ncc, nsplit);
         nsplit = pnp_cdiv(ncc, cc_per);
-        a.chunks_per_split = cc_per * 9;
+        a.chunks_per_split = cc_per * a.R * a.S;
     } else {
         a.chunks_per_split = pnp_cdiv(nch, nsplit);
         nsplit = pnp_cdiv(nch, a.chunks_per_split);
@@ -1083,7 +1107,8 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
     const int mode = (a.C % 32 == 0) ? 0 : ((a.C % 4 == 0) ? 1 : 2);
     if constexpr (VECB && KIND != 2) {
         if (taps) {
-            hipLaunchKernelGGL((conv_taps_kernel<BM, BN, WM, WN, KIND, 3>), grid, dim3(NTHREADS), 0, st, a);
+            const bool launched = launch_taps<BM, BN, WM, WN, KIND>(a, grid, st);
+            PNP_REQUIRE(launched, "conv_taps_kernel: no instance for %dx%d", a.R, a.S);
             PNP_CHECK_LAUNCH("conv_taps_kernel");
         }
     }

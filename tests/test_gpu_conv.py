@@ -37,6 +37,11 @@ CASES = [
     (2, 16, 16, 5, 16, 3, 2, 1, "SAME"),        # mask critic C=5
     (2, 1, 1, 2048, 1, 1, 1, 1, "VALID"),       # FC as 1x1 conv (adversarial.py:395-397)
     (3, 9, 7, 20, 24, 3, 1, 1, "SAME"),         # ragged everything
+    (2, 15, 13, 32, 32, 3, 2, 1, "SAME"),       # stride phases with odd extents (phase grids of different sizes)
+    (2, 9, 9, 32, 64, 3, 2, 1, "VALID"),        # stride 2 VALID: bottom/right input rows no output reads (dx rows of zeros)
+    (1, 14, 14, 32, 64, 5, 3, 1, "SAME"),       # stride 3, 5x5: phases with 2 and 1 taps per axis
+    (2, 8, 8, 32, 32, 1, 2, 1, "SAME"),         # filter smaller than the stride: zero-upsampled fallback
+    (2, 10, 10, 20, 24, 3, 2, 1, "SAME"),       # stride phases on the generic (C % 32 != 0) loaders
 ]
 
 
