@@ -219,9 +219,9 @@ def main():
             fl, by, ms, n = tot[True]
             if n:
                 ach = fl / (ms * 1e-3) / 1e12
-                res["roofline"] = {"bound": "mfma", "kernel": "conv_taps_kernel<128,128,2,2,0,3> (forward 3x3 convs on the 128x128 fp32-MFMA tile: 256->512, 512->512 (+dilated), 512->2560)",
+                res["roofline"] = {"bound": "mfma", "kernel": "conv_taps_kernel<128,128,2,2,0,3,3> (forward 3x3 convs on the 128x128 fp32-MFMA tile: 256->512, 512->512 (+dilated), 512->2560)",
                                    "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                                   "traffic": pmc_traffic_bytes("conv_taps_kernel<128, 128, 2, 2, 0, 3>"), "launches": n, "avg_launch_ms": ms / n,
+                                   "traffic": pmc_traffic_bytes("conv_taps_kernel<128, 128, 2, 2, 0, 3, 3>"), "launches": n, "avg_launch_ms": ms / n,
                                    "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mbytes_per_launch": by / n / 1e6,
                                    "traffic_note": "HBM-side bytes per launch of this kernel symbol from the committed rocprofv3 PMC passes "
                                                    "(profiles/r01_pmc_counters.json: 2*FETCH_SIZE + WRITE_SIZE, separate passes); null if absent"}

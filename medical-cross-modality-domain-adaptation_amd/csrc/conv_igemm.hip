@@ -866,14 +866,20 @@ __global__ void splitk_reduce_scatter_kernel(const float* __restrict__ part, Con
     }
 }
 
-// stride-phase (pa, pb) of w [R][S][C][K] -> wt [T][U][K][C]: taps r = pa + st*t, s = pb + st*u, both axes flipped
-__global__ void flip_transpose_phase_kernel(const float* __restrict__ w, float* __restrict__ wt, int R, int S, int C, int K, int pa,
-                                            int pb, int st, int T, int U) {
+// every stride-phase sub-filter of w [R][S][C][K] in one launch: tap (r, s) belongs to phase (pa, pb) = (r % st, s % st) and lands,
+// flipped on both axes, in that phase's wt [T][U][K][C] block; the blocks are packed in (pa, pb) order (plan_phases' wt_off)
+__global__ void flip_transpose_phase_kernel(const float* __restrict__ w, float* __restrict__ wt, int R, int S, int C, int K, int st) {
     __shared__ float tile[32][33];
-    const int tf = blockIdx.z / U, uf = blockIdx.z - tf * U;          // flipped tap of the phase filter
-    const int r = pa + st * (T - 1 - tf), sx = pb + st * (U - 1 - uf);
-    const float* src = w + (size_t)(r * S + sx) * C * K;
-    float* dst = wt + (size_t)blockIdx.z * K * C;
+    const int r = blockIdx.z / S, sx = blockIdx.z - r * S;
+    const int pa = r % st, pb = sx % st;
+    const int T = (R - pa + st - 1) / st, U = (S - pb + st - 1) / st;
+    int taps_before = 0;                                             // taps of the phases packed in front of (pa, pb)
+    for (int a = 0; a < st; ++a)
+        for (int b = 0; b < st; ++b)
+            if (a * st + b < pa * st + pb) taps_before += ((R - a + st - 1) / st) * ((S - b + st - 1) / st);
+    const int tf = T - 1 - r / st, uf = U - 1 - sx / st;            // flipped position inside the phase filter
+    const float* src = w + (size_t)blockIdx.z * C * K;
+    float* dst = wt + ((size_t)taps_before + tf * U + uf) * K * C;
     const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
@@ -1336,13 +1342,12 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
         size_t poff = woff;
         if (symp) poff += ((size_t)g->N * Ho * Wo * g->C * sizeof(float) + 255) & ~(size_t)255;
         float* split_ws = (workspace_bytes > poff) ? (float*)((char*)workspace + poff) : nullptr;
+        dim3 tgp((unsigned)pnp_cdiv(g->K, 32), (unsigned)pnp_cdiv(g->C, 32), (unsigned)(g->R * g->S));
+        hipLaunchKernelGGL(flip_transpose_phase_kernel, tgp, dim3(256), 0, st, w, wt, g->R, g->S, g->C, g->K, g->stride);
+        PNP_CHECK_LAUNCH("flip_transpose_phase_kernel");
         for (int i = 0; i < nph; ++i) {
             const DgradPhase& p = ph[i];
             if (p.I == 0 || p.J == 0) continue;
-            dim3 tgp((unsigned)pnp_cdiv(g->K, 32), (unsigned)pnp_cdiv(g->C, 32), (unsigned)(p.T * p.U));
-            hipLaunchKernelGGL(flip_transpose_phase_kernel, tgp, dim3(256), 0, st, w, wt + p.wt_off, g->R, g->S, g->C, g->K, p.pa, p.pb,
-                               g->stride, p.T, p.U);
-            PNP_CHECK_LAUNCH("flip_transpose_phase_kernel");
             const pnp_conv_geom d = phase_geom(g, p);
             ConvArgs a = make_args(dy, wt + p.wt_off, outp, &d);
             a.o_s = g->stride; a.o_H = Ho; a.o_W = Wo; a.o_h0 = p.h0; a.o_w0 = p.w0;
