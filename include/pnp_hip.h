@@ -104,6 +104,16 @@ int pnp_bn_bwd(const float* dout, const float* out, const float* x, const float*
                int64_t P, int32_t C, float eps, float alpha, int32_t training,
                float keep_prob, uint64_t seed, uint32_t stream_id,
                void* workspace, size_t workspace_bytes, void* stream);
+/* The two halves of pnp_bn_bwd, for synchronised batch statistics under data parallelism: reduce the local
+ * sums, all-reduce dgamma / dbeta across ranks (caller, RCCL), then apply with P_norm = the GLOBAL row count behind them.
+ * pnp_bn_bwd == reduce followed by apply with P_norm = P. */
+int pnp_bn_bwd_reduce(const float* dout, const float* out, const float* x, const float* mean, const float* var,
+                      float* dgamma, float* dbeta, int64_t P, int32_t C, float eps, float alpha,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int pnp_bn_bwd_apply(const float* dout, const float* out, const float* x, const float* mean, const float* var,
+                     const float* gamma, const float* dgamma, const float* dbeta, float* dx, float* dshortcut, int32_t Cs,
+                     int64_t P, int64_t P_norm, int32_t C, float eps, float alpha, int32_t training,
+                     float keep_prob, uint64_t seed, uint32_t stream_id, void* stream);
 
 /* relu/leaky-relu of (a + shortcut) with no BN (not on the reference path; kept for the dead helpers) — omitted. */
 
@@ -132,6 +142,11 @@ int pnp_seg_loss_fwd(const float* logits, const float* y, float* out, int64_t P,
 int pnp_seg_loss_bwd(const float* logits, const float* y, float* dlogits, int64_t P, int32_t ncls,
                      float miu_cross, float miu_dice, float gscale,
                      const void* workspace, size_t workspace_bytes, void* stream);
+/* Same with the pixel-mean normaliser given explicitly: under data parallelism with batch-global loss normalisers the caller
+ * all-reduces the 32 double sums at the head of the workspace (class counts, Dice sums) and passes P_norm = global pixel count. */
+int pnp_seg_loss_bwd_norm(const float* logits, const float* y, float* dlogits, int64_t P, int64_t P_norm, int32_t ncls,
+                          float miu_cross, float miu_dice, float gscale,
+                          const void* workspace, size_t workspace_bytes, void* stream);
 /* pixel_wise_softmax_2 + tf.argmax (layers.py:134-138, source_segmenter.py:80-81): exp(z)/sum exp(z), lowest index on ties */
 int pnp_softmax_argmax(const float* logits, float* prob /*nullable*/, int64_t* label, int64_t P, int32_t ncls, void* stream);
 /* lib._dice_eval (lib.py:96-110): out[0]=mean dice, out[1..ncls]=per class; label = argmax map, y one-hot */

@@ -5,6 +5,13 @@ PyTorch fallback: if the shared library is missing or a call fails, we raise.
 """
 import ctypes
 import os
+
+# torch FIRST: its wheel carries its own libamdhip64 / libhsa-runtime64.  Loaded after torch, libpnp_hip.so's DT_NEEDED libamdhip64.so.7
+# resolves to that already-mapped runtime (one HIP runtime per process, shared streams and allocations).  Loaded BEFORE torch, the
+# system copy under /opt/rocm comes in as a second HIP + HSA runtime and every launch from this library fails with
+# "no ROCm-capable device is detected" (measured on the GPU box; tests/test_abi.py guards the order).
+import torch  # noqa: F401  (import order is the point)
+
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -49,6 +56,9 @@ PROTOTYPES = {
     "pnp_bn_apply": (c_int, [_F, _F, _F, _F, _F, _F, c_int32, _F, c_int64, c_int32, c_float, c_float, c_void_p]),
     "pnp_bn_bwd": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int32, c_float, c_float, c_int32,
                            c_float, c_uint64, c_uint32, c_void_p, c_size_t, c_void_p]),
+    "pnp_bn_bwd_reduce": (c_int, [_F, _F, _F, _F, _F, _F, _F, c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    "pnp_bn_bwd_apply": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int64, c_int32, c_float, c_float, c_int32,
+                                 c_float, c_uint64, c_uint32, c_void_p]),
     "pnp_maxpool2_fwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pnp_maxpool2_bwd": (c_int, [_F, _F, _F, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pnp_ps_fwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
@@ -58,6 +68,7 @@ PROTOTYPES = {
     "pnp_seg_loss_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "pnp_seg_loss_fwd": (c_int, [_F, _F, _F, c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "pnp_seg_loss_bwd": (c_int, [_F, _F, _F, c_int64, c_int32, c_float, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    "pnp_seg_loss_bwd_norm": (c_int, [_F, _F, _F, c_int64, c_int64, c_int32, c_float, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "pnp_softmax_argmax": (c_int, [_F, _F, c_void_p, c_int64, c_int32, c_void_p]),
     "pnp_dice_eval": (c_int, [c_void_p, _F, _F, c_int64, c_int32, c_void_p, c_size_t, c_void_p]),
     "pnp_adam_step": (c_int, [_F, _F, _F, _F, c_size_t, _F, c_void_p, c_float, c_float, c_float, c_float, c_int32, c_void_p]),

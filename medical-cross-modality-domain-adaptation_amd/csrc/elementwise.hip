@@ -276,6 +276,7 @@ struct BnBwdArgs {
     const float *dout, *out, *x, *mean, *var, *gamma, *dgamma, *dbeta;
     float *dx, *dshortcut;
     long long P;
+    long long P_norm;    // rows behind dgamma / dbeta: P, or the global row count when the sums were all-reduced (SyncBN)
     int C, Cs;
     float eps, alpha;
     int training;
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(BnBwdArgs a) {
     const int CV = VEC ? (a.C >> 2) : a.C;
     const size_t nvec = (size_t)a.P * CV;
     const int cpad = (a.C - a.Cs) / 2;
-    const float invP = (float)(1.0 / (double)a.P);
+    const float invP = (float)(1.0 / (double)a.P_norm);
     const size_t gs = (size_t)gridDim.x * NT;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += gs) {
         const size_t row = i / CV;
@@ -587,21 +588,30 @@ int pnp_bn_apply(const float* x, const float* mean, const float* var, const floa
     return PNP_OK;
 }
 
-int pnp_bn_bwd(const float* dout, const float* out, const float* x, const float* mean, const float* var,
-               const float* gamma, float* dx, float* dgamma, float* dbeta, float* dshortcut, int32_t Cs, int64_t P,
-               int32_t C, float eps, float alpha, int32_t training, float keep_prob, uint64_t seed, uint32_t stream_id,
-               void* workspace, size_t workspace_bytes, void* stream) {
-    PNP_REQUIRE(dout && x && mean && var && gamma && dx && dgamma && dbeta && P > 0 && C > 0, "pnp_bn_bwd: bad argument");
-    PNP_REQUIRE(alpha < 0.f || out, "pnp_bn_bwd: `out` is required when an activation is fused");
-    PNP_REQUIRE((size_t)P * C < (1ull << 32), "pnp_bn_bwd: tensor exceeds 2^32 elements");
-    if (dshortcut) PNP_REQUIRE(Cs > 0 && Cs <= C && ((C - Cs) % 2) == 0, "pnp_bn_bwd: bad shortcut channels");
-    hipStream_t st = (hipStream_t)stream;
+int pnp_bn_bwd_reduce(const float* dout, const float* out, const float* x, const float* mean, const float* var, float* dgamma,
+                      float* dbeta, int64_t P, int32_t C, float eps, float alpha, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    PNP_REQUIRE(dout && x && mean && var && dgamma && dbeta && P > 0 && C > 0, "pnp_bn_bwd_reduce: bad argument");
+    PNP_REQUIRE(alpha < 0.f || out, "pnp_bn_bwd_reduce: `out` is required when an activation is fused");
+    PNP_REQUIRE((size_t)P * C < (1ull << 32), "pnp_bn_bwd_reduce: tensor exceeds 2^32 elements");
     ColArgs ca{};
     ca.x = x; ca.dout = dout; ca.out = out; ca.mean = mean; ca.var = var; ca.P = P; ca.C = C; ca.eps = eps; ca.alpha = alpha;
-    if (int e = run_colreduce<1>(ca, dbeta, dgamma, workspace, workspace_bytes, st, "pnp_bn_bwd")) return e;
+    return run_colreduce<1>(ca, dbeta, dgamma, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_bwd_reduce");
+}
+
+int pnp_bn_bwd_apply(const float* dout, const float* out, const float* x, const float* mean, const float* var,
+                     const float* gamma, const float* dgamma, const float* dbeta, float* dx, float* dshortcut, int32_t Cs,
+                     int64_t P, int64_t P_norm, int32_t C, float eps, float alpha, int32_t training, float keep_prob,
+                     uint64_t seed, uint32_t stream_id, void* stream) {
+    PNP_REQUIRE(dout && x && mean && var && gamma && dx && P > 0 && P_norm >= P && C > 0, "pnp_bn_bwd_apply: bad argument");
+    PNP_REQUIRE(!training || (dgamma && dbeta), "pnp_bn_bwd_apply: training mode needs the dgamma / dbeta sums");
+    PNP_REQUIRE(alpha < 0.f || out, "pnp_bn_bwd_apply: `out` is required when an activation is fused");
+    PNP_REQUIRE((size_t)P * C < (1ull << 32), "pnp_bn_bwd_apply: tensor exceeds 2^32 elements");
+    if (dshortcut) PNP_REQUIRE(Cs > 0 && Cs <= C && ((C - Cs) % 2) == 0, "pnp_bn_bwd_apply: bad shortcut channels");
+    hipStream_t st = (hipStream_t)stream;
     BnBwdArgs a{};
     a.dout = dout; a.out = out; a.x = x; a.mean = mean; a.var = var; a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta;
-    a.dx = dx; a.dshortcut = dshortcut; a.P = P; a.C = C; a.Cs = dshortcut ? Cs : C; a.eps = eps; a.alpha = alpha;
+    a.dx = dx; a.dshortcut = dshortcut; a.P = P; a.P_norm = P_norm; a.C = C; a.Cs = dshortcut ? Cs : C; a.eps = eps; a.alpha = alpha;
     a.training = training;
     a.do_drop = keep_prob < 1.f;
     a.drop_key = pnp_drop_key(seed, stream_id);
@@ -611,8 +621,17 @@ int pnp_bn_bwd(const float* dout, const float* out, const float* x, const float*
     const size_t nvec = (size_t)P * (vec ? C / 4 : C);
     if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(nvec)), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(nvec)), dim3(NT), 0, st, a);
-    PNP_CHECK_LAUNCH("pnp_bn_bwd");
+    PNP_CHECK_LAUNCH("pnp_bn_bwd_apply");
     return PNP_OK;
+}
+
+int pnp_bn_bwd(const float* dout, const float* out, const float* x, const float* mean, const float* var,
+               const float* gamma, float* dx, float* dgamma, float* dbeta, float* dshortcut, int32_t Cs, int64_t P,
+               int32_t C, float eps, float alpha, int32_t training, float keep_prob, uint64_t seed, uint32_t stream_id,
+               void* workspace, size_t workspace_bytes, void* stream) {
+    if (int e = pnp_bn_bwd_reduce(dout, out, x, mean, var, dgamma, dbeta, P, C, eps, alpha, workspace, workspace_bytes, stream)) return e;
+    return pnp_bn_bwd_apply(dout, out, x, mean, var, gamma, dgamma, dbeta, dx, dshortcut, Cs, P, P, C, eps, alpha, training, keep_prob,
+                            seed, stream_id, stream);
 }
 
 int pnp_dropout(const float* x, float* y, size_t n, float keep_prob, uint64_t seed, uint32_t stream_id, void* stream) {

@@ -116,7 +116,8 @@ __global__ void seg_loss_final_kernel(const float* __restrict__ part, double* __
 
 __global__ void __launch_bounds__(NT) seg_loss_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ y,
                                                           float* __restrict__ dlogits, const double* __restrict__ sums,
-                                                          long long P, int ncls, float miu_cross, float miu_dice, float gscale) {
+                                                          long long P, long long P_norm, int ncls, float miu_cross, float miu_dice,
+                                                          float gscale) {
     float w[MAXC], invD[MAXC], I2[MAXC];
     {
         double ntot = 0.0;
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(NT) seg_loss_bwd_kernel(const float* __restric
         for (int j = 0; j < MAXC; ++j) {
             if (j < ncls) {
                 const double D = sums[2 * MAXC + j] + sums[j] + 1e-7;
-                w[j] = (float)((1.0 - sums[j] / ntot) / (double)P);
+                w[j] = (float)((1.0 - sums[j] / ntot) / (double)P_norm);
                 invD[j] = (float)(1.0 / D);
                 I2[j] = (float)(2.0 * sums[MAXC + j] / (D * D));
             } else {
@@ -366,14 +367,21 @@ int pnp_seg_loss_fwd(const float* logits, const float* y, float* out, int64_t P,
     return PNP_OK;
 }
 
-int pnp_seg_loss_bwd(const float* logits, const float* y, float* dlogits, int64_t P, int32_t ncls, float miu_cross,
-                     float miu_dice, float gscale, const void* workspace, size_t workspace_bytes, void* stream) {
-    PNP_REQUIRE(logits && y && dlogits && workspace && P > 0 && ncls > 0 && ncls <= MAXC, "pnp_seg_loss_bwd: bad argument");
+int pnp_seg_loss_bwd_norm(const float* logits, const float* y, float* dlogits, int64_t P, int64_t P_norm, int32_t ncls,
+                          float miu_cross, float miu_dice, float gscale, const void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    PNP_REQUIRE(logits && y && dlogits && workspace && P > 0 && P_norm >= P && ncls > 0 && ncls <= MAXC,
+                "pnp_seg_loss_bwd: bad argument");
     PNP_REQUIRE(workspace_bytes >= 256, "pnp_seg_loss_bwd: workspace too small");
     hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3(loss_blocks(P)), dim3(NT), 0, (hipStream_t)stream, logits, y, dlogits,
-                       (const double*)workspace, (long long)P, ncls, miu_cross, miu_dice, gscale);
+                       (const double*)workspace, (long long)P, (long long)P_norm, ncls, miu_cross, miu_dice, gscale);
     PNP_CHECK_LAUNCH("seg_loss_bwd_kernel");
     return PNP_OK;
+}
+
+int pnp_seg_loss_bwd(const float* logits, const float* y, float* dlogits, int64_t P, int32_t ncls, float miu_cross,
+                     float miu_dice, float gscale, const void* workspace, size_t workspace_bytes, void* stream) {
+    return pnp_seg_loss_bwd_norm(logits, y, dlogits, P, P, ncls, miu_cross, miu_dice, gscale, workspace, workspace_bytes, stream);
 }
 
 int pnp_softmax_argmax(const float* logits, float* prob, int64_t* label, int64_t P, int32_t ncls, void* stream) {

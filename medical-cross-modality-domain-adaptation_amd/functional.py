@@ -11,6 +11,7 @@ import torch
 from torch.autograd import Function
 
 from . import kernels as K
+from . import parallel as par
 
 BN_EPS = 1e-3      # tf.contrib.layers.batch_norm default epsilon (layers.py:100 does not override it)
 BN_DECAY = 0.90    # layers.py:100
@@ -19,6 +20,17 @@ LEAK = 0.2         # tf.nn.leaky_relu default alpha (layers.py:12,35,166,187)
 
 def _contig(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, keep, seed, sid):
+    """backward of BN (+activation, +dropout mask of the conv in front).  With synchronised statistics the per-channel sums are
+    all-reduced between the reduction and the apply kernel; the PARAMETER gradients stay local (the GradReducer sums them)."""
+    if ctx.is_train and ctx.P_norm != xc.numel() // xc.shape[-1]:
+        sums = K.bn_bwd_reduce(dout, out, xc, mean, var, BN_EPS, ctx.alpha)
+        gsums = par.all_sum_(sums.clone())
+        dxc, dsc = K.bn_bwd_apply(dout, out, xc, mean, var, gamma, gsums, ctx.P_norm, need_sc, BN_EPS, ctx.alpha, True, keep, seed, sid)
+        return dxc, sums[0], sums[1], dsc
+    return K.bn_bwd(dout, out, xc, mean, var, gamma, need_sc, BN_EPS, ctx.alpha, ctx.is_train, keep, seed, sid)
 
 
 class Conv2dDropFn(Function):
@@ -51,9 +63,13 @@ class ConvBNActFn(Function):
         w_ = _contig(w)
         xc = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
         P = xc.numel() // xc.shape[-1]
+        ctx.P_norm = P
         if is_train:
             mean, var = K.bn_stats(xc)
-            K.bn_update_moving(moving_mean, moving_var, mean, var, P, BN_DECAY)
+            if par.sync_world() > 1:        # opt-in SyncBN: statistics of the batch concatenated over the replicas
+                mean, var = par.sync_bn_stats(mean, var)
+                ctx.P_norm = P * par.sync_world()
+            K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
         else:
             # inference statistics; snapshot only if a backward pass will read them after the moving averages may have moved
             mean, var = (moving_mean.clone(), moving_var.clone()) if any(ctx.needs_input_grad) else (moving_mean, moving_var)
@@ -70,8 +86,7 @@ class ConvBNActFn(Function):
         x, w, xc, out, mean, var, gamma = ctx.saved_tensors
         dout = _contig(dout)
         need_sc = ctx.sc_channels if ctx.needs_input_grad[6] else 0
-        dxc, dgamma, dbeta, dsc = K.bn_bwd(dout, out, xc, mean, var, gamma, need_sc, BN_EPS, ctx.alpha, ctx.is_train,
-                                           ctx.keep, ctx.seed, ctx.sid)
+        dxc, dgamma, dbeta, dsc = _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, ctx.keep, ctx.seed, ctx.sid)
         dx = K.conv2d_dgrad(dxc, w, ctx.geom) if ctx.needs_input_grad[0] else None
         dw = K.conv2d_wgrad(x, dxc, ctx.geom) if ctx.needs_input_grad[1] else None
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, None, None,
@@ -85,9 +100,13 @@ class BNActFn(Function):
     def forward(ctx, xc, gamma, beta, moving_mean, moving_var, is_train, alpha):
         xc = _contig(xc)
         P = xc.numel() // xc.shape[-1]
+        ctx.P_norm = P
         if is_train:
             mean, var = K.bn_stats(xc)
-            K.bn_update_moving(moving_mean, moving_var, mean, var, P, BN_DECAY)
+            if par.sync_world() > 1:        # opt-in SyncBN: statistics of the batch concatenated over the replicas
+                mean, var = par.sync_bn_stats(mean, var)
+                ctx.P_norm = P * par.sync_world()
+            K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
         else:
             # inference statistics; snapshot only if a backward pass will read them after the moving averages may have moved
             mean, var = (moving_mean.clone(), moving_var.clone()) if any(ctx.needs_input_grad) else (moving_mean, moving_var)
@@ -99,7 +118,7 @@ class BNActFn(Function):
     @staticmethod
     def backward(ctx, dout):
         xc, out, mean, var, gamma = ctx.saved_tensors
-        dxc, dgamma, dbeta, _ = K.bn_bwd(_contig(dout), out, xc, mean, var, gamma, 0, BN_EPS, ctx.alpha, ctx.is_train)
+        dxc, dgamma, dbeta, _ = _bn_bwd(ctx, _contig(dout), out, xc, mean, var, gamma, 0, 1.0, 0, 0)
         return dxc, dgamma, dbeta, None, None, None, None
 
 
@@ -153,6 +172,12 @@ class SegLossFn(Function):
         logits = _contig(logits)
         y = _contig(y)
         out, ws = K.seg_loss_fwd(logits, y, miu_cross, miu_dice)
+        ctx.P_norm = None
+        w = par.sync_world()
+        if w > 1:       # opt-in batch-global normalisers: class counts and Dice sums of all replicas, mean over all pixels;
+            par.all_sum_(K.seg_loss_sums(ws))      # `out` stays this replica's value (logging only)
+            ctx.P_norm = w * (logits.numel() // logits.shape[-1])
+            gscale = gscale * w                     # the replicas' gradients are summed, not averaged, in this mode
         ctx.save_for_backward(logits, y, ws)
         ctx.mc, ctx.md, ctx.gscale = miu_cross, miu_dice, gscale
         return out
@@ -160,7 +185,7 @@ class SegLossFn(Function):
     @staticmethod
     def backward(ctx, dout):
         logits, y, ws = ctx.saved_tensors
-        g = K.seg_loss_bwd(logits, y, ws, ctx.mc, ctx.md, ctx.gscale)
+        g = K.seg_loss_bwd(logits, y, ws, ctx.mc, ctx.md, ctx.gscale, ctx.P_norm)
         return g, None, None, None, None
 
 

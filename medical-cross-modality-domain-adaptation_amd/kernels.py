@@ -163,6 +163,34 @@ def bn_bwd(dout, out, x, mean, var, gamma, shortcut_channels=0, eps=1e-3, alpha=
     return dx, dgamma, dbeta, dsc
 
 
+def bn_bwd_reduce(dout, out, x, mean, var, eps=1e-3, alpha=0.2):
+    """local sums (dgamma = sum dz*xhat, dbeta = sum dz) — first half of bn_bwd, for SyncBN"""
+    lib = _lib.load()
+    C = x.shape[-1]
+    P = x.numel() // C
+    sums = torch.empty((2, C), dtype=torch.float32, device=x.device)      # [dgamma, dbeta]
+    ws = workspace(lib.pnp_bn_workspace_bytes(P, C), x.device)
+    check(lib.pnp_bn_bwd_reduce(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(sums[0]), _p(sums[1]), P, C, float(eps), float(alpha),
+                                ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_bn_bwd_reduce")
+    return sums
+
+
+def bn_bwd_apply(dout, out, x, mean, var, gamma, sums, P_norm, shortcut_channels=0, eps=1e-3, alpha=0.2, training=True, keep_prob=1.0,
+                 seed=0, stream_id=0):
+    """second half of bn_bwd with the (possibly all-reduced) sums and the row count behind them"""
+    lib = _lib.load()
+    C = x.shape[-1]
+    P = x.numel() // C
+    dx = torch.empty_like(x)
+    dsc = None
+    if shortcut_channels:
+        dsc = torch.empty(x.shape[:-1] + (shortcut_channels,), dtype=torch.float32, device=x.device)
+    check(lib.pnp_bn_bwd_apply(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(sums[0]), _p(sums[1]), _p(dx), _p(dsc),
+                               shortcut_channels, P, int(P_norm), C, float(eps), float(alpha), 1 if training else 0, float(keep_prob),
+                               int(seed), int(stream_id), _stream()), "pnp_bn_bwd_apply")
+    return dx, dsc
+
+
 def maxpool2_fwd(x):
     lib = _lib.load()
     N, H, W, C = x.shape
@@ -227,14 +255,20 @@ def seg_loss_fwd(logits, y, miu_cross=1.0, miu_dice=1.0):
     return out, ws
 
 
-def seg_loss_bwd(logits, y, ws, miu_cross=1.0, miu_dice=1.0, gscale=1.0):
+def seg_loss_bwd(logits, y, ws, miu_cross=1.0, miu_dice=1.0, gscale=1.0, P_norm=None):
+    """P_norm: pixel count behind the sums in `ws` when they were all-reduced over the replicas (default: this tensor's)"""
     lib = _lib.load()
     ncls = logits.shape[-1]
     P = logits.numel() // ncls
     dl = torch.empty_like(logits)
-    check(lib.pnp_seg_loss_bwd(_p(logits), _p(y), _p(dl), P, ncls, float(miu_cross), float(miu_dice), float(gscale),
-                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_seg_loss_bwd")
+    check(lib.pnp_seg_loss_bwd_norm(_p(logits), _p(y), _p(dl), P, int(P_norm or P), ncls, float(miu_cross), float(miu_dice),
+                                    float(gscale), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_seg_loss_bwd_norm")
     return dl
+
+
+def seg_loss_sums(ws):
+    """the 32 double sums at the head of a seg_loss workspace (per class: n_i, sum p*y, sum p*p, cross-entropy terms), as a view"""
+    return ws[:256].view(torch.float64)
 
 
 def softmax_argmax(logits, want_prob=True):

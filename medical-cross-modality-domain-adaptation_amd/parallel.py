@@ -8,7 +8,10 @@ over the 8 GPUs of a node is new functionality required by BASELINE.json.  Desig
     the arena is cut into ~32 MiB buckets in REVERSE variable order, and each bucket is all-reduced (sum) on a side HIP
     stream as soon as the last gradient inside it has been produced, overlapping the rest of the backward pass;
   * the 1/W average is folded into the loss-gradient kernel (gscale), so the reduced arena feeds the optimiser directly;
-  * BatchNorm uses per-replica statistics (like every DP framework); batch-global loss normalisers are per replica too.
+  * BatchNorm uses per-replica statistics (like every DP framework) and the batch-global loss normalisers are per replica too —
+    unless `enable_sync_stats()` is on: then the BN batch statistics, the BN backward sums and the loss's class / Dice sums are
+    all-reduced (tiny, latency-bound messages: ~2 per BN layer per pass), which makes W ranks x B slices compute exactly the
+    single-GPU step on W*B slices.  It exists for that parity test (tests/test_gpu_dp.py); production keeps it off.
 """
 import os
 
@@ -32,6 +35,47 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+_SYNC = None     # (process group, world size) while batch statistics and loss normalisers are synchronised across replicas
+
+
+def enable_sync_stats(group=None):
+    """SyncBN + batch-global loss normalisers (opt-in)"""
+    global _SYNC
+    w = dist.get_world_size(group) if dist.is_initialized() else 1
+    _SYNC = (group, w) if w > 1 else None
+
+
+def disable_sync_stats():
+    global _SYNC
+    _SYNC = None
+
+
+def sync_world():
+    return _SYNC[1] if _SYNC else 1
+
+
+def all_sum_(t):
+    """in-place sum over the replicas of the sync group (no-op when synchronisation is off)"""
+    if _SYNC:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_SYNC[0])
+    return t
+
+
+def sync_bn_stats(mean, var):
+    """per-replica (mean, biased var) over equally many rows -> the statistics of the concatenated batch.  Combined in float64:
+    E[x] = avg(mean_r), E[x^2] = avg(var_r + mean_r^2)."""
+    w = sync_world()
+    if w <= 1:
+        return mean, var
+    m = mean.double()
+    st = torch.stack([m, var.double() + m * m])
+    all_sum_(st)
+    st /= w
+    gm = st[0]
+    gv = (st[1] - gm * gm).clamp_min_(0.0)
+    return gm.float(), gv.float()
 
 
 def barrier():

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import adversarial as drn
 from .lib import _read_lists
-from .parallel import GradReducer, barrier, init_distributed
+from .parallel import GradReducer, barrier, enable_sync_stats, init_distributed
 
 logging.basicConfig(level=logging.INFO)
 rate = 0.3
@@ -60,11 +60,15 @@ def main(phase, argv=None):
     ap.add_argument("--output", default="./tmp_exps/mr2ct" + date)
     ap.add_argument("--baseline", default=None)
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--sync-stats", action="store_true", help="data parallel only: all-reduce BN statistics and loss normalisers "
+                    "(exactly the single-GPU step on the concatenated batch; ~2 tiny collectives per BN layer per pass)")
     args = ap.parse_args(argv)
     ck, nc, tc = configure(args.phase)
     num_cls, batch_size = 5, args.batch_size
     output_path = args.output
     rank, local, world = init_distributed()     # >1 only under torch.distributed.run: data-parallel, --batch-size slices per rank
+    if args.sync_stats:
+        enable_sync_stats()
     if os.environ.get("PNP_SAME_DEVICE"):       # test mode: several gloo ranks on one GPU (tests/test_gpu_dp.py)
         local = 0
     device = "cuda:%d" % local if (world > 1 and args.device == "cuda") else args.device

@@ -57,3 +57,17 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h")):
                 assert "oracle" not in open(os.path.join(dp, f)).read().replace("oracle/dropout.py", "").replace("oracle/tf_ops.py", ""), f
+
+
+def test_torch_is_loaded_before_the_library():
+    """a fresh interpreter that imports ONLY the binding must end up with torch's HIP runtime mapped before libpnp_hip.so: loaded the
+    other way round, the system libamdhip64 becomes a second runtime in the process and every launch reports 'no ROCm-capable device'"""
+    import subprocess
+    import sys
+    from conftest import PKG, ROOT
+    code = ("import sys, importlib; sys.path.insert(0, %r); L = importlib.import_module(%r + '._lib'); "
+            "assert 'torch' in sys.modules; L.load(); "
+            "hip = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}); print(hip); "
+            "assert len(hip) == 1, hip") % (ROOT, PKG)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
