@@ -190,3 +190,41 @@ print("rank", rank, "ok")
                         "--master-port", "29731", str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert p.stdout.count("ok") == 2
+
+
+def test_gloo_two_rank_synchronised_statistics(tmp_path):
+    """parallel.sync_bn_stats / all_sum_ on CPU with 2 ranks: the combined (mean, biased variance) of two half-batches equals the
+    statistics of the whole batch; with synchronisation off both are identities."""
+    script = tmp_path / "w.py"
+    script.write_text('''
+import importlib, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+par = importlib.import_module("medical-cross-modality-domain-adaptation_amd.parallel")
+rank, local, world = par.init_distributed("gloo")
+rng = np.random.default_rng(0)
+x = torch.from_numpy((rng.standard_normal((2, 64, 7)) * [1, 2, 3, 4, 5, 6, 7] + np.arange(7) * 10.0).astype(np.float32))   # [rank][rows][C]
+mine = x[rank]
+mean, var = mine.mean(0), mine.var(0, unbiased=False)
+m0, v0 = par.sync_bn_stats(mean, var)
+assert m0 is mean and v0 is var and par.sync_world() == 1          # off: identity
+t = torch.ones(3) * (rank + 1)
+assert torch.equal(par.all_sum_(t.clone()), t)
+par.enable_sync_stats()
+assert par.sync_world() == 2
+gm, gv = par.sync_bn_stats(mean, var)
+full = x.reshape(-1, 7).double()
+assert torch.allclose(gm.double(), full.mean(0), rtol=1e-6, atol=1e-6), (gm, full.mean(0))
+assert torch.allclose(gv.double(), full.var(0, unbiased=False), rtol=1e-5), (gv, full.var(0, unbiased=False))
+assert torch.equal(par.all_sum_(t.clone()), torch.ones(3) * 3)
+par.disable_sync_stats()
+assert par.sync_world() == 1
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+''' % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29733", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.stdout.count("ok") == 2
