@@ -131,3 +131,32 @@ def test_conv_full_size_vs_naive_kernel(dev, shape):
     y2 = K.conv2d_fwd(x2, w, g)
     ylin = K.conv2d_fwd(x * 0.5 + x2, w, g)
     assert _rel(ylin, y * 0.5 + y2) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [
+    (16, 32, 32, 512, 512, 3, 1, 1, "SAME"), (16, 32, 32, 512, 512, 3, 1, 2, "SAME"), (4, 32, 32, 512, 2560, 3, 1, 1, "SYMMETRIC"),
+    (16, 256, 256, 3, 16, 3, 1, 1, "SAME"), (16, 256, 256, 40, 5, 5, 1, 1, "SYMMETRIC"), (16, 256, 256, 64, 64, 3, 2, 1, "SAME"),
+    (16, 128, 128, 128, 128, 5, 2, 1, "SAME"), (16, 64, 64, 256, 256, 3, 2, 1, "SAME"), (16, 16, 16, 512, 512, 5, 4, 1, "SAME"),
+    (16, 4, 4, 512, 512, 3, 2, 1, "SYMMETRIC")])
+def test_conv_full_size_adjoint_identities(dev, shape):
+    """BASELINE sizes (B=16), size-independent property: conv is bilinear, so <conv(x,w), dy> = <x, dgrad(dy,w)> = <w, wgrad(x,dy)>.
+    One identity ties the three kernels (incl. the stride-phase data gradients and the reduction splits) together on every layer
+    shape of the hot path; inner products accumulated in float64 on the device."""
+    K = pkg("kernels")
+    N, H, W, C, Kc, R, stride, dil, padding = shape
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn((N, H, W, C), generator=gen).to(dev)
+    w = (torch.randn((R, R, C, Kc), generator=gen) / np.sqrt(R * R * C)).to(dev)
+    g = K.conv_geom(tuple(x.shape), tuple(w.shape), stride, dil, padding)
+    dy = torch.randn((N, g.OH, g.OW, Kc), generator=gen).to(dev)
+    y = K.conv2d_fwd(x, w, g)
+    dx = K.conv2d_dgrad(dy, w, g)
+    dw = K.conv2d_wgrad(x, dy, g)
+    assert dx.shape == x.shape and dw.shape == w.shape
+
+    def dot(a, b):
+        return float((a.double() * b.double()).sum())
+
+    a, b, c = dot(y, dy), dot(x, dx), dot(w, dw)
+    scale = float(y.double().norm() * dy.double().norm())       # |<y,dy>| <= |y||dy|: the natural error scale
+    assert abs(a - b) < 2e-6 * scale and abs(a - c) < 2e-6 * scale, (a, b, c, scale)
