@@ -853,6 +853,239 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
     }
 }
 
+// ===================================== direct filter gradient for narrow outputs ============================================
+// K <= 16 output channels (g1's 16-channel convs, the 40->5 logits conv, the mask critic's first conv): an MFMA tile is at most half
+// full in N and the reduction (all pixels) is long, so this one runs on the vector ALUs.  A thread owns PPT (tap, channel) pairs x K
+// accumulators, walks the pixels of its workgroup's slab, reads ONE x value per pair and pixel plus the pixel's K dy values (the
+// same address for a whole pixel group: a broadcast load) and issues PPT*K FMAs.  Workgroups with few pairs split their slab over G
+// pixel groups and combine through LDS.  Partials [nblk][R*S*C*K] are summed by splitk_reduce_kernel (fixed order: deterministic).
+struct WgdArgs {
+    const float* x;
+    const float* dy;
+    float* part;
+    int N, H, W, C, K, R, S, OH, OW, stride, dil, pad_t, pad_l;
+    int P;             // N*OH*OW
+    int npairs;        // R*S*C
+    int G;             // pixel groups per workgroup (1 when a thread owns several pairs)
+    int ppb;           // pixels per workgroup
+    unsigned x_bytes, dy_bytes;
+};
+
+typedef const float __attribute__((address_space(4))) pnp_cfloat;     // constant address space: uniform reads become s_load
+
+// UNI (one pixel group): the pixel index is uniform over the workgroup, so the K dy values come through the SCALAR cache into SGPRs
+// (v_fmac with an SGPR operand) instead of 64 lanes x 16 B of vector-memory traffic per wave and pixel for 64 useful bytes — the
+// texture-address unit, not the FMAs, bounded the first version (16->16: 0.54 ms).
+template <int KK, int PPT, bool EXACT, bool UNI>
+__global__ void __launch_bounds__(256) wgrad_direct_kernel(WgdArgs a) {
+    extern __shared__ float red[];      // [G][npairs*K], only when G > 1
+    const int t = threadIdx.x;
+    if (UNI && PPT == 1 && (t & ~63) >= a.npairs) return;      // whole wave without a pair (no barrier on this path)
+    const int g = (PPT == 1 && !UNI) ? t / a.npairs : 0;
+    const int j0 = (PPT == 1) ? t - g * a.npairs : t;
+    const bool active = g < a.G;
+    const int K = EXACT ? KK : a.K;
+    int coff[PPT], dh[PPT], dw[PPT];
+    bool pv[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int j = j0 + q * 256;
+        pv[q] = active && j < a.npairs;
+        const int jj = pv[q] ? j : 0;
+        const int tap = jj / a.C;
+        coff[q] = jj - tap * a.C;
+        const int r = tap / a.S;
+        dh[q] = r * a.dil - a.pad_t;
+        dw[q] = (tap - r * a.S) * a.dil - a.pad_l;
+    }
+    float acc[PPT][KK];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+#pragma unroll
+        for (int k = 0; k < KK; ++k) acc[q][k] = 0.f;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dy, a.dy_bytes);
+    const int p0 = blockIdx.x * a.ppb;
+    const int p1 = (p0 + a.ppb < a.P) ? p0 + a.ppb : a.P;
+    int p = UNI ? p0 : p0 + g;
+    pnp_cfloat* dyc = (pnp_cfloat*)(uintptr_t)a.dy;
+    const int OHW = a.OH * a.OW;
+    int n = p / OHW;
+    int rem = p - n * OHW;
+    int oh = rem / a.OW;
+    int ow = rem - oh * a.OW;
+    // U pixels per trip: all their loads are issued before the first FMA (one pixel per trip is bound by the global-load latency:
+    // 16->16 ran at 0.58 ms that way)
+    constexpr int U = 4;
+    for (; p < p1; p += U * a.G) {
+        float dv[U][KK], xv[U][PPT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pu = p + u * a.G;
+            const bool pin = pu < p1;
+            if constexpr (UNI) {
+                const size_t base = (size_t)(pin ? pu : p) * K;      // uniform; a pixel past the slab re-reads a valid row (its x is 0)
+#pragma unroll
+                for (int k = 0; k < KK; ++k) dv[u][k] = (k < K) ? dyc[base + k] : 0.f;
+            } else if constexpr (EXACT && (KK % 4) == 0) {
+#pragma unroll
+                for (int k4 = 0; k4 < KK / 4; ++k4) {
+                    const f32x4 v = bload4(rd, pin ? (unsigned)((pu * KK + 4 * k4) * 4) : OOB);
+                    dv[u][4 * k4] = v[0]; dv[u][4 * k4 + 1] = v[1]; dv[u][4 * k4 + 2] = v[2]; dv[u][4 * k4 + 3] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) dv[u][k] = (pin && k < K) ? bload1(rd, (unsigned)((pu * K + k) * 4)) : 0.f;
+            }
+            const int vh = oh * a.stride, vw = ow * a.stride;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const int ih = vh + dh[q], iw = vw + dw[q];
+                const bool ok = pin & pv[q] & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+                xv[u][q] = bload1(rx, ok ? (unsigned)((((n * a.H + ih) * a.W + iw) * a.C + coff[q]) * 4) : OOB);
+            }
+            ow += a.G;
+            while (ow >= a.OW) {
+                ow -= a.OW;
+                if (++oh == a.OH) { oh = 0; ++n; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                for (int k = 0; k < KK; ++k) acc[q][k] = fmaf(xv[u][q], dv[u][k], acc[q][k]);
+    }
+    const int nout = a.npairs * K;
+    float* outp = a.part + (size_t)blockIdx.x * nout;
+    if (a.G > 1) {          // PPT == 1
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < KK; ++k)
+                if (k < K) red[g * nout + j0 * K + k] = acc[0][k];
+        }
+        __syncthreads();
+        for (int e = t; e < nout; e += 256) {
+            float sum = 0.f;
+            for (int gg = 0; gg < a.G; ++gg) sum += red[gg * nout + e];
+            outp[e] = sum;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (pv[q]) {
+                const int j = j0 + q * 256;
+#pragma unroll
+                for (int k = 0; k < KK; ++k)
+                    if (k < K) outp[j * K + k] = acc[q][k];
+            }
+        }
+    }
+}
+
+// Same for C % 4 == 0 and many pairs (the 40->5 logits conv: 1000 pairs): a thread owns QPT quads of 4 consecutive channels of one
+// tap and fetches each with ONE 16-byte load — with one dword per pair the 4 loads per lane and pixel kept the texture-address unit
+// busy for the whole 0.41 ms of the kernel.  One pixel group (uniform pixel): dy through the scalar cache.
+template <int KK, int QPT, bool EXACT>
+__global__ void __launch_bounds__(256) wgrad_direct4_kernel(WgdArgs a) {
+    const int t = threadIdx.x;
+    const int nquads = a.npairs >> 2;
+    const int K = EXACT ? KK : a.K;
+    int coff[QPT], dh[QPT], dw[QPT];
+    bool pv[QPT];
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+        const int i = t + q * 256;
+        pv[q] = i < nquads;
+        const int j = pv[q] ? 4 * i : 0;
+        const int tap = j / a.C;
+        coff[q] = j - tap * a.C;
+        const int r = tap / a.S;
+        dh[q] = r * a.dil - a.pad_t;
+        dw[q] = (tap - r * a.S) * a.dil - a.pad_l;
+    }
+    float acc[QPT][4][KK];
+#pragma unroll
+    for (int q = 0; q < QPT; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < KK; ++k) acc[q][e][k] = 0.f;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    pnp_cfloat* dyc = (pnp_cfloat*)(uintptr_t)a.dy;
+    const int p0 = blockIdx.x * a.ppb;
+    const int p1 = (p0 + a.ppb < a.P) ? p0 + a.ppb : a.P;
+    const int OHW = a.OH * a.OW;
+    int n = p0 / OHW;
+    int rem = p0 - n * OHW;
+    int oh = rem / a.OW;
+    int ow = rem - oh * a.OW;
+    constexpr int U = 4;
+    for (int p = p0; p < p1; p += U) {
+        float dv[U][KK];
+        f32x4 xv[U][QPT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pu = p + u;
+            const bool pin = pu < p1;
+            const size_t base = (size_t)(pin ? pu : p) * K;
+#pragma unroll
+            for (int k = 0; k < KK; ++k) dv[u][k] = (k < K) ? dyc[base + k] : 0.f;
+            const int vh = oh * a.stride, vw = ow * a.stride;
+#pragma unroll
+            for (int q = 0; q < QPT; ++q) {
+                const int ih = vh + dh[q], iw = vw + dw[q];
+                const bool ok = pin & pv[q] & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+                xv[u][q] = bload4(rx, ok ? (unsigned)((((n * a.H + ih) * a.W + iw) * a.C + coff[q]) * 4) : OOB);
+            }
+            if (++ow == a.OW) {
+                ow = 0;
+                if (++oh == a.OH) { oh = 0; ++n; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < QPT; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) acc[q][e][k] = fmaf(xv[u][q][e], dv[u][k], acc[q][e][k]);
+    }
+    float* outp = a.part + (size_t)blockIdx.x * a.npairs * K;
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+        if (pv[q]) {
+            const int j = 4 * (t + q * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < KK; ++k)
+                    if (k < K) outp[(j + e) * K + k] = acc[q][e][k];
+        }
+    }
+}
+
+// many partials (one per workgroup of wgrad_direct_kernel), few outputs: 64 outputs x 16 slices of the partial list per workgroup
+__global__ void __launch_bounds__(1024) splitk_reduce_many_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
+                                                                  int nsplit) {
+    __shared__ float red[16][64];
+    const int l = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + l;
+    float s = 0.f;
+    if (e < n)
+        for (int z = sl; z < nsplit; z += 16) s += part[(size_t)z * n + e];
+    red[sl][l] = s;
+    __syncthreads();
+    if (sl == 0 && e < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tot += red[j][l];
+        out[e] = tot;
+    }
+}
+
 // split partials of one stride-phase ([nsplit][M][K] row-major) -> summed and scattered to the phase's pixels of dx
 __global__ void splitk_reduce_scatter_kernel(const float* __restrict__ part, ConvArgs a, int nsplit, size_t stride) {
     const size_t n = (size_t)a.M * a.K;
@@ -1205,13 +1438,53 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     return PNP_OK;
 }
 
+// ---- direct (vector-ALU) filter gradient for K <= 16: plan shared by the workspace query and the launch -------------------------
+struct WgdPlan { int use, nblk, ppb, G, ppt; size_t ws_bytes; };
+
+WgdPlan wgd_plan(const pnp_conv_geom* g) {
+    static const int off = getenv("PNP_CONV_NODIRECT") ? 1 : 0;
+    WgdPlan pl{};
+    const long long P = (long long)g->N * g->OH * g->OW;
+    const int npairs = g->R * g->S * g->C;
+    if (off || g->K > 16 || g->pad_mode != PNP_PAD_ZERO || npairs > 1024 || P < 8192) return pl;
+    pl.use = 1;
+    pl.ppt = npairs <= 256 ? 1 : pnp_cdiv(npairs, 256);
+    pl.G = pl.ppt == 1 ? 256 / npairs : 1;
+    if (pl.G > 16) pl.G = 16;
+    long long nblk = P / 128;
+    if (nblk > 2048) nblk = 2048;
+    pl.ppb = (int)pnp_cdiv(P, nblk);
+    pl.nblk = (int)pnp_cdiv(P, pl.ppb);
+    pl.ws_bytes = (size_t)pl.nblk * npairs * g->K * sizeof(float);
+    return pl;
+}
+
+template <int KK, bool EXACT>
+int launch_wgd(const WgdArgs& a, const WgdPlan& pl, hipStream_t st) {
+    const size_t lds = pl.G > 1 ? (size_t)pl.G * a.npairs * a.K * sizeof(float) : 0;
+    dim3 grid((unsigned)pl.nblk), blk(256);
+    const int nquads = a.npairs / 4;
+    if ((a.C % 4) == 0 && nquads >= 128 && nquads <= 512 && KK <= 8) {      // quads: one 16-byte x load per 4 pairs
+        if (nquads <= 256) hipLaunchKernelGGL((wgrad_direct4_kernel<KK, 1, EXACT>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((wgrad_direct4_kernel<KK, 2, EXACT>), grid, blk, 0, st, a);
+    } else if (pl.ppt == 1 && pl.G > 1) hipLaunchKernelGGL((wgrad_direct_kernel<KK, 1, EXACT, false>), grid, blk, lds, st, a);
+    else if (pl.ppt == 1) hipLaunchKernelGGL((wgrad_direct_kernel<KK, 1, EXACT, true>), grid, blk, lds, st, a);
+    else if (pl.ppt == 2) hipLaunchKernelGGL((wgrad_direct_kernel<KK, 2, EXACT, true>), grid, blk, lds, st, a);
+    else if (pl.ppt == 3) hipLaunchKernelGGL((wgrad_direct_kernel<KK, 3, EXACT, true>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((wgrad_direct_kernel<KK, 4, EXACT, true>), grid, blk, lds, st, a);
+    PNP_CHECK_LAUNCH("wgrad_direct_kernel");
+    return PNP_OK;
+}
+
 size_t wgrad_ws(const pnp_conv_geom* g) {
     const size_t nout = (size_t)g->R * g->S * g->C * g->K;
     const long long P = (long long)g->N * g->OH * g->OW;
     const int bn = ((g->K & 3) != 0 || g->K <= 32) ? 32 : (g->K > 64 ? 128 : 64);
     const int nblk = pnp_cdiv((long long)g->R * g->S * g->C, 128) * pnp_cdiv(g->K, bn);
     const int nsplit = wgrad_plan_split(nblk, pnp_cdiv(P, BK));
-    return nsplit <= 1 ? 0 : (size_t)nsplit * nout * sizeof(float);
+    const size_t mfma_ws = nsplit <= 1 ? 0 : (size_t)nsplit * nout * sizeof(float);
+    const WgdPlan pl = wgd_plan(g);
+    return (pl.use && pl.ws_bytes > mfma_ws) ? pl.ws_bytes : mfma_ws;
 }
 
 // ---- strided data gradient, one stride-phase at a time ---------------------------------------------------------------------
@@ -1403,6 +1676,26 @@ int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     if (!ws) workspace_bytes = 0;
+    const WgdPlan pl = wgd_plan(g);
+    if (pl.use && workspace_bytes >= pl.ws_bytes) {
+        WgdArgs d{};
+        d.x = x; d.dy = dy; d.part = ws;
+        d.N = g->N; d.H = g->H; d.W = g->W; d.C = g->C; d.K = g->K; d.R = g->R; d.S = g->S; d.OH = g->OH; d.OW = g->OW;
+        d.stride = g->stride; d.dil = g->dil; d.pad_t = g->pad_t; d.pad_l = g->pad_l;
+        d.P = a.M; d.npairs = a.Kred; d.G = pl.G; d.ppb = pl.ppb;
+        d.x_bytes = a.x_bytes; d.dy_bytes = a.w_bytes;
+        int e;
+        if (g->K == 16) e = launch_wgd<16, true>(d, pl, st);
+        else if (g->K == 5) e = launch_wgd<5, true>(d, pl, st);
+        else if (g->K <= 8) e = launch_wgd<8, false>(d, pl, st);
+        else e = launch_wgd<16, false>(d, pl, st);
+        if (e) return e;
+        const size_t nout = (size_t)a.Kred * a.K;
+        hipLaunchKernelGGL(splitk_reduce_many_kernel, dim3((unsigned)pnp_cdiv((long long)nout, 64)), dim3(1024), 0, st,
+                           (const float*)ws, dw, (int)nout, pl.nblk);
+        PNP_CHECK_LAUNCH("splitk_reduce_many_kernel");
+        return PNP_OK;
+    }
     if ((a.K & 3) != 0) return launch_wgrad_tile<128, 32, 4, 1, false>(a, dw, ws, workspace_bytes, st);
     if (a.K > 64) return launch_wgrad_tile<128, 128, 2, 2, true>(a, dw, ws, workspace_bytes, st);
     if (a.K > 32) return launch_wgrad_tile<128, 64, 2, 2, true>(a, dw, ws, workspace_bytes, st);

@@ -42,6 +42,12 @@ CASES = [
     (1, 14, 14, 32, 64, 5, 3, 1, "SAME"),       # stride 3, 5x5: phases with 2 and 1 taps per axis
     (2, 8, 8, 32, 32, 1, 2, 1, "SAME"),         # filter smaller than the stride: zero-upsampled fallback
     (2, 10, 10, 20, 24, 3, 2, 1, "SAME"),       # stride phases on the generic (C % 32 != 0) loaders
+    (2, 64, 64, 3, 16, 3, 1, 1, "SAME"),        # >= 8192 pixels, K <= 16: direct (vector-ALU) filter gradient, 27 pairs x 9 pixel groups
+    (2, 64, 64, 16, 16, 3, 1, 1, "SAME"),       # direct wgrad, 144 pairs, one group
+    (2, 68, 68, 40, 5, 5, 1, 1, "VALID"),       # direct wgrad, 1000 pairs = 4 per thread, K = 5 (the pre-padded logits conv)
+    (2, 128, 128, 5, 16, 3, 2, 1, "SAME"),      # direct wgrad with stride 2 (mask critic m_cls_1)
+    (2, 64, 64, 8, 7, 3, 1, 1, "SAME"),         # direct wgrad, K = 7 on the 8-wide instance
+    (2, 64, 64, 4, 12, 3, 1, 2, "SAME"),        # direct wgrad, K = 12 on the 16-wide instance, dilation 2
 ]
 
 
@@ -135,7 +141,8 @@ def test_conv_full_size_vs_naive_kernel(dev, shape):
 
 @pytest.mark.parametrize("shape", [
     (16, 32, 32, 512, 512, 3, 1, 1, "SAME"), (16, 32, 32, 512, 512, 3, 1, 2, "SAME"), (4, 32, 32, 512, 2560, 3, 1, 1, "SYMMETRIC"),
-    (16, 256, 256, 3, 16, 3, 1, 1, "SAME"), (16, 256, 256, 40, 5, 5, 1, 1, "SYMMETRIC"), (16, 256, 256, 64, 64, 3, 2, 1, "SAME"),
+    (16, 256, 256, 3, 16, 3, 1, 1, "SAME"), (16, 256, 256, 16, 16, 3, 1, 1, "SAME"), (16, 260, 260, 40, 5, 5, 1, 1, "VALID"),
+    (16, 256, 256, 40, 5, 5, 1, 1, "SYMMETRIC"), (16, 256, 256, 64, 64, 3, 2, 1, "SAME"),
     (16, 128, 128, 128, 128, 5, 2, 1, "SAME"), (16, 64, 64, 256, 256, 3, 2, 1, "SAME"), (16, 16, 16, 512, 512, 5, 4, 1, "SAME"),
     (16, 4, 4, 512, 512, 3, 2, 1, "SYMMETRIC")])
 def test_conv_full_size_adjoint_identities(dev, shape):
