@@ -99,6 +99,7 @@ class GradReducer(object):
         self.buckets = []       # (start, end) element ranges of the arena, in reverse variable order
         self._pending = []      # outstanding work handles
         self._remaining = []
+        self._members = []      # variables of each bucket
         self._var_bucket = {}
         tr = store.trainable()
         # buckets: walk variables from the LAST created (first gradient to be ready) to the first
@@ -129,6 +130,7 @@ class GradReducer(object):
     def _close(self, start, end, members):
         b = len(self.buckets)
         self.buckets.append((start, end))
+        self._members.append(list(members))
         for v in members:
             self._var_bucket[v.name] = b
         self._remaining.append(len(members))
@@ -164,10 +166,15 @@ class GradReducer(object):
         if self.world <= 1:
             return
         if self.overlap:
-            for b in range(len(self.buckets)):      # variables without a gradient this step (frozen / unused)
-                if not self._launched[b]:
+            # buckets whose hook count did not reach zero: some member had no gradient this step.  A bucket none of whose
+            # variables is being trained in this step (the GAN steps switch requires_grad per variable group: a dis step only
+            # produces the 91 MB of critic gradients, a gen step the 20 MB of adapt_*) is skipped — identically on every rank.
+            for b in range(len(self.buckets)):
+                if not self._launched[b] and any(v.tensor.requires_grad for v in self._members[b]):
                     self._launch(b)
             torch.cuda.current_stream().wait_stream(self.side)
             self.reset()
         else:
-            dist.all_reduce(self.store.grad_arena, op=dist.ReduceOp.SUM, group=self.group)
+            for b, (s, e) in enumerate(self.buckets):
+                if any(v.tensor.requires_grad for v in self._members[b]):
+                    dist.all_reduce(self.store.grad_arena[s:e], op=dist.ReduceOp.SUM, group=self.group)

@@ -181,6 +181,17 @@ red.allreduce()
 exp = sum(r + 1 for r in range(world))
 assert torch.all(net.store.grad_arena[7:] == exp)
 assert torch.equal(net.store.grad_arena[:7], torch.arange(7, dtype=torch.float32) * exp)
+# variable groups switched off for a step (GAN dis / gen steps): buckets without a trained variable are not reduced
+keep = red._members[0]
+for v in net.store.trainable():
+    v.tensor.requires_grad_(any(v is k for k in keep))
+net.store.grad_arena.fill_(float(rank + 1))
+red.allreduce()
+s0, e0 = red.buckets[0]
+assert torch.all(net.store.grad_arena[s0:e0] == exp)
+mask = torch.ones_like(net.store.grad_arena, dtype=torch.bool)
+mask[s0:e0] = False
+assert torch.all(net.store.grad_arena[mask] == float(rank + 1))
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
