@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--workload", choices=["segmenter", "gan"], default="segmenter",
+                    help="segmenter: BASELINE configs[1] (the default, the headline line); gan: configs[3] joint step = 1 dis + clip + 1 gen")
     args = ap.parse_args()
 
     par = importlib.import_module(PKG + ".parallel")
@@ -160,21 +162,52 @@ def main():
     ss = importlib.import_module(PKG + ".source_segmenter")
     K = importlib.import_module(PKG + ".kernels")
     B = args.batch
-    net = ss.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, cost_kwargs=dict(COST), seed=0, world_size=world)
-    # He-scaled weights (the reference's stddev=.01 init gives vanishing activations after 30 layers; either is "random init")
-    sd = net.store.state_dict()
-    for k in sd:
-        if "/Variable" in k:
-            s = sd[k].shape
-            sd[k] = (sd[k] * (np.sqrt(2.0 / (s[0] * s[1] * s[2])) / 0.01)).astype(np.float32)
-    net.store.load_state_dict(sd)
-    reducer = par.GradReducer(net.store, overlap=not args.no_overlap) if world > 1 else None
-    tr = ss.Trainer(net, None, None, num_cls=5, batch_size=B, optimizer="adam", opt_kwargs={"learning_rate": 1e-3}, reducer=reducer)
-    tr.opt = tr._get_optimizer(10)
-
     rng = np.random.default_rng(100 + rank)
     x = torch.from_numpy(rng.standard_normal((B, 256, 256, 3)).astype(np.float32)).to(dev)
-    y = torch.from_numpy(one_hot(blob_labels(rng, B))).to(dev)
+
+    def he_scale(net):
+        # He-scaled weights (the reference's stddev=.01 init gives vanishing activations after 30 layers; either is "random init")
+        sd = net.store.state_dict()
+        wr = np.random.default_rng(7)
+        for k in sd:
+            if "Variable" in k:
+                s = sd[k].shape
+                if len(s) == 4 and "cls" not in k:      # segmenter conv filters: rescale the truncated-normal(0.01) init
+                    sd[k] = (sd[k] * (np.sqrt(2.0 / (s[0] * s[1] * s[2])) / 0.01)).astype(np.float32)
+                else:                                   # critic convs / FC (stddev 0.1 shared variables): fresh He-normal draw
+                    sd[k] = (wr.standard_normal(s) * np.sqrt(2.0 / np.prod(s[:-1]))).astype(np.float32)
+        net.store.load_state_dict(sd)
+
+    if args.workload == "segmenter":
+        net = ss.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, cost_kwargs=dict(COST), seed=0, world_size=world)
+        he_scale(net)
+        reducer = par.GradReducer(net.store, overlap=not args.no_overlap) if world > 1 else None
+        tr = ss.Trainer(net, None, None, num_cls=5, batch_size=B, optimizer="adam", opt_kwargs={"learning_rate": 1e-3}, reducer=reducer)
+        tr.opt = tr._get_optimizer(10)
+        y = torch.from_numpy(one_hot(blob_labels(rng, B))).to(dev)
+
+        def train_step(i):
+            return tr.train_step(x, y, 0.75, i * world + rank)
+        metric = "training slices/sec (256x256x3, B=16 per GPU) segmenter train step (fwd+bwd+Adam)"
+        workload = "BASELINE configs[1]: source segmenter fwd+bwd+Adam, B=%d/GPU, 256x256x3, fp32, dropout .75, BN train" % B
+    else:
+        adv = importlib.import_module(PKG + ".adversarial")
+        net = adv.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, seed=0, world_size=world,
+                           cost_kwargs={"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.3},
+                           network_config={"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True,
+                                           "cls_trainable": True, "m_cls_trainable": True})
+        he_scale(net)
+        reducer = par.GradReducer(net.store, overlap=not args.no_overlap) if world > 1 else None
+        tr = adv.Trainer(net, None, None, None, None, num_cls=5, batch_size=B, opt_kwargs={"learning_rate": 3e-4},
+                         train_config={"dis_sub_iter": 1, "gen_sub_iter": 1}, reducer=reducer)
+        tr._get_optimizer()
+        ct = torch.from_numpy((rng.standard_normal((B, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32)).to(dev)
+
+        def train_step(i):
+            tr.dis_step(x, ct, 0.75, 2 * (i * world + rank) + 1)
+            return tr.gen_step(ct, 0.75, 2 * (i * world + rank) + 2)
+        metric = "training slices/sec (256x256x3, B=16 per GPU) joint segmenter+GAN step (1 dis update on B MR + B CT, clip, 1 gen update on B CT)"
+        workload = "BASELINE configs[3]: train_gan.py --phase train-gan joint step, B=%d/GPU of each domain, fp32, dropout .75, mask critic on" % B
 
     probe = ConvFwdProbe(K)
     if not args.no_probe:
@@ -187,13 +220,13 @@ def main():
 
     step = 0
     for _ in range(args.warmup):
-        tr.train_step(x, y, 0.75, step * world + rank)
+        train_step(step)
         step += 1
     barrier()
     probe.enabled = not args.no_probe
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tr.train_step(x, y, 0.75, step * world + rank)
+        loss = train_step(step)
         step += 1
     barrier()
     el = time.perf_counter() - t0
@@ -207,11 +240,11 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "training slices/sec (256x256x3, B=16 per GPU) segmenter train step (fwd+bwd+Adam)",
+            "metric": metric,
             "value": world * B * args.steps / el, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: source segmenter fwd+bwd+Adam, B=%d/GPU, 256x256x3, fp32, dropout .75, BN train" % B,
+            "config": {"workload": workload,
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": lossv},
         }
         if not args.no_probe:
@@ -229,7 +262,7 @@ def main():
             if n2:
                 res["roofline_small_convs"] = {"launches": n2, "avg_launch_ms": ms2 / n2, "achieved_tflops": fl2 / (ms2 * 1e-3) / 1e12,
                                                "algorithmic_GBps": by2 / (ms2 * 1e-3) / 1e9}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "segmenter":     # the oracle sample is the segmenter step
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
     if world > 1:

@@ -34,6 +34,15 @@ def test_bench_two_rank_launch_line(dev):
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["scaling"] == "weak" and r["value"] > 0
 
 
+def test_bench_two_rank_gan_workload(dev):
+    """config 4 launch line: joint dis + gen step, 2 ranks, gradient buckets of the frozen groups skipped"""
+    p = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--workload", "gan"],
+             {"PNP_DIST_BACKEND": "gloo", "PNP_SAME_DEVICE": "1"})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and "joint" in r["metric"] and r["value"] > 0 and "cpu_baseline" not in r
+
+
 def test_train_segmenter_two_ranks(dev, tmp_path):
     """the entry point itself under torch.distributed.run: sharded file lists, per-rank feeders, overlapped reduction, rank-0 checkpoint"""
     out = str(tmp_path / "seg_dp")
