@@ -179,8 +179,9 @@ __global__ void __launch_bounds__(1024) colreduce_final_kernel(const float* __re
 
 int colreduce_plan(long long P, int C, int* nblk, int* rpb) {
     // ~2048 blocks max, at least 64 rows per block
+    static const int cap = getenv("PNP_BN_NBLK") ? atoi(getenv("PNP_BN_NBLK")) : 2048;
     long long b = (P + 63) / 64;
-    if (b > 2048) b = 2048;
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     long long r = (P + b - 1) / b;
     b = (P + r - 1) / r;
