@@ -58,6 +58,14 @@ typedef struct pnp_conv_geom {
 /* replaces tf.nn.conv2d (layers.py:18,24,67,73) and tf.nn.atrous_conv2d (layers.py:86,92) + tf.nn.dropout */
 int pnp_conv2d_fwd(const float* x, const float* w, float* y, const pnp_conv_geom* g,
                    float keep_prob, uint64_t seed, uint32_t stream_id, void* stream);
+/* Same with a workspace: layers with few output pixels (the critics' 4x4 / 2x2 maps, small batches) leave most of the 256 CUs
+ * without a tile; given pnp_conv2d_fwd_workspace_bytes(g) bytes the reduction over R*S*C is split across workgroups and the
+ * partial sums (fixed order: deterministic) pass through the workspace; dropout is then applied by the summing kernel.
+ * workspace may be NULL / 0 bytes (== pnp_conv2d_fwd). */
+size_t pnp_conv2d_fwd_workspace_bytes(const pnp_conv_geom* g);
+int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_geom* g,
+                      float keep_prob, uint64_t seed, uint32_t stream_id,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* gradient w.r.t. the conv input (TF autodiff of the ops above; Conv2DBackpropInput).
  * dy is the gradient w.r.t. the conv accumulator (i.e. AFTER the dropout mask has been applied by the caller).

@@ -1067,6 +1067,19 @@ __global__ void __launch_bounds__(256) wgrad_direct4_kernel(WgdArgs a) {
     }
 }
 
+// forward conv with a split reduction: sum the partials, then the dropout of the fused conv->dropout (same element-index hash as the
+// un-split epilogue)
+__global__ void splitk_reduce_drop_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nsplit, size_t stride,
+                                          uint32_t drop_key, uint32_t drop_thresh, float drop_scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gs = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += gs) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * stride + i];
+        out[i] = pnp_drop_keep((uint32_t)i, drop_key, drop_thresh) ? s * drop_scale : 0.f;
+    }
+}
+
 // many partials (one per workgroup of wgrad_direct_kernel), few outputs: 64 outputs x 16 slices of the partial list per workgroup
 __global__ void __launch_bounds__(1024) splitk_reduce_many_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
                                                                   int nsplit) {
@@ -1292,7 +1305,8 @@ int choose_split(long long M, int K, int Kred, int tile) {
     int nsplit = 1;
     if (rounds <= 0.5) nsplit = (int)(512 / nblk);
     else if (rounds < 3.0 && (ceil(rounds) - rounds) > 0.3) nsplit = 2;
-    if (nsplit > 4) nsplit = 4;
+    const int cap = nblk <= 64 ? 32 : 4;        // a handful of tiles (4x4 / 2x2 feature maps, M = 256 rows): split deeper
+    if (nsplit > cap) nsplit = cap;
     if (nsplit > nch / 8) nsplit = nch / 8;
     return nsplit < 1 ? 1 : nsplit;
 }
@@ -1341,7 +1355,8 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
     a.nsplit = nsplit;
     a.split_stride = (long long)a.M * a.K;
     float* final_out = a.y;
-    if (nsplit > 1) a.y = split_ws;
+    const int drop_in_reduce = (nsplit > 1) ? a.do_drop : 0;
+    if (nsplit > 1) { a.y = split_ws; a.do_drop = 0; }
     dim3 grid((unsigned)(a.nblk_m * a.nblk_n * nsplit));
     const int mode = (a.C % 32 == 0) ? 0 : ((a.C % 4 == 0) ? 1 : 2);
     if constexpr (VECB && KIND != 2) {
@@ -1362,7 +1377,10 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
         const size_t nout = (size_t)a.M * a.K;
         int nb = pnp_cdiv((long long)nout, 256);
         if (nb > 4096) nb = 4096;
-        if (a.o_s != 0) {
+        if (drop_in_reduce) {
+            hipLaunchKernelGGL(splitk_reduce_drop_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, final_out, nout, nsplit, nout,
+                               a.drop_key, a.drop_thresh, a.drop_scale);
+        } else if (a.o_s != 0) {
             ConvArgs ar = a;
             ar.y = final_out;
             hipLaunchKernelGGL(splitk_reduce_scatter_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, ar, nsplit, nout);
@@ -1543,8 +1561,20 @@ pnp_conv_geom phase_geom(const pnp_conv_geom* g, const DgradPhase& p) {
 
 extern "C" {
 
+size_t pnp_conv2d_fwd_workspace_bytes(const pnp_conv_geom* g) {
+    if (!g || g->pad_mode != PNP_PAD_ZERO) return 0;
+    const long long M = (long long)g->N * g->OH * g->OW;
+    const int ns = choose_split(M, g->K, g->R * g->S * g->C, choose_tile(M, g->K));
+    return ns > 1 ? (size_t)ns * M * g->K * sizeof(float) : 0;
+}
+
 int pnp_conv2d_fwd(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
                    uint32_t stream_id, void* stream) {
+    return pnp_conv2d_fwd_ws(x, w, y, g, keep_prob, seed, stream_id, nullptr, 0, stream);
+}
+
+int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
+                      uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream) {
     if (int e = check_geom(g, "pnp_conv2d_fwd")) return e;
     PNP_REQUIRE(x && w && y, "pnp_conv2d_fwd: null pointer");
     PNP_REQUIRE(keep_prob > 0.f, "pnp_conv2d_fwd: keep_prob must be > 0");
@@ -1555,7 +1585,9 @@ int pnp_conv2d_fwd(const float* x, const float* w, float* y, const pnp_conv_geom
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
     }
-    return launch_fwd<0>(a, (hipStream_t)stream);
+    float* split_ws = (workspace && workspace_bytes >= pnp_conv2d_fwd_workspace_bytes(g) && pnp_conv2d_fwd_workspace_bytes(g) > 0)
+                          ? (float*)workspace : nullptr;
+    return launch_fwd<0>(a, (hipStream_t)stream, split_ws);
 }
 
 int pnp_conv2d_fwd_naive(const float* x, const float* w, float* y, const pnp_conv_geom* g, void* stream) {

@@ -83,8 +83,11 @@ def conv2d_fwd(x, w, g, keep_prob=1.0, seed=0, stream_id=0, out=None, naive=Fals
     if naive:
         check(lib.pnp_conv2d_fwd_naive(_p(x), _p(w), _p(y), ctypes.byref(g), _stream()), "pnp_conv2d_fwd_naive")
     else:
-        check(lib.pnp_conv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _stream()),
-              "pnp_conv2d_fwd")
+        nbytes = lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))      # > 0 only for layers with too few output tiles
+        ws = workspace(nbytes, x.device) if nbytes else None
+        check(lib.pnp_conv2d_fwd_ws(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id),
+                                    ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
+                                    _stream()), "pnp_conv2d_fwd")
     return y
 
 

@@ -102,9 +102,12 @@ def test_conv_transpose_detecting(dev):
     assert np.abs(y - ref).max() < 1e-3 * np.abs(ref).max()
 
 
-def test_dropout_epilogue_matches_oracle_mask(dev):
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 64, 3, 1, 1, "SAME"),
+                                  (2, 8, 8, 512, 512, 3, 1, 1, "SAME"),      # 8 tiles: reduction split 18 ways, dropout in the summing kernel
+                                  (2, 16, 16, 512, 512, 5, 4, 1, "SAME")])   # critic k5 s4 -> 4x4 map
+def test_dropout_epilogue_matches_oracle_mask(dev, case):
     K = pkg("kernels")
-    x, w, stride, dil, padding = _mk((2, 16, 16, 32, 64, 3, 1, 1, "SAME"))
+    x, w, stride, dil, padding = _mk(case)
     g = K.conv_geom(x.shape, w.shape, stride, dil, padding)
     xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
     y0 = K.conv2d_fwd(xd, wd, g).cpu()
@@ -113,7 +116,7 @@ def test_dropout_epilogue_matches_oracle_mask(dev):
     ref = y0 * torch.from_numpy(mask) * np.float32(1.0 / np.float32(0.75))
     assert torch.equal(y1 != 0, (torch.from_numpy(mask) != 0) & (y0 != 0))
     assert _rel(y1, ref) < 1e-6
-    assert abs(mask.mean() - 0.75) < 0.01
+    assert abs(mask.mean() - 0.75) < (0.01 if mask.size > 100000 else 0.03)
     # the standalone dropout kernel (used in backward) draws the same stream
     y2 = K.dropout(xd.new_tensor(y0.numpy()), 0.75, 1234567, 5).cpu()
     assert _rel(y2, ref) < 1e-6
