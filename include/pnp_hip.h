@@ -67,6 +67,17 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
                       float keep_prob, uint64_t seed, uint32_t stream_id,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Inference-mode conv -> dropout -> batch norm -> (+ shortcut) -> leaky-ReLU in ONE kernel (the monitoring forwards of
+ * source_segmenter.py:525-570 / adversarial.py:948-991, every frozen-BN forward of the GAN steps, Trainer.test_eval):
+ *   y = act( drop(conv(x,w)) * scale[k] + shift[k] + pad_channels(shortcut) ),  scale / shift from pnp_bn_fold.
+ * shortcut [N*OH*OW, Cs] is zero-padded (K-Cs)/2 channels on each side (layers.py:159-165); alpha < 0: no activation. */
+int pnp_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float* scale, float* shift,
+                int32_t C, float eps, void* stream);
+int pnp_conv2d_fwd_bn(const float* x, const float* w, float* y, const pnp_conv_geom* g,
+                      float keep_prob, uint64_t seed, uint32_t stream_id,
+                      const float* scale, const float* shift, const float* shortcut /*nullable*/, int32_t Cs, float alpha,
+                      void* stream);
+
 /* gradient w.r.t. the conv input (TF autodiff of the ops above; Conv2DBackpropInput).
  * dy is the gradient w.r.t. the conv accumulator (i.e. AFTER the dropout mask has been applied by the caller).
  * workspace: pnp_conv2d_dgrad_workspace_bytes(g). */

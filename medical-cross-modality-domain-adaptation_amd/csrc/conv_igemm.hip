@@ -59,7 +59,23 @@ struct ConvArgs {
     // output scatter of one stride-phase of a strided data gradient (o_s = 0: plain [M][K] rows): GEMM row (n, i, j) is the
     // image pixel (n, o_h0 + i*o_s, o_w0 + j*o_s) of an o_H x o_W image
     int o_s, o_H, o_W, o_h0, o_w0;
+    // fused inference-mode batch norm (+ shortcut + leaky-ReLU) behind the convolution (monitoring / frozen-BN forwards):
+    //   y = act( drop(acc) * ep_scale[k] + ep_shift[k] + pad_channels(ep_res) ),  act(v) = v > 0 ? v : ep_alpha * v  (ep_alpha < 0: none)
+    const float* ep_scale;
+    const float* ep_shift;
+    const float* ep_res;        // [M][ep_cs] or null
+    int ep_cs;                   // shortcut channels, zero-padded (K - ep_cs)/2 on each side
+    float ep_alpha;
 };
+
+__device__ __forceinline__ float bn_epilogue(const ConvArgs& a, float v, int m, int n) {
+    v = fmaf(v, a.ep_scale[n], a.ep_shift[n]);
+    if (a.ep_res) {
+        const int cs = n - ((a.K - a.ep_cs) >> 1);
+        if ((unsigned)cs < (unsigned)a.ep_cs) v += a.ep_res[(size_t)m * a.ep_cs + cs];
+    }
+    return (a.ep_alpha >= 0.f && v < 0.f) ? v * a.ep_alpha : v;
+}
 
 __device__ __forceinline__ size_t out_row(const ConvArgs& a, int m, bool scatter) {
     if (!scatter) return (size_t)m * a.K;
@@ -566,6 +582,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
                     float v = acc.v[tm][tn][r];
                     const size_t idx = (size_t)m * a.K + n;
                     if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                    if (a.ep_scale) v = bn_epilogue(a, v, m, n);
                     yout[out_row(a, m, scatter) + n] = v;
                 }
             }
@@ -735,6 +752,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
                     float v = acc.v[tm][tn][r];
                     const size_t idx = (size_t)m * a.K + n;
                     if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                    if (a.ep_scale) v = bn_epilogue(a, v, m, n);
                     yout[out_row(a, m, scatter) + n] = v;
                 }
             }
@@ -1078,6 +1096,16 @@ __global__ void splitk_reduce_drop_kernel(const float* __restrict__ part, float*
         for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * stride + i];
         out[i] = pnp_drop_keep((uint32_t)i, drop_key, drop_thresh) ? s * drop_scale : 0.f;
     }
+}
+
+// inference-mode batch norm as one multiply-add per channel: scale = gamma * rsqrt(var + eps), shift = beta - mean * scale
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                               const float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * (1.0f / sqrtf(var[c] + eps));
+    scale[c] = sc;
+    shift[c] = beta[c] - mean[c] * sc;
 }
 
 // many partials (one per workgroup of wgrad_direct_kernel), few outputs: 64 outputs x 16 slices of the partial list per workgroup
@@ -1588,6 +1616,33 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
     float* split_ws = (workspace && workspace_bytes >= pnp_conv2d_fwd_workspace_bytes(g) && pnp_conv2d_fwd_workspace_bytes(g) > 0)
                           ? (float*)workspace : nullptr;
     return launch_fwd<0>(a, (hipStream_t)stream, split_ws);
+}
+
+int pnp_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float* scale, float* shift, int32_t C,
+                float eps, void* stream) {
+    PNP_REQUIRE(gamma && beta && mean && var && scale && shift && C > 0, "pnp_bn_fold: bad argument");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)pnp_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, scale,
+                       shift, C, eps);
+    PNP_CHECK_LAUNCH("bn_fold_kernel");
+    return PNP_OK;
+}
+
+int pnp_conv2d_fwd_bn(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
+                      uint32_t stream_id, const float* scale, const float* shift, const float* shortcut, int32_t Cs, float alpha,
+                      void* stream) {
+    if (int e = check_geom(g, "pnp_conv2d_fwd_bn")) return e;
+    PNP_REQUIRE(x && w && y && scale && shift, "pnp_conv2d_fwd_bn: null pointer");
+    PNP_REQUIRE(keep_prob > 0.f, "pnp_conv2d_fwd_bn: keep_prob must be > 0");
+    if (shortcut) PNP_REQUIRE(Cs > 0 && Cs <= g->K && ((g->K - Cs) % 2) == 0, "pnp_conv2d_fwd_bn: bad shortcut channels");
+    ConvArgs a = make_args(x, w, y, g);
+    if (keep_prob < 1.f) {
+        a.do_drop = 1;
+        a.drop_scale = 1.f / keep_prob;
+        a.drop_key = pnp_drop_key(seed, stream_id);
+        a.drop_thresh = pnp_drop_thresh(keep_prob);
+    }
+    a.ep_scale = scale; a.ep_shift = shift; a.ep_res = shortcut; a.ep_cs = shortcut ? Cs : g->K; a.ep_alpha = alpha;
+    return launch_fwd<0>(a, (hipStream_t)stream);      // no workspace: the reduction is never split on this path
 }
 
 int pnp_conv2d_fwd_naive(const float* x, const float* w, float* y, const pnp_conv_geom* g, void* stream) {

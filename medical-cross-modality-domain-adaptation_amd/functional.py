@@ -7,6 +7,7 @@ Fused units (what TF-1.4 lowers layers.py's chains to, restated as one forward +
                     (layers.py:9-45 and the tails of residual_block / DR_block, 145-189)
   MaxPool2Fn, PSFn, SegLossFn, CriticInputFn
 """
+import os
 import torch
 from torch.autograd import Function
 
@@ -16,6 +17,9 @@ from . import parallel as par
 BN_EPS = 1e-3      # tf.contrib.layers.batch_norm default epsilon (layers.py:100 does not override it)
 BN_DECAY = 0.90    # layers.py:100
 LEAK = 0.2         # tf.nn.leaky_relu default alpha (layers.py:12,35,166,187)
+# inference-mode conv -> dropout -> BN -> shortcut -> activation in one kernel (pnp_conv2d_fwd_bn) whenever the BN parameters take no
+# gradient (monitoring forwards, frozen-BN forwards of the GAN steps, volume inference); False: separate kernels
+FUSE_BN_INFER = os.environ.get("PNP_FUSE_BN_INFER", "1") != "0"
 
 
 def _contig(t):
@@ -61,6 +65,18 @@ class ConvBNActFn(Function):
     def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, shortcut, geom, keep_prob, seed, stream_id, is_train, alpha):
         x = _contig(x)
         w_ = _contig(w)
+        sc = _contig(shortcut) if shortcut is not None else None
+        ctx.geom, ctx.keep, ctx.seed, ctx.sid = geom, keep_prob, seed, stream_id
+        ctx.is_train, ctx.alpha = is_train, alpha
+        ctx.sc_channels = sc.shape[-1] if sc is not None else 0
+        ctx.fused = (not is_train) and FUSE_BN_INFER and not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        if ctx.fused:
+            # inference statistics; snapshot only if a backward pass will read them after the moving averages may have moved
+            mean, var = (moving_mean.clone(), moving_var.clone()) if any(ctx.needs_input_grad) else (moving_mean, moving_var)
+            out = K.conv2d_fwd_bn(x, w_, geom, K.bn_fold(gamma, beta, mean, var, BN_EPS), sc, alpha, keep_prob, seed, stream_id)
+            ctx.P_norm = out.numel() // out.shape[-1]
+            ctx.save_for_backward(x, w_, out, out, mean, var, gamma)     # the pre-BN tensor is never read in inference mode
+            return out
         xc = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
         P = xc.numel() // xc.shape[-1]
         ctx.P_norm = P
@@ -71,14 +87,9 @@ class ConvBNActFn(Function):
                 ctx.P_norm = P * par.sync_world()
             K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
         else:
-            # inference statistics; snapshot only if a backward pass will read them after the moving averages may have moved
             mean, var = (moving_mean.clone(), moving_var.clone()) if any(ctx.needs_input_grad) else (moving_mean, moving_var)
-        sc = _contig(shortcut) if shortcut is not None else None
         out = K.bn_apply(xc, mean, var, gamma, beta, sc, BN_EPS, alpha)
         ctx.save_for_backward(x, w_, xc, out, mean, var, gamma)
-        ctx.geom, ctx.keep, ctx.seed, ctx.sid = geom, keep_prob, seed, stream_id
-        ctx.is_train, ctx.alpha = is_train, alpha
-        ctx.sc_channels = sc.shape[-1] if sc is not None else 0
         return out
 
     @staticmethod
@@ -86,7 +97,12 @@ class ConvBNActFn(Function):
         x, w, xc, out, mean, var, gamma = ctx.saved_tensors
         dout = _contig(dout)
         need_sc = ctx.sc_channels if ctx.needs_input_grad[6] else 0
-        dxc, dgamma, dbeta, dsc = _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, ctx.keep, ctx.seed, ctx.sid)
+        if ctx.fused:
+            dxc, dsc = K.bn_bwd_apply(dout, out, out, mean, var, gamma, None, ctx.P_norm, need_sc, BN_EPS, ctx.alpha, False, ctx.keep,
+                                      ctx.seed, ctx.sid)
+            dgamma = dbeta = None
+        else:
+            dxc, dgamma, dbeta, dsc = _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, ctx.keep, ctx.seed, ctx.sid)
         dx = K.conv2d_dgrad(dxc, w, ctx.geom) if ctx.needs_input_grad[0] else None
         dw = K.conv2d_wgrad(x, dxc, ctx.geom) if ctx.needs_input_grad[1] else None
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, None, None,

@@ -91,6 +91,25 @@ def conv2d_fwd(x, w, g, keep_prob=1.0, seed=0, stream_id=0, out=None, naive=Fals
     return y
 
 
+def bn_fold(gamma, beta, mean, var, eps=1e-3):
+    """inference-mode BN as per-channel (scale, shift)"""
+    lib = _lib.load()
+    C = gamma.numel()
+    ss = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
+    check(lib.pnp_bn_fold(_p(gamma), _p(beta), _p(mean), _p(var), _p(ss[0]), _p(ss[1]), C, float(eps), _stream()), "pnp_bn_fold")
+    return ss
+
+
+def conv2d_fwd_bn(x, w, g, scale_shift, shortcut=None, alpha=0.2, keep_prob=1.0, seed=0, stream_id=0):
+    """conv -> dropout -> inference BN -> (+ shortcut) -> leaky-ReLU in one launch (pnp_conv2d_fwd_bn)"""
+    lib = _lib.load()
+    y = torch.empty((g.N, g.OH, g.OW, g.K), dtype=torch.float32, device=x.device)
+    cs = shortcut.shape[-1] if shortcut is not None else 0
+    check(lib.pnp_conv2d_fwd_bn(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _p(scale_shift[0]),
+                                _p(scale_shift[1]), _p(shortcut), cs, float(alpha), _stream()), "pnp_conv2d_fwd_bn")
+    return y
+
+
 def conv2d_dgrad(dy, w, g):
     lib = _lib.load()
     dx = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dy.device)
@@ -188,7 +207,8 @@ def bn_bwd_apply(dout, out, x, mean, var, gamma, sums, P_norm, shortcut_channels
     dsc = None
     if shortcut_channels:
         dsc = torch.empty(x.shape[:-1] + (shortcut_channels,), dtype=torch.float32, device=x.device)
-    check(lib.pnp_bn_bwd_apply(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(sums[0]), _p(sums[1]), _p(dx), _p(dsc),
+    dg, db = (sums[0], sums[1]) if sums is not None else (None, None)      # not read in inference mode
+    check(lib.pnp_bn_bwd_apply(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(dg), _p(db), _p(dx), _p(dsc),
                                shortcut_channels, P, int(P_norm), C, float(eps), float(alpha), 1 if training else 0, float(keep_prob),
                                int(seed), int(stream_id), _stream()), "pnp_bn_bwd_apply")
     return dx, dsc

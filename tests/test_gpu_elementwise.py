@@ -136,3 +136,42 @@ def test_critic_input(dev):
     grads = K.critic_input_bwd(torch.from_numpy(g).to(dev), tuple(tuple(t.shape) for t in ts), 3)
     for got, t in zip(grads, ts):
         assert _rel(got, t.grad) < 1e-6
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 64, 3, 1, 1, True, 0.75, 0.2), (2, 16, 16, 64, 64, 3, 1, 2, True, 1.0, 0.2),
+                                  (2, 16, 16, 20, 24, 3, 2, 1, False, 0.75, -1.0), (1, 8, 8, 512, 512, 3, 1, 1, True, 1.0, 0.2)])
+def test_fused_conv_bn_inference_equals_separate_kernels(dev, case):
+    """conv -> dropout -> inference BN -> (+ channel-padded shortcut) -> leaky-ReLU in ONE kernel (pnp_conv2d_fwd_bn)
+    against the same chain on separate kernels (pnp_conv2d_fwd, pnp_bn_apply), forward and the gradients reaching x, w, shortcut."""
+    N, H, W, C, Kc, R, stride, dil, with_sc, keep, alpha = case
+    F, K = pkg("functional"), pkg("kernels")
+    rng = np.random.default_rng(5)
+    g = K.conv_geom((N, H, W, C), (R, R, C, Kc), stride, dil, "SAME")
+    mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev)
+    x0, w0 = mk(N, H, W, C), mk(R, R, C, Kc) * float(1.0 / np.sqrt(R * R * C))
+    gamma, beta, mm = 1.0 + 0.1 * mk(Kc), 0.1 * mk(Kc), 0.2 * mk(Kc)
+    mv = 0.5 + torch.from_numpy(rng.random(Kc).astype(np.float32)).to(dev)
+    sc0 = mk(N, g.OH, g.OW, Kc // 2 if Kc % 4 == 0 else Kc) if with_sc else None       # Kc/2 channels: zero-padded Kc/4 each side
+    dout = mk(N, g.OH, g.OW, Kc)
+    res = {}
+    for fused in (True, False):
+        F.FUSE_BN_INFER = fused
+        x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        sc = sc0.clone().requires_grad_(True) if with_sc else None
+        mm1, mv1 = mm.clone(), mv.clone()
+        out = F.ConvBNActFn.apply(x, w, gamma, beta, mm1, mv1, sc, g, keep, 77, 3, False, alpha)
+        out.backward(dout)
+        assert torch.equal(mm1, mm) and torch.equal(mv1, mv)                        # inference mode: moving statistics untouched
+        res[fused] = (out.detach(), x.grad, w.grad, sc.grad if with_sc else None)
+    F.FUSE_BN_INFER = True
+    names = ("out", "dx", "dw", "dshortcut")
+    for a, b, nme in zip(res[True], res[False], names):
+        if a is None:
+            continue
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        assert err < 1e-5, (nme, err)      # fused = one fp32 FMA per element more/less; the small-map case also differs in the reduction split
+    # with trainable BN parameters the fused route must not be taken (their gradients need the pre-BN tensor)
+    gam = gamma.clone().requires_grad_(True)
+    out = F.ConvBNActFn.apply(x0, w0, gam, beta, mm.clone(), mv.clone(), None, g, 1.0, 0, 0, False, alpha)
+    out.backward(dout)
+    assert gam.grad is not None and float(gam.grad.abs().max()) > 0
