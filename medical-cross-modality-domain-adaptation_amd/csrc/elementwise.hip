@@ -485,6 +485,67 @@ __global__ void __launch_bounds__(NT) ps_kernel(const float* __restrict__ src, f
     }
 }
 
+// LDS-transposing version: the permutation is contiguous in the COARSE layout per pixel (all nc*r*r channels) and in the FINE layout per
+// (pixel row u: r*nc floats, and consecutive coarse pixels jj continue the same fine row), but a thread-per-element copy is 4-byte
+// scattered on one side (173 / 262 us for the 168 MB of g10's output at B=16, 2-4x the HBM time).  A workgroup takes T coarse pixels of
+// one row (T*Cin <= 4096 floats), moves them through LDS and is coalesced on both sides.  LDS slot of coarse element x: x + x/64 — the
+// fine order walks channels first (stride r*r = 64 floats in x), 65 makes that walk conflict-free.
+template <bool BWD>
+__global__ void __launch_bounds__(NT) ps_tile_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int A, int B, int r,
+                                                     int nc, int T) {
+    __shared__ float tile[4096 + 64];
+    const int t = threadIdx.x;
+    const int rr = r * r, Cin = nc * rr, X = T * Cin, rn = r * nc, run = T * rn;
+    const int bpr = B / T;
+    int b = blockIdx.x;
+    const int jb = b % bpr;
+    b /= bpr;
+    const int ii = b % A, n = b / A;
+    const int jj0 = jb * T;
+    const size_t base_c = (((size_t)n * A + ii) * B + jj0) * Cin;
+    const size_t fine0 = (((size_t)n * A * r + (size_t)ii * r) * (size_t)(B * r) + (size_t)jj0 * r) * nc;
+    const size_t row_stride = (size_t)(B * r) * nc;
+    const float inv_run = 1.0f / (float)run, inv_rn = 1.0f / (float)rn, inv_nc = 1.0f / (float)nc;
+    // exact for these small integers: (f + 0.5) / d is at least 0.5/d away from an integer
+    auto fdiv = [](int f, float inv) { return (int)(((float)f + 0.5f) * inv); };
+    auto decode = [&](int f, int& u, int& rem) {      // fine-order index -> coarse-order index x
+        u = fdiv(f, inv_run);
+        rem = f - u * run;
+        const int tj = fdiv(rem, inv_rn);
+        const int q = rem - tj * rn;
+        const int v = fdiv(q, inv_nc);
+        const int c = q - v * nc;
+        return tj * Cin + c * rr + v * r + u;
+    };
+    if constexpr (!BWD) {
+        for (int x = t; x < X; x += NT) tile[x + (x >> 6)] = src[base_c + x];
+        __syncthreads();
+        for (int f = t; f < X; f += NT) {
+            int u, rem;
+            const int x = decode(f, u, rem);
+            dst[fine0 + (size_t)u * row_stride + rem] = tile[x + (x >> 6)];
+        }
+    } else {
+        for (int f = t; f < X; f += NT) {
+            int u, rem;
+            const int x = decode(f, u, rem);
+            tile[x + (x >> 6)] = src[fine0 + (size_t)u * row_stride + rem];
+        }
+        __syncthreads();
+        for (int x = t; x < X; x += NT) dst[base_c + x] = tile[x + (x >> 6)];
+    }
+}
+
+// coarse pixels per workgroup of ps_tile_kernel: the largest divisor of B with T*Cin <= 4096 (0: use the per-element kernel)
+inline int ps_tile_T(int B, int Cin) {
+    static const int off = getenv("PNP_PS_NOTILE") ? 1 : 0;
+    if (off || Cin > 4096) return 0;
+    int T = 4096 / Cin;
+    if (T > B) T = B;
+    while (T > 1 && (B % T) != 0) --T;
+    return T;
+}
+
 // ---- critic input assembly (adversarial.py:325-335) ---------------------------------------------
 struct CriticArgs {
     const float *a, *b, *c, *d, *logits;
@@ -675,6 +736,11 @@ int pnp_maxpool2_bwd(const float* x, const float* dy, float* dx, int32_t N, int3
 int pnp_ps_fwd(const float* x, float* y, int32_t N, int32_t A, int32_t B, int32_t r, int32_t nc, void* stream) {
     PNP_REQUIRE(x && y && N > 0 && A > 0 && B > 0 && r > 0 && nc > 0, "pnp_ps_fwd: bad argument");
     const size_t total = (size_t)N * A * B * nc * r * r;
+    if (const int T = ps_tile_T(B, nc * r * r)) {
+        hipLaunchKernelGGL(ps_tile_kernel<false>, dim3((unsigned)(N * A * (B / T))), dim3(NT), 0, (hipStream_t)stream, x, y, N, A, B, r, nc, T);
+        PNP_CHECK_LAUNCH("pnp_ps_fwd");
+        return PNP_OK;
+    }
     hipLaunchKernelGGL(ps_kernel<false>, dim3(grid_for(total, 256 * 16)), dim3(NT), 0, (hipStream_t)stream, x, y, N, A, B, r, nc);
     PNP_CHECK_LAUNCH("pnp_ps_fwd");
     return PNP_OK;
@@ -683,6 +749,11 @@ int pnp_ps_fwd(const float* x, float* y, int32_t N, int32_t A, int32_t B, int32_
 int pnp_ps_bwd(const float* dy, float* dx, int32_t N, int32_t A, int32_t B, int32_t r, int32_t nc, void* stream) {
     PNP_REQUIRE(dy && dx && N > 0 && A > 0 && B > 0 && r > 0 && nc > 0, "pnp_ps_bwd: bad argument");
     const size_t total = (size_t)N * A * B * nc * r * r;
+    if (const int T = ps_tile_T(B, nc * r * r)) {
+        hipLaunchKernelGGL(ps_tile_kernel<true>, dim3((unsigned)(N * A * (B / T))), dim3(NT), 0, (hipStream_t)stream, dy, dx, N, A, B, r, nc, T);
+        PNP_CHECK_LAUNCH("pnp_ps_bwd");
+        return PNP_OK;
+    }
     hipLaunchKernelGGL(ps_kernel<true>, dim3(grid_for(total, 256 * 16)), dim3(NT), 0, (hipStream_t)stream, dy, dx, N, A, B, r, nc);
     PNP_CHECK_LAUNCH("pnp_ps_bwd");
     return PNP_OK;

@@ -93,7 +93,8 @@ def test_maxpool(dev, shape):
     assert torch.equal(K.maxpool2_bwd(xd, torch.from_numpy(dy).to(dev)).cpu(), xt.grad)
 
 
-@pytest.mark.parametrize("N,A,B,r,nc", [(2, 4, 4, 8, 40), (3, 2, 5, 8, 2), (2, 3, 3, 2, 4)])
+@pytest.mark.parametrize("N,A,B,r,nc", [(2, 4, 4, 8, 40), (3, 2, 5, 8, 2), (2, 3, 3, 2, 4), (2, 4, 32, 8, 4), (1, 2, 6, 8, 8), (1, 2, 2, 8, 72),
+                                        (16, 32, 32, 8, 40)])
 def test_ps(dev, N, A, B, r, nc):
     K = pkg("kernels")
     x = np.arange(N * A * B * nc * r * r, dtype=np.float32).reshape(N, A, B, nc * r * r)
