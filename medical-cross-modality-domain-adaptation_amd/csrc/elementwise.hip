@@ -553,28 +553,37 @@ struct CriticArgs {
     long long P;
     int Ca, tile_a, Cb, Cc, Cd, ncls, Ctot;
 };
+__device__ __forceinline__ float critic_channel(const CriticArgs& k, size_t p, int ch, int o1, int o2, int o3, int o4, int o5) {
+    if (ch < o1) return k.a[p * k.Ca + (ch % k.Ca)];
+    if (ch < o2) return k.b[p * k.Cb + (ch - o1)];
+    if (ch < o3) return k.c[p * k.Cc + (ch - o2)];
+    if (ch < o4) return k.d[p * k.Cd + (ch - o3)];
+    if (ch < o5) return k.logits[p * k.ncls + (ch - o4)];
+    const float* z = k.logits + p * k.ncls;
+    int am = 0;
+    float m = z[0];
+    for (int j = 1; j < k.ncls; ++j)
+        if (z[j] > m) { m = z[j]; am = j; }
+    return (float)am;
+}
+// VEC: one 16-byte store per thread (Ctot % 4 == 0: the reference's 32 channels), i.e. 8 lanes cover one pixel's 128 contiguous bytes
+template <bool VEC>
 __global__ void __launch_bounds__(NT) critic_input_fwd_kernel(CriticArgs k) {
-    const size_t total = (size_t)k.P * k.Ctot;
+    const int CV = VEC ? (k.Ctot >> 2) : k.Ctot;
+    const size_t total = (size_t)k.P * CV;
     const size_t gs = (size_t)gridDim.x * NT;
     const int o1 = k.Ca * k.tile_a, o2 = o1 + k.Cb, o3 = o2 + k.Cc, o4 = o3 + k.Cd, o5 = o4 + k.ncls;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += gs) {
-        const size_t p = i / k.Ctot;
-        const int ch = (int)(i - p * k.Ctot);
-        float v;
-        if (ch < o1) v = k.a[p * k.Ca + (ch % k.Ca)];
-        else if (ch < o2) v = k.b[p * k.Cb + (ch - o1)];
-        else if (ch < o3) v = k.c[p * k.Cc + (ch - o2)];
-        else if (ch < o4) v = k.d[p * k.Cd + (ch - o3)];
-        else if (ch < o5) v = k.logits[p * k.ncls + (ch - o4)];
-        else {
-            const float* z = k.logits + p * k.ncls;
-            int am = 0;
-            float m = z[0];
-            for (int j = 1; j < k.ncls; ++j)
-                if (z[j] > m) { m = z[j]; am = j; }
-            v = (float)am;
+        const size_t p = i / CV;
+        const int cv = (int)(i - p * CV);
+        if constexpr (VEC) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = critic_channel(k, p, 4 * cv + e, o1, o2, o3, o4, o5);
+            st4(k.out + i * 4, v);
+        } else {
+            k.out[i] = critic_channel(k, p, cv, o1, o2, o3, o4, o5);
         }
-        k.out[i] = v;
     }
 }
 struct CriticBwdArgs {
@@ -764,7 +773,10 @@ int pnp_critic_input_fwd(const float* a, int32_t Ca, int32_t tile_a, const float
     PNP_REQUIRE(a && b && c && d && logits && out && P > 0 && Ca > 0 && tile_a > 0 && Cb > 0 && Cc > 0 && Cd > 0 && ncls > 0,
                 "pnp_critic_input_fwd: bad argument");
     CriticArgs k{a, b, c, d, logits, out, (long long)P, Ca, tile_a, Cb, Cc, Cd, ncls, Ca * tile_a + Cb + Cc + Cd + ncls + 1};
-    hipLaunchKernelGGL(critic_input_fwd_kernel, dim3(grid_for((size_t)P * k.Ctot, 256 * 16)), dim3(NT), 0, (hipStream_t)stream, k);
+    if ((k.Ctot & 3) == 0)
+        hipLaunchKernelGGL(critic_input_fwd_kernel<true>, dim3(grid_for((size_t)P * (k.Ctot / 4), 256 * 16)), dim3(NT), 0, (hipStream_t)stream, k);
+    else
+        hipLaunchKernelGGL(critic_input_fwd_kernel<false>, dim3(grid_for((size_t)P * k.Ctot, 256 * 16)), dim3(NT), 0, (hipStream_t)stream, k);
     PNP_CHECK_LAUNCH("pnp_critic_input_fwd");
     return PNP_OK;
 }
