@@ -522,11 +522,6 @@ class Trainer(object):
         self.global_step += 1
         return loss
 
-    def _to_dev(self, batch):
-        x = torch.from_numpy(np.ascontiguousarray(batch[:, :, :, 0:3])).to(self.net.device)
-        y = torch.from_numpy(_label_decomp(self.num_cls, batch[:, :, :, 3])).to(self.net.device)
-        return x, y
-
     def train(self, output_path, restore=True, restored_path=None, training_iters=200, epochs=1000, dropout=0.75, display_step=5):
         """adversarial.py:767-946 (schedule, sub-iteration growth, periodic save + lr decay)"""
         self.output_path = output_path
