@@ -1589,11 +1589,21 @@ pnp_conv_geom phase_geom(const pnp_conv_geom* g, const DgradPhase& p) {
 
 extern "C" {
 
-size_t pnp_conv2d_fwd_workspace_bytes(const pnp_conv_geom* g) {
-    if (!g || g->pad_mode != PNP_PAD_ZERO) return 0;
+// forward: only layers that leave at least 3/4 of the workgroup slots empty — at half a dispatch round the extra pass over the partials
+// costs more than the idle CUs (128->128@32^2, 256 tiles: 0.049 ms unsplit, 0.060 split in two)
+static int fwd_split(const pnp_conv_geom* g) {
+    if (g->pad_mode != PNP_PAD_ZERO) return 1;
     const long long M = (long long)g->N * g->OH * g->OW;
-    const int ns = choose_split(M, g->K, g->R * g->S * g->C, choose_tile(M, g->K));
-    return ns > 1 ? (size_t)ns * M * g->K * sizeof(float) : 0;
+    const int tile = choose_tile(M, g->K);
+    const int bn = tile == 0 ? 128 : (tile == 1 ? 64 : 32);
+    if ((long long)pnp_cdiv(M, 128) * pnp_cdiv(g->K, bn) > 128) return 1;
+    return choose_split(M, g->K, g->R * g->S * g->C, tile);
+}
+
+size_t pnp_conv2d_fwd_workspace_bytes(const pnp_conv_geom* g) {
+    if (!g) return 0;
+    const int ns = fwd_split(g);
+    return ns > 1 ? (size_t)ns * g->N * g->OH * g->OW * g->K * sizeof(float) : 0;
 }
 
 int pnp_conv2d_fwd(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
