@@ -1332,8 +1332,8 @@ int choose_split(long long M, int K, int Kred, int tile) {
     const double rounds = (double)nblk / 512.0;
     int nsplit = 1;
     // (at exactly half a round — 256 tiles — two-way splitting LOSES: g4 128->128 dgrad 0.054 ms unsplit, 0.063 split)
-    if (rounds <= 0.25) nsplit = (int)(512 / nblk);
-    else if (rounds < 3.0 && (ceil(rounds) - rounds) > 0.3) nsplit = 2;
+    if (rounds <= 0.4) nsplit = (int)(512 / nblk);
+    else if (rounds > 1.0 && rounds < 3.0 && (ceil(rounds) - rounds) > 0.3) nsplit = 2;
     const int cap = nblk <= 64 ? 32 : 4;        // a handful of tiles (4x4 / 2x2 feature maps, M = 256 rows): split deeper
     if (nsplit > cap) nsplit = cap;
     if (nsplit > nch / 8) nsplit = nch / 8;
