@@ -143,6 +143,7 @@ struct Acc {
 // (unused) prefetch past the last stage need neither branches nor selects: the main-loop body is ONE basic block,
 // which is what lets the MFMA / ds_read / buffer_load interleave below be scheduled at all.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const float __attribute__((address_space(4))) pnp_cfloat;     // constant address space: uniform reads become s_load
 constexpr unsigned OOB = 0xFFFFFF00u;   // beyond any legal offset (host checks tensors are < 2^30 elements)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
@@ -871,6 +872,77 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
     }
 }
 
+// ===================================== direct forward conv for narrow outputs ============================================
+// K <= 8 output channels at stride 1 (the 40->5 logits conv at 256^2): an MFMA tile would be >= 3/4 empty in N (measured 15 TF/s,
+// bound by the matrix pipe doing mostly zeros).  A thread owns one output pixel and its K accumulators.  The workgroup's input patch
+// ((8 + (R-1)dil) x (32 + (S-1)dil) pixels x C channels) is staged once in LDS with a pixel stride of C+4 floats when C/4 is even (an odd
+// number of 16-byte slots per pixel: the 64 lanes of a ds_read_b128 spread over all banks); the filter values are uniform over the
+// wave and come through the scalar cache (constant address space), so the inner loop is v_pk_fma_f32 acc, x, s[w].
+struct NarrowArgs {
+    const float* x;
+    const float* w;
+    float* y;
+    int N, H, W, C, K, R, S, OH, OW, dil, pad_t, pad_l;
+    int PH, PW, CP;                 // patch extent (pixels) and padded pixel stride (floats)
+    int do_drop;
+    float drop_scale;
+    uint32_t drop_thresh, drop_key;
+    unsigned x_bytes;
+};
+
+template <int KK, bool EXACT>
+__global__ void __launch_bounds__(256) conv_fwd_narrow_kernel(NarrowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int t = threadIdx.x;
+    const int tx = t & 31, ty = t >> 5;
+    const int ow0 = blockIdx.x * 32, oh0 = blockIdx.y * 8, n = blockIdx.z;
+    const int K = EXACT ? KK : a.K;
+    const int C4 = a.C >> 2;
+    // ---- stage the patch (zero outside the image) --------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const int nvec = a.PH * a.PW * C4;
+    for (int i = t; i < nvec; i += 256) {
+        const int pix = i / C4, c4 = i - pix * C4;
+        const int pr = pix / a.PW, pc = pix - pr * a.PW;
+        const int ih = oh0 - a.pad_t + pr, iw = ow0 - a.pad_l + pc;
+        const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+        const f32x4 v = bload4(rx, ok ? (unsigned)((((n * a.H + ih) * a.W + iw) * a.C + 4 * c4) * 4) : OOB);
+        *reinterpret_cast<f32x4*>(xs + pix * a.CP + 4 * c4) = v;
+    }
+    __syncthreads();
+    // ---- accumulate ---------------------------------------------------------------------------------------------------
+    pnp_cfloat* wc = (pnp_cfloat*)(uintptr_t)a.w;
+    float acc[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) acc[k] = 0.f;
+    for (int r = 0; r < a.R; ++r)
+        for (int sx = 0; sx < a.S; ++sx) {
+            const float* xp = xs + ((ty + r * a.dil) * a.PW + tx + sx * a.dil) * a.CP;
+            const int wbase = (r * a.S + sx) * a.C * K;
+#pragma unroll 2
+            for (int c4 = 0; c4 < C4; ++c4) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 4 * c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int k = 0; k < KK; ++k)
+                        if (k < K) acc[k] = fmaf(xv[e], wc[wbase + (4 * c4 + e) * K + k], acc[k]);
+            }
+        }
+    const int oh = oh0 + ty, ow = ow0 + tx;
+    if (oh < a.OH && ow < a.OW) {
+        const size_t m = ((size_t)n * a.OH + oh) * a.OW + ow;
+#pragma unroll
+        for (int k = 0; k < KK; ++k)
+            if (k < K) {
+                const size_t idx = m * K + k;
+                float v = acc[k];
+                if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                a.y[idx] = v;
+            }
+    }
+}
+
 // ===================================== direct filter gradient for narrow outputs ============================================
 // K <= 16 output channels (g1's 16-channel convs, the 40->5 logits conv, the mask critic's first conv): an MFMA tile is at most half
 // full in N and the reduction (all pixels) is long, so this one runs on the vector ALUs.  A thread owns PPT (tap, channel) pairs x K
@@ -889,7 +961,6 @@ struct WgdArgs {
     unsigned x_bytes, dy_bytes;
 };
 
-typedef const float __attribute__((address_space(4))) pnp_cfloat;     // constant address space: uniform reads become s_load
 
 // UNI (one pixel group): the pixel index is uniform over the workgroup, so the K dy values come through the SCALAR cache into SGPRs
 // (v_fmac with an SGPR operand) instead of 64 lanes x 16 B of vector-memory traffic per wave and pixel for 64 useful bytes — the
@@ -1494,6 +1565,18 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     return PNP_OK;
 }
 
+// ---- direct forward for K <= 8 (conv_fwd_narrow_kernel): applicability + launch -------------------------------------------------
+bool narrow_fwd_ok(const pnp_conv_geom* g, NarrowArgs* na) {
+    static const int off = getenv("PNP_CONV_NONARROW") ? 1 : 0;
+    if (off || g->K > 8 || g->stride != 1 || g->pad_mode != PNP_PAD_ZERO || (g->C & 3) != 0 || g->C < 8) return false;
+    if ((long long)g->N * g->OH * g->OW < 8192) return false;
+    const int PH = 8 + (g->R - 1) * g->dil, PW = 32 + (g->S - 1) * g->dil;
+    const int CP = ((g->C >> 2) & 1) ? g->C : g->C + 4;
+    if ((size_t)PH * PW * CP * sizeof(float) > 150 * 1024) return false;
+    if (na) { na->PH = PH; na->PW = PW; na->CP = CP; }
+    return true;
+}
+
 // ---- direct (vector-ALU) filter gradient for K <= 16: plan shared by the workspace query and the launch -------------------------
 struct WgdPlan { int use, nblk, ppb, G, ppt; size_t ws_bytes; };
 
@@ -1632,6 +1715,29 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
         a.drop_scale = 1.f / keep_prob;
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
+    }
+    NarrowArgs na{};
+    if (narrow_fwd_ok(g, &na)) {
+        na.x = x; na.w = w; na.y = y;
+        na.N = g->N; na.H = g->H; na.W = g->W; na.C = g->C; na.K = g->K; na.R = g->R; na.S = g->S; na.OH = g->OH; na.OW = g->OW;
+        na.dil = g->dil; na.pad_t = g->pad_t; na.pad_l = g->pad_l;
+        na.do_drop = a.do_drop; na.drop_scale = a.drop_scale; na.drop_thresh = a.drop_thresh; na.drop_key = a.drop_key;
+        na.x_bytes = a.x_bytes;
+        const size_t lds = (size_t)na.PH * na.PW * na.CP * sizeof(float);
+        dim3 grid((unsigned)pnp_cdiv(g->OW, 32), (unsigned)pnp_cdiv(g->OH, 8), (unsigned)g->N);
+        if (g->K == 5) {
+            PNP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_narrow_kernel<5, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                        "conv_fwd_narrow_kernel: cannot reserve %zu bytes of LDS", lds);
+            hipLaunchKernelGGL((conv_fwd_narrow_kernel<5, true>), grid, dim3(256), lds, (hipStream_t)stream, na);
+        } else {
+            PNP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_narrow_kernel<8, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                        "conv_fwd_narrow_kernel: cannot reserve %zu bytes of LDS", lds);
+            hipLaunchKernelGGL((conv_fwd_narrow_kernel<8, false>), grid, dim3(256), lds, (hipStream_t)stream, na);
+        }
+        PNP_CHECK_LAUNCH("conv_fwd_narrow_kernel");
+        return PNP_OK;
     }
     float* split_ws = (workspace && workspace_bytes >= pnp_conv2d_fwd_workspace_bytes(g) && pnp_conv2d_fwd_workspace_bytes(g) > 0)
                           ? (float*)workspace : nullptr;

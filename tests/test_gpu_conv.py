@@ -104,7 +104,8 @@ def test_conv_transpose_detecting(dev):
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 64, 3, 1, 1, "SAME"),
                                   (2, 8, 8, 512, 512, 3, 1, 1, "SAME"),      # 8 tiles: reduction split 18 ways, dropout in the summing kernel
-                                  (2, 16, 16, 512, 512, 5, 4, 1, "SAME")])   # critic k5 s4 -> 4x4 map
+                                  (2, 16, 16, 512, 512, 5, 4, 1, "SAME"),    # critic k5 s4 -> 4x4 map
+                                  (2, 68, 68, 40, 5, 5, 1, 1, "VALID")])     # logits conv on the direct narrow-output kernel
 def test_dropout_epilogue_matches_oracle_mask(dev, case):
     K = pkg("kernels")
     x, w, stride, dil, padding = _mk(case)
