@@ -873,8 +873,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
 }
 
 // ===================================== direct forward conv for narrow outputs ============================================
-// K <= 8 output channels at stride 1 (the 40->5 logits conv at 256^2): an MFMA tile would be >= 3/4 empty in N (measured 15 TF/s,
-// bound by the matrix pipe doing mostly zeros).  A thread owns one output pixel and its K accumulators.  The workgroup's input patch
+// K <= 16 output channels at stride 1 (the 40->5 logits conv and g1's 16->16 convs at 256^2, and their data gradients when the INPUT
+// is that narrow): an MFMA tile is half to 5/6 empty in N (40->5 measured 15 TF/s, bound by the matrix pipe doing mostly zeros).  A thread owns one output pixel and its K accumulators.  The workgroup's input patch
 // ((8 + (R-1)dil) x (32 + (S-1)dil) pixels x C channels) is staged once in LDS with a pixel stride of C+4 floats when C/4 is even (an odd
 // number of 16-byte slots per pixel: the 64 lanes of a ds_read_b128 spread over all banks); the filter values are uniform over the
 // wave and come through the scalar cache (constant address space), so the inner loop is v_pk_fma_f32 acc, x, s[w].
@@ -912,6 +912,7 @@ __global__ void __launch_bounds__(256) conv_fwd_narrow_kernel(NarrowArgs a) {
     __syncthreads();
     // ---- accumulate ---------------------------------------------------------------------------------------------------
     pnp_cfloat* wc = (pnp_cfloat*)(uintptr_t)a.w;
+    constexpr int UNR = KK <= 8 ? 2 : 1;        // 4*KK filter values per channel quad live in SGPRs
     float acc[KK];
 #pragma unroll
     for (int k = 0; k < KK; ++k) acc[k] = 0.f;
@@ -919,7 +920,7 @@ __global__ void __launch_bounds__(256) conv_fwd_narrow_kernel(NarrowArgs a) {
         for (int sx = 0; sx < a.S; ++sx) {
             const float* xp = xs + ((ty + r * a.dil) * a.PW + tx + sx * a.dil) * a.CP;
             const int wbase = (r * a.S + sx) * a.C * K;
-#pragma unroll 2
+#pragma unroll UNR
             for (int c4 = 0; c4 < C4; ++c4) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 4 * c4);
 #pragma unroll
@@ -1568,13 +1569,43 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
 // ---- direct forward for K <= 8 (conv_fwd_narrow_kernel): applicability + launch -------------------------------------------------
 bool narrow_fwd_ok(const pnp_conv_geom* g, NarrowArgs* na) {
     static const int off = getenv("PNP_CONV_NONARROW") ? 1 : 0;
-    if (off || g->K > 8 || g->stride != 1 || g->pad_mode != PNP_PAD_ZERO || (g->C & 3) != 0 || g->C < 8) return false;
+    if (off || g->K > 16 || g->stride != 1 || g->pad_mode != PNP_PAD_ZERO || (g->C & 3) != 0 || g->C < 8) return false;
     if ((long long)g->N * g->OH * g->OW < 8192) return false;
+    // 9..16 outputs: the MFMA tile is half full, the vector ALUs only win while the work per pixel is small (16->16 3x3: 0.154 -> 0.130 ms;
+    // 32->16 3x3, twice the work: 0.062 -> 0.071)
+    if (g->K > 8 && (long long)g->R * g->S * g->C * g->K > 2304) return false;
     const int PH = 8 + (g->R - 1) * g->dil, PW = 32 + (g->S - 1) * g->dil;
     const int CP = ((g->C >> 2) & 1) ? g->C : g->C + 4;
     if ((size_t)PH * PW * CP * sizeof(float) > 150 * 1024) return false;
     if (na) { na->PH = PH; na->PW = PW; na->CP = CP; }
     return true;
+}
+
+template <int KK, bool EXACT>
+int launch_narrow_inst(const NarrowArgs& na, dim3 grid, size_t lds, hipStream_t st) {
+    PNP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_narrow_kernel<KK, EXACT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                "conv_fwd_narrow_kernel: cannot reserve %zu bytes of LDS", lds);
+    hipLaunchKernelGGL((conv_fwd_narrow_kernel<KK, EXACT>), grid, dim3(256), lds, st, na);
+    PNP_CHECK_LAUNCH("conv_fwd_narrow_kernel");
+    return PNP_OK;
+}
+
+// x, w, y and geometry of a stride-1 zero-padded conv with K <= 16 (forward, or a data gradient expressed as one); dropout from `a`
+int launch_narrow(const float* x, const float* w, float* y, const pnp_conv_geom* g, const ConvArgs& a, hipStream_t st) {
+    NarrowArgs na{};
+    narrow_fwd_ok(g, &na);
+    na.x = x; na.w = w; na.y = y;
+    na.N = g->N; na.H = g->H; na.W = g->W; na.C = g->C; na.K = g->K; na.R = g->R; na.S = g->S; na.OH = g->OH; na.OW = g->OW;
+    na.dil = g->dil; na.pad_t = g->pad_t; na.pad_l = g->pad_l;
+    na.do_drop = a.do_drop; na.drop_scale = a.drop_scale; na.drop_thresh = a.drop_thresh; na.drop_key = a.drop_key;
+    na.x_bytes = a.x_bytes;
+    const size_t lds = (size_t)na.PH * na.PW * na.CP * sizeof(float);
+    dim3 grid((unsigned)pnp_cdiv(g->OW, 32), (unsigned)pnp_cdiv(g->OH, 8), (unsigned)g->N);
+    if (g->K == 5) return launch_narrow_inst<5, true>(na, grid, lds, st);
+    if (g->K == 16) return launch_narrow_inst<16, true>(na, grid, lds, st);
+    if (g->K <= 8) return launch_narrow_inst<8, false>(na, grid, lds, st);
+    return launch_narrow_inst<16, false>(na, grid, lds, st);
 }
 
 // ---- direct (vector-ALU) filter gradient for K <= 16: plan shared by the workspace query and the launch -------------------------
@@ -1716,29 +1747,7 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
     }
-    NarrowArgs na{};
-    if (narrow_fwd_ok(g, &na)) {
-        na.x = x; na.w = w; na.y = y;
-        na.N = g->N; na.H = g->H; na.W = g->W; na.C = g->C; na.K = g->K; na.R = g->R; na.S = g->S; na.OH = g->OH; na.OW = g->OW;
-        na.dil = g->dil; na.pad_t = g->pad_t; na.pad_l = g->pad_l;
-        na.do_drop = a.do_drop; na.drop_scale = a.drop_scale; na.drop_thresh = a.drop_thresh; na.drop_key = a.drop_key;
-        na.x_bytes = a.x_bytes;
-        const size_t lds = (size_t)na.PH * na.PW * na.CP * sizeof(float);
-        dim3 grid((unsigned)pnp_cdiv(g->OW, 32), (unsigned)pnp_cdiv(g->OH, 8), (unsigned)g->N);
-        if (g->K == 5) {
-            PNP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_narrow_kernel<5, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
-                        "conv_fwd_narrow_kernel: cannot reserve %zu bytes of LDS", lds);
-            hipLaunchKernelGGL((conv_fwd_narrow_kernel<5, true>), grid, dim3(256), lds, (hipStream_t)stream, na);
-        } else {
-            PNP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_narrow_kernel<8, false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
-                        "conv_fwd_narrow_kernel: cannot reserve %zu bytes of LDS", lds);
-            hipLaunchKernelGGL((conv_fwd_narrow_kernel<8, false>), grid, dim3(256), lds, (hipStream_t)stream, na);
-        }
-        PNP_CHECK_LAUNCH("conv_fwd_narrow_kernel");
-        return PNP_OK;
-    }
+    if (narrow_fwd_ok(g, nullptr)) return launch_narrow(x, w, y, g, a, (hipStream_t)stream);
     float* split_ws = (workspace && workspace_bytes >= pnp_conv2d_fwd_workspace_bytes(g) && pnp_conv2d_fwd_workspace_bytes(g) > 0)
                           ? (float*)workspace : nullptr;
     return launch_fwd<0>(a, (hipStream_t)stream, split_ws);
@@ -1865,6 +1874,16 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
     float* out = sym ? (float*)((char*)workspace + woff) : dx;
     ConvArgs a = make_args(dy, wt, out, &d);
     a.ups = g->stride;
+    if (g->stride == 1 && narrow_fwd_ok(&d, nullptr)) {       // few INPUT channels: the data gradient is a narrow-output conv of dy
+        if (int e = launch_narrow(dy, wt, out, &d, a, st)) return e;
+        if (sym) {
+            const size_t total = (size_t)g->N * g->H * g->W * g->C;
+            hipLaunchKernelGGL(sympad_bwd_kernel, dim3((unsigned)pnp_cdiv((long long)total, 256)), dim3(256), 0, st,
+                               (const float*)out, dx, g->N, g->H, g->W, g->C, g->pad_t);
+            PNP_CHECK_LAUNCH("sympad_bwd_kernel");
+        }
+        return PNP_OK;
+    }
     size_t poff = woff;
     if (sym) poff += ((size_t)d.N * d.OH * d.OW * d.K * sizeof(float) + 255) & ~(size_t)255;
     float* split_ws = (workspace_bytes > poff) ? (float*)((char*)workspace + poff) : nullptr;

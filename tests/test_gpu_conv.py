@@ -48,6 +48,9 @@ CASES = [
     (2, 128, 128, 5, 16, 3, 2, 1, "SAME"),      # direct wgrad with stride 2 (mask critic m_cls_1)
     (2, 64, 64, 8, 7, 3, 1, 1, "SAME"),         # direct wgrad, K = 7 on the 8-wide instance
     (2, 64, 64, 4, 12, 3, 1, 2, "SAME"),        # direct wgrad, K = 12 on the 16-wide instance, dilation 2
+    (2, 64, 64, 32, 12, 3, 1, 2, "SAME"),       # direct narrow-output forward, K = 12 on the 16-wide instance, dilation 2
+    (2, 64, 64, 16, 32, 3, 1, 1, "SAME"),       # data gradient with 16 INPUT channels: narrow-output kernel over dy (32 channels)
+    (2, 70, 66, 16, 16, 3, 1, 1, "SAME"),       # narrow kernels with ragged 8x32 output patches
 ]
 
 
