@@ -12,7 +12,7 @@ import os
 # "no ROCm-capable device is detected" (measured on the GPU box; tests/test_abi.py guards the order).
 import torch  # noqa: F401  (import order is the point)
 
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PNP_LIB") or os.path.join(_HERE, "libpnp_hip.so")   # PNP_LIB: timing-experiment builds (tools/)

@@ -8,7 +8,7 @@ Fused units (what TF-1.4 lowers layers.py's chains to, restated as one forward +
   MaxPool2Fn, PSFn, SegLossFn, CriticInputFn
 """
 import os
-import torch
+
 from torch.autograd import Function
 
 from . import kernels as K

@@ -5,7 +5,6 @@ arithmetic result comes from libpnp_hip.so.  Tensors are NHWC float32, filters H
 reference's layouts (layers.py).  Each function names the reference op it stands for.
 """
 import ctypes
-import math
 
 import torch
 

@@ -6,9 +6,6 @@ CPU restatement of the adaptation graph of the reference's adversarial.py:
 Variables: dict {TF variable name: torch CPU tensor}, same names as the product's VariableStore.
 Dropout stream ids are consumed in graph-construction order (one per conv call), like the product.
 """
-from collections import OrderedDict
-
-import numpy as np
 import torch
 
 from . import tf_ops as T

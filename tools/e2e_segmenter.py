@@ -1,6 +1,6 @@
 """Throughput of the train_segmenter.py entry point itself (synthetic tfrecords on disk -> SliceQueue -> DeviceFeeder -> train step,
 monitoring forwards every 5th step): the number to hold against bench.py's resident-input slices/s."""
-import importlib, time, sys, os, logging
+import importlib, time, sys, os
 sys.path.insert(0, os.getcwd())
 ts = importlib.import_module("medical-cross-modality-domain-adaptation_amd.train_segmenter")
 import torch
