@@ -71,3 +71,40 @@ def test_torch_is_loaded_before_the_library():
             "assert len(hip) == 1, hip") % (ROOT, PKG)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
+
+
+def test_host_planners_through_the_workspace_queries(built):
+    """the reduction-split / stride-phase / direct-kernel planners are host code: their decisions show in the workspace sizes
+    (no GPU needed).  B=16 shapes of the hot path."""
+    import ctypes
+    lib = built._lib.load()
+    K = pkg("kernels")
+
+    def geo(N, H, C, Kc, R, stride=1, dil=1, padding="SAME"):
+        return K.conv_geom((N, H, H, C), (R, R, C, Kc), stride, dil, padding)
+
+    fwd = lambda g: lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))
+    dgr = lambda g: lib.pnp_conv2d_dgrad_workspace_bytes(ctypes.byref(g))
+    wgr = lambda g: lib.pnp_conv2d_wgrad_workspace_bytes(ctypes.byref(g))
+    big = geo(16, 32, 512, 512, 3)
+    filt = lambda g: ((g.R * g.S * g.C * g.K * 4 + 255) // 256) * 256
+    assert fwd(big) == 0                                     # 512 tiles: a full dispatch round, never split
+    assert dgr(big) == filt(big)                             # only the flipped filters
+    assert wgr(big) == 7 * 3 * 3 * 512 * 512 * 4             # 144 tiles x 7 splits = 1.97 rounds (DESIGN.md §4.1)
+    g4 = geo(16, 32, 128, 128, 3)
+    assert fwd(g4) == 0 and dgr(g4) == filt(g4)              # 256 tiles = half a round: splitting loses (measured)
+    tiny = geo(16, 16, 512, 512, 5, stride=4)                # critic cls_5: 4x4 maps, 8 tiles
+    out_elems = 16 * 4 * 4 * 512
+    assert fwd(tiny) % (out_elems * 4) == 0 and 8 <= fwd(tiny) // (out_elems * 4) <= 32
+    # strided data gradient by stride phases: filters + the largest phase's partials, far less than the zero-upsampled formulation
+    k5s2 = geo(16, 128, 128, 128, 5, stride=2)
+    assert filt(k5s2) <= dgr(k5s2) < filt(k5s2) + 2 * 16 * 128 * 128 * 128 * 4
+    # g10's data gradient on the pre-padded input: 580 tiles = 1.13 rounds -> 7 splits (7.93 rounds)
+    g10 = K.conv_geom((16, 34, 34, 512), (3, 3, 512, 2560), 1, 1, "VALID")
+    assert dgr(g10) == ((3 * 3 * 512 * 2560 * 4 + 255) // 256) * 256 + 7 * 16 * 34 * 34 * 512 * 4
+    # direct filter gradient for K <= 16: one partial per workgroup (2048 slabs)
+    g1 = geo(16, 256, 16, 16, 3)
+    assert wgr(g1) == 2048 * 3 * 3 * 16 * 16 * 4
+    logits = K.conv_geom((16, 260, 260, 40), (5, 5, 40, 5), 1, 1, "VALID")
+    assert wgr(logits) == 2048 * 5 * 5 * 40 * 5 * 4
+    assert lib.pnp_conv2d_dgrad_workspace_bytes(None) == 0 and lib.pnp_conv2d_fwd_workspace_bytes(None) == 0
