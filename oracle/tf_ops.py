@@ -69,6 +69,41 @@ def conv2d(x, w, stride=1, dil=1, padding="SAME"):
     return y.permute(0, 2, 3, 1)
 
 
+def conv2d_dgrad_by_phases(dy, w, in_hw, stride, pad_t, pad_l):
+    """Data gradient of a strided zero-padded conv, restated the way the HIP path computes it (csrc/conv_igemm.hip::plan_phases):
+    dx[h] receives only the filter taps r with r = (h + pad) mod stride, so every residue class of pixels ("phase") is a stride-1
+    correlation of dy with the flipped sub-filter {r = a, a+stride, ...}:
+        dx[h0 + stride*i] = sum_t dy[i + q - t] * W[a + stride*t],   h0 = (a - pad) mod stride,  q = (h0 + pad - a) / stride
+    Checked on the CPU against autograd (tests/test_host.py); pure test infrastructure like the rest of this module.
+    dy [N,OH,OW,K], w [R,S,C,K], in_hw = (H, W) of the conv input -> dx [N,H,W,C]."""
+    R, S, C, K = w.shape
+    N, OH, OW, _ = dy.shape
+    H, W = in_hw
+    dx = torch.zeros((N, H, W, C), dtype=dy.dtype)
+    for a in range(stride):
+        for b in range(stride):
+            T, U = -(-(R - a) // stride) if a < R else 0, -(-(S - b) // stride) if b < S else 0
+            h0, w0 = (a - pad_t) % stride, (b - pad_l) % stride
+            if T == 0 or U == 0 or h0 >= H or w0 >= W:
+                continue
+            qa, qb = (h0 + pad_t - a) // stride, (w0 + pad_l - b) // stride
+            I, J = (H - 1 - h0) // stride + 1, (W - 1 - w0) // stride + 1
+            sub = w[a::stride, b::stride]                              # [T,U,C,K]
+            wf = torch.flip(sub, (0, 1)).permute(0, 1, 3, 2)           # flipped, K <-> C : filter of the correlation over dy
+            pt, pl = T - 1 - qa, U - 1 - qb                            # zero padding before (may be negative: crop instead)
+            # rows i' in [0, I) read dy rows i' - pt ... i' - pt + T - 1
+            need_h, need_w = I + T - 1, J + U - 1
+            src = torch.zeros((N, need_h, need_w, K), dtype=dy.dtype)
+            lo_h, lo_w = max(pt, 0), max(pl, 0)                         # where dy row 0 lands in the padded buffer
+            sh, sw = max(-pt, 0), max(-pl, 0)                           # dy rows skipped when the padding is negative
+            nh, nw = min(OH - sh, need_h - lo_h), min(OW - sw, need_w - lo_w)
+            if nh > 0 and nw > 0:
+                src[:, lo_h:lo_h + nh, lo_w:lo_w + nw] = dy[:, sh:sh + nh, sw:sw + nw]
+            out = F.conv2d(src.permute(0, 3, 1, 2), wf.permute(3, 2, 0, 1)).permute(0, 2, 3, 1)     # [N,I,J,C]
+            dx[:, h0::stride, w0::stride] = out[:, :I, :J]
+    return dx
+
+
 def conv2d_direct_np(x, w, stride=1, dil=1, padding="SAME"):
     """From-the-definition float64 loop nest (numpy) — an implementation-independent check of conv2d() above for
     small shapes (pure-Python loops over taps only)."""

@@ -239,3 +239,36 @@ print("rank", rank, "ok")
                         "--master-port", "29733", str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert p.stdout.count("ok") == 2
+
+
+def test_stride_phase_data_gradient_restatement():
+    """the decomposition behind the strided data gradients of the HIP path (one stride-1 correlation per residue class of pixels) equals
+    autograd's gradient for every stride / filter / padding / extent combination, including the ones the model never uses"""
+    rng = np.random.default_rng(0)
+    cases = 0
+    for stride in (2, 3, 4):
+        for R, S in ((3, 3), (5, 5), (2, 3), (4, 2), (7, 5), (1, 1), (2, 2)):
+            for H, W in ((8, 8), (9, 7), (15, 13), (4, 5)):
+                for padding in ("SAME", "VALID", "explicit"):
+                    if padding == "SAME":
+                        OH, pt, _ = T.same_pad(H, R, stride)
+                        OW, pl, _ = T.same_pad(W, S, stride)
+                    elif padding == "VALID":
+                        if H < R or W < S:
+                            continue
+                        OH, OW, pt, pl = (H - R) // stride + 1, (W - S) // stride + 1, 0, 0
+                    else:                                   # arbitrary explicit zero padding (incl. more than SAME would use)
+                        pt, pl = R - 1, S // 2
+                        OH, OW = (H + 2 * pt - R) // stride + 1, (W + 2 * pl - S) // stride + 1
+                        if OH < 1 or OW < 1:
+                            continue
+                    x = torch.from_numpy(rng.standard_normal((2, H, W, 3))).requires_grad_(True)
+                    w = torch.from_numpy(rng.standard_normal((R, S, 3, 4)))
+                    xp = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (pl, S + stride, pt, R + stride))     # generous zeros after
+                    y = torch.nn.functional.conv2d(xp, w.permute(3, 2, 0, 1), stride=stride).permute(0, 2, 3, 1)[:, :OH, :OW]
+                    dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)))
+                    y.backward(dy)
+                    got = T.conv2d_dgrad_by_phases(dy, w, (H, W), stride, pt, pl)
+                    assert torch.allclose(got, x.grad, rtol=1e-10, atol=1e-10), (stride, R, S, H, W, padding)
+                    cases += 1
+    assert cases > 200
