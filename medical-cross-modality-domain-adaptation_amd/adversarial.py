@@ -597,6 +597,15 @@ class Trainer(object):
         np.savetxt(os.path.join(output_path, "cm.csv"), all_cm)
         return self.sample_metric_stddev(sample_eval_list)
 
+    def test_model(self, this_model, output_path):
+        """adversarial.py:1097-1108: restore a checkpoint (.npz of this package), then test_eval"""
+        os.makedirs(output_path, exist_ok=True)
+        self.net.restore(None, this_model)
+        logging.info("model has been loaded!")
+        dice, jac = self.test_eval(None, output_path)
+        logging.info("testing finished")
+        return dice, jac
+
     def sample_metric_stddev(self, sample_eval_list):
         """adversarial.py:1054-1084"""
         from . import volume_eval as ve

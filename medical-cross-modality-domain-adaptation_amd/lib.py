@@ -93,6 +93,14 @@ def confusion_matrix(compact_y, compact_pred, num_classes):
     return torch.bincount(idx, minlength=num_classes * num_classes).reshape(num_classes, num_classes).cpu().numpy()
 
 
+def _inverse_lookup(my_dict, _value):
+    """lib.py:113-118: first key holding _value (contour_map name of a label id)"""
+    for key, dic_value in list(my_dict.items()):
+        if dic_value == _value:
+            return key
+    return None
+
+
 def _jaccard(conf_matrix):
     """lib.py:121-134"""
     num_cls = conf_matrix.shape[0]

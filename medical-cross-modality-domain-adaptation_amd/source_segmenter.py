@@ -482,6 +482,15 @@ class Trainer(object):
                                            flip_correction, shuffle=False, on_sample=on_sample)
         return self.sample_metric_stddev(sample_eval_list)
 
+    def test_choose_model(self, this_model, output_path):
+        """source_segmenter.py:666-675: restore a checkpoint (.npz of this package), then test_eval"""
+        os.makedirs(output_path, exist_ok=True)
+        self.net.restore(None, this_model)
+        logging.info("model has been loaded!")
+        dice, jac = self.test_eval(None, output_path)
+        logging.info("testing finished")
+        return dice, jac
+
     def sample_metric_stddev(self, sample_eval_list):
         """source_segmenter.py:634-664"""
         from . import volume_eval as ve

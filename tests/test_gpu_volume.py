@@ -87,6 +87,10 @@ def test_segmenter_test_eval(dev, tmp_path):
     assert np.array_equal(gth, np.flip(np.flip(laby, 0), 1))
     assert np.allclose(dice, L._dice(cm)) and second.shape == (1, 2)
     assert cm.sum() == 3 * B * 256 * 256
+    # test_choose_model (source_segmenter.py:666-675): restore a checkpoint, then the same evaluation
+    ck = net.save(str(tmp_path / "ck.npz"))
+    d2, _ = tr.test_choose_model(ck, str(tmp_path / "out2"))
+    assert np.allclose(d2, dice)
 
 
 def test_adaptation_test_eval(dev, tmp_path):
@@ -119,3 +123,7 @@ def test_adaptation_test_eval(dev, tmp_path):
     assert np.allclose(dice, np.mean(dices, axis=0)) and second.shape == (1, 2)
     assert np.array_equal(np.loadtxt(os.path.join(out, "cm.csv")), total)
     assert total.sum() == 2 * 2 * B * 256 * 256
+    ck = net.save(str(tmp_path / "ck.npz"))
+    np.random.seed(11)
+    d2, _ = tr.test_model(ck, str(tmp_path / "out2"))                       # adversarial.py:1097-1108
+    assert np.allclose(d2, dice)
