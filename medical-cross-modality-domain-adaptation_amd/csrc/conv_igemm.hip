@@ -185,6 +185,20 @@ struct BLoader {
             }
         }
     }
+    // Scalar-offset variant (wgrad, dy < 2 GiB): the thread's byte offset inside a 32-row stage never changes, the stage itself is a
+    // scalar offset; rows past the end of the matrix are past the buffer -> 0 from the hardware.  No VALU per stage.
+    unsigned boff[NP];
+    __device__ __forceinline__ void init_s(int ncols, int n0) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            boff[i] = (n0 + 4 * bcol < ncols) ? (unsigned)(((brow + RP * i) * ncols + n0 + 4 * bcol) * 4) : 0x80000000u;
+    }
+    __device__ __forceinline__ void load_s(__amdgpu_buffer_rsrc_t rb, int k0, int ncols) {
+        const int soff = k0 * ncols * 4;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, boff[i], soff, 0));
+    }
     __device__ __forceinline__ void store(float* lds) const {
 #pragma unroll
         for (int i = 0; i < NP; ++i)
@@ -320,7 +334,7 @@ struct WgradALoader {
     // MODE 3 (stride 1, zero padding, OW >= 32, C % 4 == 0): the reduction index p (output pixel) advances by 32 per stage, so the
     // pixel coordinates and the input byte offset are carried incrementally — no integer division and ~12 VALU per row per stage
     // instead of ~70 (three divisions) in the general path.
-    int l_ow[NP], l_oh[NP], l_p[NP], l_off[NP];
+    int l_ow[NP], l_oh[NP], l_off[NP];
     int l_dh, l_dw;         // tap displacement: r*dil - pad_t, s*dil - pad_l
     __device__ __forceinline__ void init(int t, int mm0, const ConvArgs& a, int p_first = 0) {
         acol = t % C4;
@@ -341,7 +355,6 @@ struct WgradALoader {
                 const int rem = p - n * a.OHW;
                 l_oh[i] = rem / a.OW;
                 l_ow[i] = rem - l_oh[i] * a.OW;
-                l_p[i] = p;
                 l_off[i] = (((n * a.H + l_oh[i] + l_dh) * a.W + l_ow[i] + l_dw) * a.C + c_u) * 4;
             }
         }
@@ -350,10 +363,10 @@ struct WgradALoader {
     __device__ __forceinline__ void load_advance(const ConvArgs& a, __amdgpu_buffer_rsrc_t rx, int pend) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const bool ok = mok & (l_p[i] < pend) & ((unsigned)(l_oh[i] + l_dh) < (unsigned)a.H) &
-                            ((unsigned)(l_ow[i] + l_dw) < (unsigned)a.W);
+            // (no test against the end of the pixel range: splits end on stage boundaries, and rows past the LAST pixel either land
+            // past the end of x -> 0 from the hardware, or meet a dy row past the end of dy -> 0)
+            const bool ok = mok & ((unsigned)(l_oh[i] + l_dh) < (unsigned)a.H) & ((unsigned)(l_ow[i] + l_dw) < (unsigned)a.W);
             reg[i] = bload4(rx, ok ? (unsigned)l_off[i] : OOB);
-            l_p[i] += BK;
             l_ow[i] += BK;
             l_off[i] += BK * a.C * 4;
             const bool ww = l_ow[i] >= a.OW;                    // at most one wrap per step because OW >= 32
@@ -788,6 +801,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
     BLoader<BN, VECB> lb;
     la.init(t, mm0, a, z * a.chunks_per_split * BK);
     lb.init(t);
+    constexpr bool BS = (MODE == 3) && VECB;       // host: dy < 2 GiB on this path
+    if constexpr (BS) lb.init_s(a.K, n0);
 
     Acc<TM, TN> acc;
     acc.zero();
@@ -803,7 +818,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
     if (nchunks > 0) {
         const int pend = (c_end * BK < P) ? c_end * BK : P;     // this split's pixel range ends here
         la.load(a, rx, c_begin * BK, pend);
-        lb.load(rw, c_begin * BK, pend, a.K, n0);
+        if constexpr (BS) lb.load_s(rw, c_begin * BK, a.K);
+        else lb.load(rw, c_begin * BK, pend, a.K, n0);
         la.store(lds);
         lb.store(lds + 2 * ASZ);
         __syncthreads();
@@ -818,7 +834,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
             const int p0 = (c_begin + c + 1) * BK;                 // >= pend on the last stage -> zeros
             f1.load(As, Bs, 1, wm0, wn0, lane);
             la.load(a, rx, p0, pend);
-            lb.load(rw, p0, pend, a.K, n0);
+            if constexpr (BS) lb.load_s(rw, p0, a.K);
+            else lb.load(rw, p0, pend, a.K, n0);
             f0.mma(acc);
             __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);      // slice-1 fragment reads first
 #pragma unroll
@@ -1552,7 +1569,7 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     dim3 grid((unsigned)(nblk * nsplit));
     static const int env_nolin = getenv("PNP_CONV_NOLIN") ? 1 : 0;
     const bool lin = !env_nolin && a.stride == 1 && a.pad_mode == PNP_PAD_ZERO && (a.C % 4) == 0 && a.OW >= BK &&
-                     a.x_bytes < 0x80000000u;
+                     a.x_bytes < 0x80000000u && a.w_bytes < 0x80000000u;
     if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 3, VECB>), grid, dim3(NTHREADS), 0, st, a);
     else if (a.C % 4 == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 1, VECB>), grid, dim3(NTHREADS), 0, st, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 2, VECB>), grid, dim3(NTHREADS), 0, st, a);
