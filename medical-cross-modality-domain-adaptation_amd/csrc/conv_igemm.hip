@@ -5,7 +5,7 @@
 //
 // GEMM view (no im2col buffer is ever materialised):
 //   fwd  : Y[M=N*OH*OW][K]   = A[M][R*S*C] * Wm[R*S*C][K]       A gathered from x on the fly
-//   dgrad: the same kernel on dy with flipped/transposed filters (and zero-upsampled dy for stride>1)
+//   dgrad: the same kernel on dy with flipped/transposed filters; stride > 1: one stride-1 correlation per stride phase (plan_phases)
 //   wgrad: dW[R*S*C][K]      = At[R*S*C][P=N*OH*OW] * dY[P][K]  split over P across workgroups
 //
 // Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD = the 157 TF fp32 peak).
@@ -14,9 +14,15 @@
 // pipeline (Frag): ds_reads of slice q+1, the next stage's global loads and its LDS stores all fly under MFMAs; 1 barrier / stage.
 //
 // Kernels:
-//   conv_taps_kernel   3x3, stride 1, zero/VALID padding, C % 32 == 0 (forward and data gradient): taps unrolled, scalar offsets
-//   conv_fwd_kernel    everything else (any C, 5x5, strides, in-kernel SYMMETRIC mirror, zero-upsampled dy for strided dgrads)
-//   conv_wgrad_kernel  filter gradient; reduction over pixels split across workgroups + splitk_reduce_kernel
+//   conv_taps_kernel        zero/VALID padding, C % 32 == 0, filter shapes 1x1..3x3 / 5x5, any stride (forward, stride-1 data gradient,
+//                           stride-phase sub-filters): taps unrolled, scalar offsets; optional fused inference-BN epilogue
+//   conv_fwd_kernel         everything else on the matrix cores (any C, in-kernel SYMMETRIC mirror, filters smaller than the stride)
+//   conv_wgrad_kernel       filter gradient; reduction over pixels split across workgroups + splitk_reduce_kernel
+//   conv_fwd_narrow_kernel  K <= 16 outputs at stride 1 on the vector ALUs (LDS patch, filters through the scalar cache, v_pk_fma_f32)
+//   wgrad_direct(4)_kernel  filter gradient for K <= 16 on the vector ALUs (dy through the scalar cache) + splitk_reduce_many_kernel
+//   flip_transpose(_phase)_kernel, splitk_reduce(_scatter/_drop)_kernel, sympad_fwd/bwd_kernel, bn_fold_kernel, naive_conv_kernel
+// Host planners: choose_tile / choose_split (dispatch-round filling), plan_phases (strided data gradients), wgrad_plan_split, wgd_plan,
+// narrow_fwd_ok — their decisions are visible through the pnp_conv2d_*_workspace_bytes queries (tests/test_abi.py).
 //
 // LDS layouts (dwords):
 //   fwd  A tile  [BM][36]     row = output pixel, 32 k's contiguous (+4 pad). A fragments are read with
