@@ -79,12 +79,16 @@ def l2_multiplicity(name):
     return 1 if "/Variable" in name else 0
 
 
-def segmenter_forward(V, x, keep_prob=1.0, main_bn=True, adapt_bn=True, seed=0, n_class=5, taps=None):
-    """logits of Full_DRN.create_network.  V: dict of torch tensors (moving stats are updated in place when training)."""
+def segmenter_forward(V, x, keep_prob=1.0, main_bn=True, adapt_bn=True, seed=0, n_class=5, taps=None, operand_round=None):
+    """logits of Full_DRN.create_network.  V: dict of torch tensors (moving stats are updated in place when training).
+    operand_round (e.g. tf_ops.round_bf16): applied to both operands of every convolution, accumulation stays float32 — the
+    arithmetic of a bf16-MFMA mixed-precision path (BASELINE config 5), used to budget its tolerance on the CPU."""
     nm = _Namer()
     sid = [0]
 
     def conv(x, w, stride=1, dil=1, padding="SAME", keep=keep_prob):
+        if operand_round is not None:
+            x, w = operand_round(x), operand_round(w)
         y = T.conv2d(x, w, stride, dil, padding)
         s = sid[0]
         sid[0] += 1

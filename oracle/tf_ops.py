@@ -69,6 +69,12 @@ def conv2d(x, w, stride=1, dil=1, padding="SAME"):
     return y.permute(0, 2, 3, 1)
 
 
+def round_bf16(t):
+    """round-to-nearest-even to bfloat16 and back to float32: what a bf16 MFMA operand (or a bf16 tensor in HBM) holds.  Used only
+    to budget the tolerance of BASELINE config 5 (bf16 mixed precision) on the CPU; nothing on the fp32 path calls it."""
+    return t.to(torch.bfloat16).to(torch.float32) if t.dtype == torch.float32 else t
+
+
 def conv2d_dgrad_by_phases(dy, w, in_hw, stride, pad_t, pad_l):
     """Data gradient of a strided zero-padded conv, restated the way the HIP path computes it (csrc/conv_igemm.hip::plan_phases):
     dx[h] receives only the filter taps r with r = (h + pad) mod stride, so every residue class of pixels ("phase") is a stride-1
