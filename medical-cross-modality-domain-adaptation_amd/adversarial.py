@@ -364,14 +364,20 @@ class Full_DRN(object):
         self.ct_logits = o["ct_logits"]
         return self.ct_gen_loss
 
-    def evaluate(self, ct, ct_y, mr, mr_y, keep_prob=1.0):
-        """monitoring fetches (adversarial.py:101-116, 948-991): CT / MR Dice of the current segmenter, critic scores"""
+    def evaluate(self, ct, ct_y, mr, mr_y, keep_prob=1.0, detail=False):
+        """monitoring fetches that are not TensorBoard summaries (adversarial.py:101-116, 948-991): CT / MR hard Dice of the current
+        segmenter, with `detail` the CT confusion matrix.  Every segmenter BN in inference mode; the critics are not evaluated (nothing
+        here consumes their scores), so the forward has no side effect on any variable."""
+        from . import lib
         with torch.no_grad():
-            o = self._graph(mr, ct, keep_prob, mr_front_bn=False, joint_bn=False, ct_front_bn=False)
+            o = self._graph(mr, ct, keep_prob, mr_front_bn=False, joint_bn=False, ct_front_bn=False, critics=False)
             self.predicter, self.compact_pred = K.softmax_argmax(o["ct_logits"].contiguous())
             self.mr_seg_valid, self.compact_mr_valid = K.softmax_argmax(o["mr_logits"].contiguous())
             self.ct_dice_eval, self.ct_dice_eval_arr = _dice_eval(self.compact_pred, ct_y, self.n_class)
             self.mr_dice_eval, self.mr_dice_eval_arr = _dice_eval(self.compact_mr_valid, mr_y, self.n_class)
+            if detail:
+                self.compact_y = torch.argmax(ct_y, 3)
+                self.confusion_matrix = lib.confusion_matrix(self.compact_y, self.compact_pred, self.n_class)
         return float(self.ct_dice_eval), float(self.mr_dice_eval)
 
     def predict_ct(self, ct, ct_y):
@@ -429,6 +435,7 @@ class Full_DRN(object):
 
 
 contour_map = {"bg": 0, "la_myo": 1, "la_blood": 2, "lv_blood": 3, "aa": 4}     # adversarial.py:19-25
+verbose = True
 
 
 class _Null(object):
@@ -476,6 +483,7 @@ class Trainer(object):
         self.clip_mask = None
         self.global_step = 0
         self.step_times = []
+        self.loss_dict = {}
 
     def next_batch(self, source):
         from .tfrecord import SliceQueue
@@ -563,9 +571,8 @@ class Trainer(object):
                 self.step_times.append(time.time() - start)
                 logging.info("Training step %s epoch %s has been finished! Time elapsed %s seconds" % (step, epoch, time.time() - start))
                 if step % display_step == 0:
-                    ct_x, ct_y, _ = ct_val.next()
-                    mr_x, mr_y, _ = mr_val.next()
-                    self.net.evaluate(ct_x, ct_y, mr_x, mr_y)
+                    self.output_minibatch_stats(step, *ct_feed.next()[:2], *mr_feed.next()[:2])                # a training batch ...
+                    self.output_minibatch_stats(step, *ct_val.next()[:2], *mr_val.next()[:2], detail=True)     # ... and a validation batch
                 if step % tc.get("checkpoint_space", 100) == 0 and step != 0:
                     if self.rank == 0:
                         self.net.save(os.path.join(output_path, "checkpoint.npz"))
@@ -578,6 +585,14 @@ class Trainer(object):
             self.net.save(os.path.join(output_path, "checkpoint.npz"))
         barrier()
         return save_path
+
+    def output_minibatch_stats(self, step, ct_batch, ct_batch_y, mr_batch, mr_batch_y, detail=False):
+        """adversarial.py:948-991 without the TensorBoard writers: Dice of both domains, confusion matrix + per-organ report on `detail`"""
+        from .lib import _indicator_eval
+        ct_d, mr_d = self.net.evaluate(ct_batch, ct_batch_y, mr_batch, mr_batch_y, detail=detail)
+        self.loss_dict["val" if detail else "train"] = (step, ct_d, mr_d)
+        if detail:
+            _indicator_eval(self.net.confusion_matrix, verbose=verbose)
 
     # -- volume inference (SURVEY.md §8f-4) -------------------------------------------------------------------------------
     def _predict_batch(self, vol, slice_y):

@@ -83,3 +83,71 @@ def test_pretrain_phase_freezes_adaptation_module():
     assert all(not v.trainable for v in n.adapt_vars)
     assert n.lambda_mask_loss == 0.0
     assert {v.name.split("/")[0] for v in n.store.trainable()} == {"cls_scope", "mask_cls_scope"}
+
+
+def test_gan_training_schedule_with_stub_steps(tmp_path):
+    """adversarial.py:831-946 on the CPU with the two step functions stubbed out: no update at step 0, discriminator before generator,
+    sub-iteration growth every `iter_upd_interval` steps, a training + a validation monitoring batch every display_step, learning-rate
+    decay with every periodic checkpoint, one fresh batch per (sub-)step."""
+    import numpy as np
+    import torch
+    adv = pkg("adversarial")
+
+    class Src(object):
+        def __init__(self, tag):
+            self.tag, self.n = tag, 0
+
+        def next_batch(self, B):
+            self.n += 1
+            b = np.zeros((B, 4, 4, 4), np.float32)
+            b[..., 0] = self.n
+            return b, ["%s%d" % (self.tag, self.n)] * B
+
+    class Opt(object):
+        lr = 1.0
+
+    class Net(object):
+        device = torch.device("cpu")
+        n_class = 5
+        saved = 0
+
+        def evaluate(self, ct, ct_y, mr, mr_y, keep_prob=1.0, detail=False):
+            events.append(("eval", detail))
+            self.confusion_matrix = np.eye(5)
+            return 0.5, 0.5
+
+        def save(self, path):
+            Net.saved += 1
+            return path
+
+    events = []
+    srcs = {k: Src(k) for k in ("mr_t", "mr_v", "ct_t", "ct_v")}
+    tr = adv.Trainer(Net(), srcs["mr_t"], srcs["mr_v"], srcs["ct_t"], srcs["ct_v"], num_cls=5, batch_size=2, opt_kwargs={"learning_rate": 1.0},
+                     train_config={"dis_interval": 1, "gen_interval": 2, "dis_sub_iter": 2, "gen_sub_iter": 1, "dis_sub_iter_inc": 1,
+                                   "gen_sub_iter_inc": 0, "iter_upd_interval": 4, "checkpoint_space": 3, "lr_decay_factor": 0.5})
+    tr.dis_optimizer, tr.gen_optimizer = Opt(), Opt()
+    tr.dis_step = lambda mr, ct, dropout, seed: events.append(("dis", float(mr[0, 0, 0, 0]), float(ct[0, 0, 0, 0]), seed))
+    tr.gen_step = lambda ct, dropout, seed: events.append(("gen", float(ct[0, 0, 0, 0]), seed))
+    adv.verbose = False
+    try:
+        tr.train(str(tmp_path / "o"), restore=False, training_iters=7, epochs=1, display_step=5)
+    finally:
+        adv.verbose = True
+    per_step, cur = [], []
+    # rebuild the per-step grouping from the order of events: evals close a display step
+    kinds = [e[0] + ("*" if e[0] == "eval" and e[1] else "") for e in events]
+    # step 0: only the two monitoring batches; steps 1..6: dis x2 (x3 from step 5 on: growth at step 4 applies afterwards), gen on even steps
+    expect = (["eval", "eval*"]                                  # step 0
+              + ["dis", "dis"]                                     # 1
+              + ["dis", "dis", "gen"]                              # 2
+              + ["dis", "dis"]                                     # 3
+              + ["dis", "dis", "gen"]                              # 4 (sub-iterations grow AFTER this step's updates)
+              + ["dis", "dis", "dis", "eval", "eval*"]            # 5 (display step)
+              + ["dis", "dis", "dis", "gen"])                      # 6
+    assert kinds == expect, kinds
+    seeds = [e[-1] for e in events if e[0] in ("dis", "gen")]
+    assert seeds == list(range(seeds[0], seeds[0] + len(seeds)))          # one dropout stream per update
+    ct_used = [e[2] for e in events if e[0] == "dis"] + [e[1] for e in events if e[0] == "gen"]
+    assert len(set(ct_used)) == len(ct_used)                              # every update sees a fresh CT batch
+    assert tr.dis_optimizer.lr == 0.25 and tr.gen_optimizer.lr == 0.25    # checkpoints at steps 3 and 6
+    assert Net.saved == 3                                                 # steps 3, 6 and the final one
