@@ -272,3 +272,70 @@ def test_stride_phase_data_gradient_restatement():
                     assert torch.allclose(got, x.grad, rtol=1e-10, atol=1e-10), (stride, R, S, H, W, padding)
                     cases += 1
     assert cases > 200
+
+
+def test_segmenter_training_schedule_with_stub_step(tmp_path):
+    """source_segmenter.py:474-523 on the CPU with the train step stubbed out: one dequeued batch per step, the train-batch and
+    validation monitoring forwards every display_step (the first in BN TRAIN mode like the reference), loss fetched one step late
+    but for every step, final checkpoint by rank 0."""
+    ss = pkg("source_segmenter")
+
+    class Src(object):
+        def __init__(self):
+            self.n = 0
+
+        def next_batch(self, B):
+            self.n += 1
+            b = np.zeros((B, 4, 4, 4), np.float32)
+            b[..., 0] = self.n
+            b[..., 3] = self.n % 5
+            return b, ["f%d" % self.n] * B
+
+    events = []
+
+    class Net(object):
+        device = torch.device("cpu")
+        cost = torch.tensor(1.0)
+        dice_eval = torch.tensor(0.5)
+        confusion_matrix = np.eye(5)
+
+        def evaluate(self, x, y, keep_prob=1.0, main_bn=True, adapt_bn=True, want_confusion=False):
+            events.append(("eval", main_bn, adapt_bn, want_confusion, float(x[0, 0, 0, 0])))
+            assert tuple(y.shape) == (2, 4, 4, 5) and float(y.sum()) == 2 * 16          # one-hot labels made on the device side
+            return self.cost
+
+        def save(self, path):
+            events.append(("save",))
+            return path
+
+    class Opt(object):
+        lr = 1e-3
+
+    tr = ss.Trainer(Net(), Src(), Src(), num_cls=5, batch_size=2, optimizer="adam", opt_kwargs={"learning_rate": 1e-3})
+    tr.opt = Opt()
+    tr.train_step = lambda bx, by, dropout, step: (events.append(("step", step, float(bx[0, 0, 0, 0]), dropout)), torch.tensor(float(step)))[1]
+    logged = []
+    import logging
+    h = logging.Handler()
+    h.emit = lambda rec: logged.append(rec.getMessage())
+    logging.getLogger().addHandler(h)
+    lvl = logging.getLogger().level
+    logging.getLogger().setLevel(logging.INFO)
+    ss_verbose = ss.verbose
+    try:
+        tr.train(str(tmp_path / "o"), restore=False, training_iters=7, epochs=1, display_step=5, dropout=0.75)
+    finally:
+        logging.getLogger().removeHandler(h)
+        logging.getLogger().setLevel(lvl)
+        ss.verbose = ss_verbose
+    kinds = [e[0] for e in events]
+    assert kinds == ["step", "eval", "eval"] + ["step"] * 4 + ["step", "eval", "eval"] + ["step", "save"], kinds
+    steps = [e for e in events if e[0] == "step"]
+    assert [e[1] for e in steps] == list(range(7)) and [e[2] for e in steps] == [float(i) for i in range(1, 8)] and steps[0][3] == 0.75
+    evals = [e for e in events if e[0] == "eval"]
+    assert evals[0][1:4] == (True, True, False) and evals[0][4] == 1.0        # train batch of step 0, BN train mode
+    assert evals[1][1:4] == (False, False, True)                             # validation batch, inference mode, confusion matrix
+    assert evals[2][4] == 6.0                                                # train batch of step 5
+    losses = [m for m in logged if m.startswith("Training at step")]
+    assert len(losses) == 7 and "step 6 " in losses[-1] and "6.0000" in losses[-1]
+    assert len(tr.step_times) == 7
