@@ -108,3 +108,10 @@ def test_host_planners_through_the_workspace_queries(built):
     logits = K.conv_geom((16, 260, 260, 40), (5, 5, 40, 5), 1, 1, "VALID")
     assert wgr(logits) == 2048 * 5 * 5 * 40 * 5 * 4
     assert lib.pnp_conv2d_dgrad_workspace_bytes(None) == 0 and lib.pnp_conv2d_fwd_workspace_bytes(None) == 0
+
+
+def test_documents_quote_the_current_abi_size(built):
+    n = len(built._lib.PROTOTYPES)
+    for doc in ("README.md", "DESIGN.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        assert ("%d entry points" % n in text) or ("%d `extern \"C\"` entry points" % n in text) or ("all %d symbols" % n in text), doc
