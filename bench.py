@@ -9,6 +9,9 @@ BN in training mode — exactly `sess.run(optimizer)` of source_segmenter.py:484
 maps already resident in HBM.  Weak scaling: every rank processes its own 16 slices; gradients are all-reduced over RCCL.
 One JSON line is printed by rank 0, carrying `roofline` (dominant kernel: the 3x3 fp32-MFMA forward convolution, timed live
 with HIP events around each of its launches inside the timed region) and `cpu_baseline` (the CPU oracle on the host cores).
+
+`--workload gan` measures BASELINE configs[3] on the same contract instead: the joint step (1 discriminator update on B MR + B CT
+slices, weight clip, 1 generator update on B CT slices; adversarial.py:839-882), B slices counted per step; no cpu_baseline there.
 """
 import argparse
 import importlib
