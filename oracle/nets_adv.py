@@ -14,8 +14,9 @@ CRITIC_KEEP = 0.75
 
 
 class _Ctx(object):
-    def __init__(self, V, keep_prob, seed):
+    def __init__(self, V, keep_prob, seed, critic_keep=CRITIC_KEEP):
         self.V, self.keep, self.seed, self.sid = V, keep_prob, seed, 0
+        self.critic_keep = critic_keep
 
     def conv(self, x, w, stride=1, dil=1, padding="SAME", keep=None):
         y = T.conv2d(x, w, stride, dil, padding)
@@ -84,29 +85,31 @@ def _classifier(c, c4, c6, b7, c9, logits):
     h = x
     for k, kd, sd in spec:
         s = p + "cls_%d/" % k
-        h = c.rb(h, V[s + "Variable"], V[s + "Variable_1"], s + "cls_%d" % k, True, keep=CRITIC_KEEP)
-        h = c.cbr(h, V[s + "Variable_2"], s + "cls_%d_3" % k, True, stride=sd, keep=CRITIC_KEEP)
-    h = c.cbr(h, V[p + "cls_6/Variable"], p + "cls_6/cls_6", True, stride=2, padding="SYMMETRIC", keep=CRITIC_KEEP)
+        h = c.rb(h, V[s + "Variable"], V[s + "Variable_1"], s + "cls_%d" % k, True, keep=c.critic_keep)
+        h = c.cbr(h, V[s + "Variable_2"], s + "cls_%d_3" % k, True, stride=sd, keep=c.critic_keep)
+    h = c.cbr(h, V[p + "cls_6/Variable"], p + "cls_6/cls_6", True, stride=2, padding="SYMMETRIC", keep=c.critic_keep)
     return h.reshape(h.shape[0], -1) @ V[p + "cls_out/Variable"]
 
 
 def _mask_critic(c, logits):
     V = c.V
     p = "mask_cls_scope/"
-    h = c.cbr(logits, V[p + "mask_cls_1/Variable"], p + "mask_cls_1/mask_cls_1", True, stride=2, keep=CRITIC_KEEP)
+    h = c.cbr(logits, V[p + "mask_cls_1/Variable"], p + "mask_cls_1/mask_cls_1", True, stride=2, keep=c.critic_keep)
     s = p + "mask_cls_2/"
-    h = c.rb(h, V[s + "Variable"], V[s + "Variable_1"], s + "m_cls_2", True, keep=CRITIC_KEEP)
-    h = c.cbr(h, V[s + "Variable_2"], s + "m_cls_2_3", True, stride=4, keep=CRITIC_KEEP)
+    h = c.rb(h, V[s + "Variable"], V[s + "Variable_1"], s + "m_cls_2", True, keep=c.critic_keep)
+    h = c.cbr(h, V[s + "Variable_2"], s + "m_cls_2_3", True, stride=4, keep=c.critic_keep)
     s = p + "mask_cls_3/"
-    h = c.rb(h, V[s + "Variable"], V[s + "Variable_1"], s + "m_cls_3", True, keep=CRITIC_KEEP)
-    h = c.cbr(h, V[s + "Variable_2"], s + "m_cls_3_3", True, stride=4, keep=CRITIC_KEEP)
-    h = c.cbr(h, V[p + "mask_cls_4/Variable"], p + "mask_cls_4/m_cls_4", True, stride=4, padding="SYMMETRIC", keep=CRITIC_KEEP)
+    h = c.rb(h, V[s + "Variable"], V[s + "Variable_1"], s + "m_cls_3", True, keep=c.critic_keep)
+    h = c.cbr(h, V[s + "Variable_2"], s + "m_cls_3_3", True, stride=4, keep=c.critic_keep)
+    h = c.cbr(h, V[p + "mask_cls_4/Variable"], p + "mask_cls_4/m_cls_4", True, stride=4, padding="SYMMETRIC", keep=c.critic_keep)
     return h.reshape(h.shape[0], -1) @ V[p + "m_cls_out/Variable"]
 
 
-def adv_forward(V, mr, ct, keep_prob, mr_front_bn=False, joint_bn=False, ct_front_bn=False, seed=0, segmenter_no_grad=False):
-    """the graph of adversarial.py:82-119 for the fed branches (mr or ct may be None)"""
-    c = _Ctx(V, keep_prob, seed)
+def adv_forward(V, mr, ct, keep_prob, mr_front_bn=False, joint_bn=False, ct_front_bn=False, seed=0, segmenter_no_grad=False,
+                critic_keep=CRITIC_KEEP):
+    """the graph of adversarial.py:82-119 for the fed branches (mr or ct may be None).  critic_keep: the critics' dropout keep
+    probability — 0.75 in the reference (the builders' default argument, adversarial.py:320,402); 1.0 only for the golden fixtures."""
+    c = _Ctx(V, keep_prob, seed, critic_keep)
     out = {}
     ctx = torch.no_grad() if segmenter_no_grad else torch.enable_grad()
     with ctx:

@@ -5,8 +5,9 @@ time; nothing is copied into the repo) over a small numpy/torch stand-in for the
 What this pins: the op SEQUENCES and wiring of the reference — ops.PS (ops.py:3-27), layers.residual_block / DR_block /
 conv_bn_relu2d / conv2d(SYMMETRIC) (layers.py), lib._label_decomp / _dice / _jaccard (lib.py),
 source_segmenter.Full_DRN.create_network + _get_cost (source_segmenter.py:48-273, exec'd from the file text because the
-module itself has SyntaxErrors at lines 611/619), and the TF variable names recorded in lists/{old_bn_list,pred_bn_list,
-half_zip_*_vars}.  What it cannot pin: the arithmetic of the TF ops themselves (TF-1.4 is not installable here) — the
+module itself has SyntaxErrors at lines 611/619), adversarial.Full_DRN's create_zip_network / create_second_half /
+create_classifier / create_mask_critic / _get_cost (adversarial.py:127-476, exec'd the same way because __init__ dies on
+`self.predicter`), and the TF variable names recorded in lists/{old_bn_list,pred_bn_list,half_zip_*_vars}.  What it cannot pin: the arithmetic of the TF ops themselves (TF-1.4 is not installable here) — the
 stand-in implements them with oracle.tf_ops, i.e. the same restatement the oracle uses ("parity unpinned").
 
 Run in the build container:  python tests/golden/make_golden.py
@@ -65,6 +66,7 @@ class Graph(object):
         self.nscope, self.vscope = [], []
         self.uniq = {}
         self.training_flags = {}
+        self.name_init = None     # optional (name, shape) -> array: variable values as a pure function of the TF name
 
     def unique(self, base, var_scope):
         pre = "/".join(s for s in (self.vscope if var_scope else self.nscope) if s)
@@ -98,6 +100,7 @@ def make_tf(seed=0, weight_scale=None):
     tf.concat = lambda xs, axis, name=None: ft(np.concatenate([np.asarray(a) for a in xs], axis))
     tf.expand_dims = lambda x, a: ft(np.expand_dims(np.asarray(x), a))
     tf.exp = lambda x: ft(np.exp(np.asarray(x)))
+    tf.matmul = lambda a, b: ft(np.asarray(a, dtype=np.float32) @ np.asarray(b, dtype=np.float32))
     tf.log = lambda x: ft(np.log(np.asarray(x)))
     tf.reduce_sum = lambda x, axis=None, keep_dims=False: ft(np.sum(np.asarray(x), axis=axis, keepdims=keep_dims, dtype=np.float32))
     tf.reduce_mean = lambda x, axis=None: ft(np.mean(np.asarray(x), axis=axis, dtype=np.float32))
@@ -132,8 +135,10 @@ def make_tf(seed=0, weight_scale=None):
     tf.truncated_normal_initializer = lambda stddev=1.0: (lambda shape: truncated_normal(shape, stddev))
 
     def Variable(initial, trainable=True, name=None):
-        nm = G.unique("Variable", False)
+        nm = G.unique(name or "Variable", False)
         v = ft(np.array(initial, dtype=np.float32))
+        if G.name_init is not None and v.ndim >= 2:
+            v = ft(G.name_init(nm, v.shape))
         G.vars[nm] = v
         return v
     tf.Variable = Variable
@@ -142,7 +147,7 @@ def make_tf(seed=0, weight_scale=None):
         pre = "/".join(s for s in G.vscope if s)
         nm = (pre + "/" + name) if pre else name
         if nm not in G.vars:
-            G.vars[nm] = initializer(shape)
+            G.vars[nm] = initializer(shape) if G.name_init is None else ft(G.name_init(nm, tuple(shape)))
         return G.vars[nm]
     tf.get_variable = get_variable
 
@@ -237,6 +242,76 @@ def load_reference_module(name, tf):
 
 def he(w):
     return (w * (np.sqrt(2.0 / (w.shape[0] * w.shape[1] * w.shape[2])) / 0.01 * 0.9)).astype(np.float32) if w.ndim == 4 else w
+
+
+def name_init(name, shape):
+    """variable values as a pure function of the TF variable name (so that the test side can rebuild them without replaying the
+    creation order): N(0,1) from default_rng(crc32(name)), scaled sqrt(2/fan_in)*0.9 for filters, 1/sqrt(fan_in) for FC matrices"""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    w = rng.standard_normal(size=tuple(shape))
+    fan = int(np.prod(shape[:-1]))
+    return (w * (np.sqrt(2.0 / fan) * 0.9 if len(shape) == 4 else 1.0 / np.sqrt(fan))).astype(np.float32)
+
+
+def golden_adaptation_graph(out, meta):
+    """adversarial.Full_DRN's four graph builders + _get_cost (adversarial.py:127-476), exec'd from the file text because __init__ itself
+    dies on `self.predicter` (line 95): MR front, CT front, shared second half on both, feature critic and mask critic on both domains,
+    WGAN losses and L2 terms.  keep_prob 1 everywhere (TF's dropout RNG is not reproducible), critic BN on batch statistics."""
+    tf = make_tf(9)
+    G.name_init = name_init
+    layers = load_reference_module("layers", tf)
+    ops = load_reference_module("ops", tf)
+    lib = load_reference_module("lib", tf)
+    lines = open(os.path.join(REF, "adversarial.py")).read().split("\n")
+    cls_src = "\n".join(lines[43:476])           # `class Full_DRN(object):` ... end of _get_cost (file lines 44-476)
+    ns = {"tf": tf, "np": np, "raw_size": [256, 256, 3], "volume_size": [256, 256, 3], "label_size": [256, 256, 1],
+          "_dice_eval": lib._dice_eval}
+    for m in (layers, ops):
+        ns.update({k: v for k, v in m.__dict__.items() if not k.startswith("__")})
+    exec(compile(cls_src, "adversarial.py[44:476]", "exec"), ns)
+    Full_DRN = ns["Full_DRN"]
+    B = 2
+    rng = np.random.default_rng(33)
+    mr = rng.standard_normal((B, 256, 256, 3)).astype(np.float32)
+    ct = (rng.standard_normal((B, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32)
+    net = Full_DRN.__new__(Full_DRN)
+    net.n_class, net.batch_size = 5, B
+    net.mr_front_weights, net.ct_front_weights, net.cls_weights, net.m_cls_weights, net.joint_weights = [], [], [], [], []
+    net.mr, net.ct, net.keep_prob = ft(mr), ft(ct), 1.0
+    mr_c4, ct_c4, mr_c6, ct_c6 = net.create_zip_network(input_channel=3, feature_base=16, num_cls=5, keep_prob=1.0, main_bn=False,
+                                                        main_trainable=False, adapt_bn=True, adapt_trainable=True)
+    with tf.variable_scope("", reuse=tf.AUTO_REUSE):
+        ct_c9, ct_b8, ct_b7, ct_logits = net.create_second_half(ct_c6, feature_base=16, input_channel=3, num_cls=5, keep_prob=1.0,
+                                                                joint_bn=False, joint_trainable=False)
+        mr_c9, mr_b8, mr_b7, mr_logits = net.create_second_half(mr_c6, feature_base=16, input_channel=3, num_cls=5, keep_prob=1.0,
+                                                                joint_bn=False, joint_trainable=False)
+    with tf.variable_scope("cls_scope", reuse=tf.AUTO_REUSE):
+        ct_cls = net.create_classifier(ct_c4, ct_c6, ct_b7, ct_c9, ct_logits, keep_prob=1.0)
+        mr_cls = net.create_classifier(mr_c4, mr_c6, mr_b7, mr_c9, mr_logits, keep_prob=1.0)
+    with tf.variable_scope("mask_cls_scope", reuse=tf.AUTO_REUSE):
+        ct_mask = net.create_mask_critic(ct_logits, num_cls=5, keep_prob=1.0)
+        mr_mask = net.create_mask_critic(mr_logits, num_cls=5, keep_prob=1.0)
+    ck = {"miu_dis": 0.002, "miu_gen": 0.002, "lambda_mask_loss": 0.3, "regularizer": 1e-4, "gan_regularizer": 1e-4}
+    dis_loss, gen_loss, fixed_reg, dis_reg, gen_reg = net._get_cost(ct_logits, mr_logits, ct_cls, mr_cls, ct_mask, mr_mask, dict(ck))
+
+    def names_of(ws):
+        return [[k for k, v in G.vars.items() if v is w][0] for w in ws]
+    meta["adv_var_order"] = list(G.vars.keys())
+    meta["adv_var_shapes"] = {k: list(np.asarray(v).shape) for k, v in G.vars.items()}
+    meta["adv_lists"] = {"mr_front_weights": names_of(net.mr_front_weights), "ct_front_weights": names_of(net.ct_front_weights),
+                         "cls_weights": names_of(net.cls_weights), "m_cls_weights": names_of(net.m_cls_weights),
+                         "joint_weights": names_of(net.joint_weights)}
+    meta["adv_cost_kwargs"] = ck
+    meta["adv_scalars"] = {"dis_loss": float(dis_loss), "gen_loss": float(gen_loss), "fixed_coeff_reg": float(fixed_reg),
+                           "dis_reg": float(dis_reg), "gen_reg": float(gen_reg)}
+    for tag, v in (("ct_cls", ct_cls), ("mr_cls", mr_cls), ("ct_mask", ct_mask), ("mr_mask", mr_mask)):
+        out["adv_" + tag] = np.asarray(v, dtype=np.float32)
+    out["adv_ct_logits_sub"] = np.asarray(ct_logits)[:, ::16, ::16, :].copy()
+    out["adv_mr_logits_sub"] = np.asarray(mr_logits)[:, ::16, ::16, :].copy()
+    out["adv_ct_c4_sub"] = np.asarray(ct_c4)[:, ::4, ::4, ::8].copy()
+    out["adv_mr_c6_sub"] = np.asarray(mr_c6)[:, ::4, ::4, ::16].copy()
+    G.name_init = None
 
 
 def main():
@@ -334,6 +409,9 @@ def main():
     out["seg_logits_sub"] = lg[:, ::8, ::8, :].copy()
     out["seg_argmax"] = np.asarray(net.compact_pred).astype(np.uint8)
     meta["seg_var_l2norm"] = {k: float(np.sqrt((np.asarray(v, dtype=np.float64) ** 2).sum())) for k, v in G.vars.items() if "Variable" in k}
+
+    # ---- the adaptation graph (both domains, both critics, WGAN losses) from adversarial.py's own builders ---------------
+    golden_adaptation_graph(out, meta)
 
     # ---- TF variable names recorded by the reference authors -----------------------------------------------------------
     for f in ("old_bn_list", "pred_bn_list", "half_zip_mri_vars", "half_zip_ct_vars"):

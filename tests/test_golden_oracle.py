@@ -144,3 +144,68 @@ def test_oracle_segmenter_matches_reference_graph(gold):
     assert abs(float(cost) - s["cost"]) < 1e-5 and abs(float(reg) - s["reg"]) < 1e-6 * s["reg"]
     assert abs(float(wl) - s["weighted_loss"]) < 1e-5 and abs(float(dl) - s["dice_loss"]) < 1e-5
     assert abs(float(de) - s["dice_eval"]) < 1e-5
+
+
+def _name_init(name, shape):
+    """== tests/golden/make_golden.py::name_init"""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    w = rng.standard_normal(size=tuple(shape))
+    fan = int(np.prod(shape[:-1]))
+    return (w * (np.sqrt(2.0 / fan) * 0.9 if len(shape) == 4 else 1.0 / np.sqrt(fan))).astype(np.float32)
+
+
+def test_oracle_adaptation_graph_matches_reference_builders(gold):
+    """the adaptation model: MR front + CT front + shared half on both + feature critic + mask critic + WGAN losses + L2 terms, as
+    produced by adversarial.py's OWN create_zip_network / create_second_half / create_classifier / create_mask_critic / _get_cost
+    (exec'd over the stand-in tf), against oracle/nets_adv.py on the same name-derived variables."""
+    from oracle import nets_adv
+    z, meta = gold
+    shapes = meta["adv_var_shapes"]
+    V = {}
+    for k in meta["adv_var_order"]:
+        s = tuple(shapes[k])
+        if len(s) >= 2:
+            V[k] = torch.from_numpy(_name_init(k, s))
+        elif k.endswith(("gamma", "moving_variance")):
+            V[k] = torch.ones(s)
+        elif len(s) == 1:
+            V[k] = torch.zeros(s)
+    rng = np.random.default_rng(33)
+    mr = torch.from_numpy(rng.standard_normal((2, 256, 256, 3)).astype(np.float32))
+    ct = torch.from_numpy((rng.standard_normal((2, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32))
+    with torch.no_grad():
+        o = nets_adv.adv_forward(V, mr, ct, 1.0, mr_front_bn=False, joint_bn=False, ct_front_bn=True, critic_keep=1.0)
+        dis, gen = nets_adv.wgan_losses(o, 0.002, 0.002, 0.3)
+    for tag in ("ct_cls", "mr_cls", "ct_mask", "mr_mask"):
+        ref = z["adv_" + tag]
+        assert tuple(o[tag].shape) == ref.shape == (2, 1)
+        assert np.abs(o[tag].numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), (tag, o[tag].numpy().ravel(), ref.ravel())
+    assert np.abs(o["ct_logits"].numpy()[:, ::16, ::16, :] - z["adv_ct_logits_sub"]).max() < 1e-4 * np.abs(z["adv_ct_logits_sub"]).max()
+    assert np.abs(o["mr_logits"].numpy()[:, ::16, ::16, :] - z["adv_mr_logits_sub"]).max() < 1e-4 * np.abs(z["adv_mr_logits_sub"]).max()
+    s = meta["adv_scalars"]
+    assert abs(float(dis) - s["dis_loss"]) < 1e-6 + 1e-4 * abs(s["dis_loss"]) and abs(float(gen) - s["gen_loss"]) < 1e-6 + 1e-4 * abs(s["gen_loss"])
+    # L2 terms: sum over the reference's own (duplicated) weight lists == the oracle's per-variable coefficients
+    ck = meta["adv_cost_kwargs"]
+    l2 = lambda n: float(0.5 * (V[n].double() ** 2).sum())
+    dis_reg = sum(nets_adv.l2_coefficient(n, "dis", ck["miu_dis"], ck["gan_regularizer"], ck["lambda_mask_loss"]) * l2(n) for n in V if "Variable" in n)
+    gen_reg = sum(nets_adv.l2_coefficient(n, "gen", ck["miu_gen"], ck["gan_regularizer"], ck["lambda_mask_loss"]) * l2(n) for n in V if "Variable" in n)
+    assert abs(dis_reg - s["dis_reg"]) < 1e-5 * s["dis_reg"] and abs(gen_reg - s["gen_reg"]) < 1e-5 * s["gen_reg"]
+    L = meta["adv_lists"]
+    assert all(L["cls_weights"].count(n) == 2 for n in set(L["cls_weights"])) and all(L["m_cls_weights"].count(n) == 2 for n in set(L["m_cls_weights"]))
+    assert L["joint_weights"] == [] and len(set(L["ct_front_weights"])) == len(L["ct_front_weights"]) == 21
+
+
+def test_product_adaptation_variables_match_reference_builders(gold):
+    """every variable the reference's builders create (name, shape, creation order) == the product's symbolic build on the CPU"""
+    _, meta = gold
+    adv = pkg("adversarial")
+    net = adv.Full_DRN(channels=3, n_class=5, batch_size=2, device="cpu",
+                       cost_kwargs={"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.3},
+                       network_config={"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True,
+                                       "cls_trainable": True, "m_cls_trainable": True})
+    ref_names = [n for n in meta["adv_var_order"] if n not in ("miu_dis", "miu_gen")]       # the two scalar coefficients are plain floats here
+    mine = list(net.store.vars.keys())
+    assert mine == ref_names
+    for n in ref_names:
+        assert list(net.store.vars[n].shape) == meta["adv_var_shapes"][n], n
