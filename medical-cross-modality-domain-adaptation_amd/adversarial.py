@@ -267,9 +267,10 @@ class Full_DRN(object):
         return m_cls_logits
 
     # ---- the graph of adversarial.py:82-119, executed eagerly ---------------------------------------------------------------
-    def _graph(self, mr, ct, keep_prob, mr_front_bn, joint_bn, ct_front_bn, record=False, segmenter_no_grad=False, drop_seed=0, critics=True):
+    def _graph(self, mr, ct, keep_prob, mr_front_bn, joint_bn, ct_front_bn, record=False, segmenter_no_grad=False, drop_seed=0, critics=True, critic_keep=None):
         """mr / ct: [B,256,256,3] (either may be None: pruned branch).  Returns dict of critic logits and segmenter logits."""
         st = self.store
+        ckw = {} if critic_keep is None else {"keep_prob": critic_keep}     # None: the builders' own default (0.75, adversarial.py:320,402)
         self._lists = {"mr_front_weights": [], "ct_front_weights": [], "cls_weights": [], "m_cls_weights": [], "joint_weights": []}
         nc = self.n_class
         out = {}
@@ -294,13 +295,13 @@ class Full_DRN(object):
                     if br in feats:
                         c9, b8, b7, lg = feats[br]
                         out[br + "_cls"] = self.create_classifier(z[br + "_c4"], z[br + "_c6"], b7, c9, lg, feature_base=self.feature_base,
-                                                                  cls_trainable=self.cls_trainable)
+                                                                  cls_trainable=self.cls_trainable, **ckw)
                         out[br + "_logits"] = lg
             with st.variable_scope("mask_cls_scope"):
                 for br in ("ct", "mr"):
                     if br in feats:
                         out[br + "_mask"] = self.create_mask_critic(feats[br][3], feature_base=self.feature_base, num_cls=nc,
-                                                                    m_cls_trainable=self.m_cls_trainable)
+                                                                    m_cls_trainable=self.m_cls_trainable, **ckw)
         return out
 
     # ---- adversarial.py:478-501 ------------------------------------------------------------------------------------------

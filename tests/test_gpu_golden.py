@@ -45,3 +45,37 @@ def test_hip_ps_vs_reference_op_sequence_golden(dev):
         x = np.arange(B * a * b * nc * r * r, dtype=np.float32).reshape(B, a, b, nc * r * r)
         y = K.ps_fwd(torch.from_numpy(x).to(dev), r, nc).cpu().numpy()
         assert np.array_equal(y, z[tag + "_out"]), tag
+
+
+def test_hip_adaptation_graph_vs_reference_builders_golden(dev):
+    """the HIP path of the whole adaptation graph (both fronts, shared half, feature critic, mask critic, WGAN losses) against the
+    fixtures produced by adversarial.py's own builders (keep_prob 1 everywhere, critic BN on batch statistics)"""
+    from test_golden_oracle import _name_init
+    z = np.load(os.path.join(HERE, "golden", "golden.npz"))
+    meta = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+    adv = pkg("adversarial")
+    ck = meta["adv_cost_kwargs"]
+    net = adv.Full_DRN(channels=3, n_class=5, batch_size=2, device=dev, cost_kwargs=dict(ck),
+                       network_config={"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True,
+                                       "cls_trainable": True, "m_cls_trainable": True})
+    sd = net.store.state_dict()
+    for k in sd:
+        if sd[k].ndim >= 2:
+            sd[k] = _name_init(k, sd[k].shape)
+    net.store.load_state_dict(sd)
+    rng = np.random.default_rng(33)
+    mr = torch.from_numpy(rng.standard_normal((2, 256, 256, 3)).astype(np.float32)).to(dev)
+    ct = torch.from_numpy((rng.standard_normal((2, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        o = net._graph(mr, ct, 1.0, mr_front_bn=False, joint_bn=False, ct_front_bn=True, critic_keep=1.0)
+    for tag in ("ct_cls", "mr_cls", "ct_mask", "mr_mask"):
+        ref = z["adv_" + tag]
+        got = o[tag].cpu().numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 5e-4 * max(1.0, np.abs(ref).max()), (tag, got.ravel(), ref.ravel())
+    for br in ("ct", "mr"):
+        ref = z["adv_%s_logits_sub" % br]
+        assert np.abs(o[br + "_logits"].cpu().numpy()[:, ::16, ::16, :] - ref).max() < 1e-4 * np.abs(ref).max()
+    s = meta["adv_scalars"]
+    dis = -ck["miu_dis"] * float((o["mr_cls"] - o["ct_cls"]).mean()) - ck["lambda_mask_loss"] * ck["miu_dis"] * float((o["mr_mask"] - o["ct_mask"]).mean())
+    gen = -ck["miu_gen"] * float(o["ct_cls"].mean()) - ck["lambda_mask_loss"] * ck["miu_gen"] * float(o["ct_mask"].mean())
+    assert abs(dis - s["dis_loss"]) < 1e-6 + 5e-4 * abs(s["dis_loss"]) and abs(gen - s["gen_loss"]) < 1e-6 + 5e-4 * abs(s["gen_loss"])
