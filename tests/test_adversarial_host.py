@@ -151,3 +151,37 @@ def test_gan_training_schedule_with_stub_steps(tmp_path):
     assert len(set(ct_used)) == len(ct_used)                              # every update sees a fresh CT batch
     assert tr.dis_optimizer.lr == 0.25 and tr.gen_optimizer.lr == 0.25    # checkpoints at steps 3 and 6
     assert Net.saved == 3                                                 # steps 3, 6 and the final one
+
+
+def test_baseline_hand_off_follows_the_reference_lists():
+    """train_gan.py --phase pre-train (adversarial.py:706-765) with the reference's OWN lists: every BatchNorm_k of the source segmenter
+    lands on the pred_*/adapt-era name at the same list position (group_<n>/ prefix rebuilt from the name like the reference does), conv
+    filters go across by name, and the MR early layers are copied onto the CT adaptation module pairwise (half_zip_mri_vars ->
+    half_zip_ct_vars)."""
+    adv, ss = pkg("adversarial"), pkg("source_segmenter")
+    meta = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+    old_bn, new_bn = meta["list_old_bn_list"], meta["list_pred_bn_list"]
+    mr_vars, ct_vars = meta["list_half_zip_mri_vars"], meta["list_half_zip_ct_vars"]
+    assert len(old_bn) == len(new_bn) == 120 and len(mr_vars) == len(ct_vars)
+    seg = ss.Full_DRN(channels=3, n_class=5, batch_size=2, device="cpu", cost_kwargs={"regularizer": 1e-4})
+    rng = np.random.default_rng(0)
+    seg_state = {k: rng.standard_normal(v.shape).astype(np.float32) for k, v in seg.store.state_dict().items()}
+    net = adv.Full_DRN(channels=3, n_class=5, batch_size=2, cost_kwargs=dict(COST), network_config=dict(NETCFG), device="cpu")
+    before = net.store.state_dict()
+    net.load_baseline(seg_state, old_bn, new_bn, ct_vars, mr_vars)
+    after = net.store.state_dict()
+    strip = lambda n: n.split(":")[0]
+    for o, n in zip(old_bn, new_bn):
+        n = strip(n)
+        tgt = "group_" + n.split("_")[1] + "/" + n                     # adversarial.py:753-755
+        assert tgt in after, tgt
+        assert np.array_equal(after[tgt], seg_state[strip(o)]), (o, tgt)
+    for k in seg_state:
+        if "/Variable" in k:
+            assert np.array_equal(after[k], seg_state[k]), k               # same TF name in both graphs
+    for m, a in zip(mr_vars, ct_vars):
+        assert np.array_equal(after[strip(a)], after[strip(m)]), (m, a)
+    untouched = [k for k in after if "cls" in k]
+    assert untouched and all(np.array_equal(after[k], before[k]) for k in untouched)        # critics keep their initialisation
+    with pytest.raises(KeyError):
+        net.load_baseline(seg_state, ["BatchNorm_999/beta:0"], ["pred_7_1/beta:0"], ct_vars, mr_vars)
