@@ -397,11 +397,13 @@ class Full_DRN(object):
         return path
 
     def restore(self, sess_or_none, model_path, no_gan=False, clear_rms=False):
-        """adversarial.py:503-574: name-matched restore; no_gan skips every variable whose name contains 'cls'"""
+        """adversarial.py:503-574: name-matched restore.  no_gan: only the main variables — names containing 'group' or 'output' and
+        neither 'adapt' nor 'cls' (the baseline's BatchNorm_k statistics arrive through load_baseline).  clear_rms concerns the optimiser
+        slots, which live in the Trainer here (Trainer.restore_optimizer)."""
         with np.load(model_path) as z:
             sd = {k.replace("|", "/"): z[k] for k in z.files}
         if no_gan:
-            sd = {k: v for k, v in sd.items() if "cls" not in k}
+            sd = {k: v for k, v in sd.items() if ("group" in k or "output" in k) and "adapt" not in k and "cls" not in k}
         self.store.load_state_dict({k: v for k, v in sd.items() if k in self.store.vars}, strict=False)
 
     def load_baseline(self, segmenter_state, old_bn_list=None, new_bn_list=None, adapt_var_list=None, mr_var_list=None):
@@ -459,6 +461,16 @@ class RMSPropOptimizer(object):
     def step(self):
         K.rmsprop_step(self.store.arena, self.store.grad_arena, self.ms, self.l2, self.mask, self.lr, self.decay, self.eps)
 
+    # the slot and the learning rate are TF variables in the reference, i.e. part of every checkpoint (tf.train.Saver)
+    def state_dict(self):
+        return {"ms": self.ms.detach().cpu().numpy(), "lr": np.float64(self.lr)}
+
+    def load_state_dict(self, sd, slots=True, lr=True):
+        if slots:
+            self.ms.copy_(torch.from_numpy(np.asarray(sd["ms"], dtype=np.float32)).reshape(self.ms.shape))
+        if lr:
+            self.lr = float(sd["lr"])
+
 
 class Trainer(object):
     """Train the adaptation model (adversarial.py:576-946).  Data sources: lists of .tfrecords files or objects with
@@ -512,6 +524,28 @@ class Trainer(object):
         self.clip_mask = st.chunk_table(lambda v: 1 if ("cls" in v.name and "Variable" in v.name) else 0, np.uint8)
         return self.dis_optimizer, self.gen_optimizer
 
+    def save_checkpoint(self, output_path):
+        """lib._save (tf.train.Saver over ALL variables, lib.py:23-29): the model variables plus the RMSProp slots, the two learning
+        rates and the global step"""
+        self.net.save(os.path.join(output_path, "checkpoint.npz"))
+        d, g = self.dis_optimizer.state_dict(), self.gen_optimizer.state_dict()
+        np.savez(os.path.join(output_path, "optimizer.npz"), dis_ms=d["ms"], dis_lr=d["lr"], gen_ms=g["ms"], gen_lr=g["lr"],
+                 global_step=np.int64(self.global_step))
+
+    def restore_optimizer(self, restored_path, clear_rms, lr_update):
+        """adversarial.py:503-574, 803-805: RMSProp slots come back unless clear_rms; the learning rates come back unless lr_update
+        (then the configured rate replaces the checkpoint's, LR_refresh)"""
+        f = os.path.join(restored_path, "optimizer.npz")
+        if not os.path.exists(f):
+            return False
+        with np.load(f) as z:
+            if "dis_ms" not in z.files or z["dis_ms"].size != self.dis_optimizer.ms.numel():
+                return False                                   # a checkpoint of another graph (e.g. the source segmenter's)
+            self.dis_optimizer.load_state_dict({"ms": z["dis_ms"], "lr": z["dis_lr"]}, slots=not clear_rms, lr=not lr_update)
+            self.gen_optimizer.load_state_dict({"ms": z["gen_ms"], "lr": z["gen_lr"]}, slots=not clear_rms, lr=not lr_update)
+            self.global_step = int(z["global_step"])
+        return True
+
     def dis_step(self, mr_batch, ct_batch, dropout, seed):
         """sess.run(dis_optimizer) + sess.run(clip_op) (adversarial.py:852-861)"""
         loss = self.net.dis_loss_and_grads(mr_batch, ct_batch, dropout, drop_seed=seed)
@@ -545,6 +579,8 @@ class Trainer(object):
             ck = os.path.join(restored_path, "checkpoint.npz")
             if os.path.exists(ck):
                 self.net.restore(None, ck, no_gan=bool(tc.get("restore_from_baseline")), clear_rms=bool(tc.get("clear_rms")))
+                if not tc.get("restore_from_baseline"):
+                    self.restore_optimizer(restored_path, clear_rms=bool(tc.get("clear_rms")), lr_update=bool(tc.get("lr_update")))
         ct_feed, mr_feed = self._feeder(self.ct_train_list), self._feeder(self.mr_train_list)
         ct_val, mr_val = self._feeder(self.ct_val_list), self._feeder(self.mr_val_list)
         dis_interval, gen_interval = tc.get('dis_interval', 1), tc.get('gen_interval', 1)
@@ -576,14 +612,14 @@ class Trainer(object):
                     self.output_minibatch_stats(step, *ct_val.next()[:2], *mr_val.next()[:2], detail=True)     # ... and a validation batch
                 if step % tc.get("checkpoint_space", 100) == 0 and step != 0:
                     if self.rank == 0:
-                        self.net.save(os.path.join(output_path, "checkpoint.npz"))
+                        self.save_checkpoint(output_path)
                     f = tc.get('lr_decay_factor', 1.0)
                     self.dis_optimizer.lr *= f
                     self.gen_optimizer.lr *= f
         for f in (ct_feed, mr_feed, ct_val, mr_val):
             f.close()
         if self.rank == 0:
-            self.net.save(os.path.join(output_path, "checkpoint.npz"))
+            self.save_checkpoint(output_path)
         barrier()
         return save_path
 

@@ -288,6 +288,17 @@ class AdamOptimizer(object):
         self.t += 1
         K.adam_step(self.store.arena, self.store.grad_arena, self.m, self.v, self.l2, None, self.lr, self.b1, self.b2, self.eps, self.t)
 
+    # slots, beta powers (t) and the learning-rate variable are part of every TF checkpoint (tf.train.Saver, lib.py:23-29)
+    def state_dict(self):
+        return {"m": self.m.detach().cpu().numpy(), "v": self.v.detach().cpu().numpy(), "t": np.int64(self.t), "lr": np.float64(self.lr)}
+
+    def load_state_dict(self, sd, lr=True):
+        self.m.copy_(torch.from_numpy(np.asarray(sd["m"], dtype=np.float32)).reshape(self.m.shape))
+        self.v.copy_(torch.from_numpy(np.asarray(sd["v"], dtype=np.float32)).reshape(self.v.shape))
+        self.t = int(sd["t"])
+        if lr:
+            self.lr = float(sd["lr"])
+
 
 class MomentumOptimizer(object):
     """tf.train.MomentumOptimizer with staircase exponential decay (source_segmenter.py:359-373)."""
@@ -302,9 +313,22 @@ class MomentumOptimizer(object):
     def lr(self):
         return self.lr0 * (self.decay_rate ** (self.t // max(self.decay_steps, 1)))
 
+    @lr.setter
+    def lr(self, value):          # tf.assign(learning_rate_node, ...) of the periodic checkpoint block (source_segmenter.py:512-513)
+        self.lr0 = float(value) / (self.decay_rate ** (self.t // max(self.decay_steps, 1)))
+
     def step(self):
         K.momentum_step(self.store.arena, self.store.grad_arena, self.acc, self.l2, None, self.lr, self.mom)
         self.t += 1
+
+    def state_dict(self):
+        return {"acc": self.acc.detach().cpu().numpy(), "t": np.int64(self.t), "lr0": np.float64(self.lr0)}
+
+    def load_state_dict(self, sd, lr=True):
+        self.acc.copy_(torch.from_numpy(np.asarray(sd["acc"], dtype=np.float32)).reshape(self.acc.shape))
+        self.t = int(sd["t"])
+        if lr:
+            self.lr0 = float(sd["lr0"])
 
 
 class Trainer(object):
@@ -345,6 +369,27 @@ class Trainer(object):
             return source
         return SliceQueue(source, self.batch_size, capacity=capacity, min_after_dequeue=min_after_dequeue, num_threads=num_threads,
                           shard=self.shard)
+
+    def save_checkpoint(self, output_path):
+        """lib._save (tf.train.Saver over ALL variables): model variables + optimiser slots / step / learning rate"""
+        self.net.save(os.path.join(output_path, "checkpoint.npz"))
+        np.savez(os.path.join(output_path, "optimizer.npz"), kind=self.optimizer, global_step=np.int64(self.global_step),
+                 **self.opt.state_dict())
+
+    def restore_optimizer(self, restored_path):
+        """source_segmenter.py:275-300, 460-462: whatever the checkpoint holds comes back; lr_update_flag keeps the configured rate"""
+        f = os.path.join(restored_path, "optimizer.npz")
+        if not os.path.exists(f):
+            return False
+        with np.load(f) as z:
+            if "kind" not in z.files or str(z["kind"]) != self.optimizer:
+                return False
+            slot = "m" if self.optimizer == "adam" else "acc"
+            if z[slot].size != self.net.store.arena.numel():
+                return False                                   # a checkpoint of another graph
+            self.opt.load_state_dict({k: z[k] for k in z.files if k not in ("kind", "global_step")}, lr=self.lr_update_flag is not True)
+            self.global_step = int(z["global_step"])
+        return True
 
     def _feeder(self, source):
         """dequeue -> pinned staging -> async H2D -> on-device one-hot, one batch ahead of the step (feeder.DeviceFeeder)"""
@@ -406,6 +451,7 @@ class Trainer(object):
             ck = os.path.join(restored_path, "checkpoint.npz")
             if os.path.exists(ck):
                 self.net.restore(None, ck)
+                self.restore_optimizer(restored_path)
             else:
                 print("Unable to restore, start from beginning")
             if self.lr_update_flag is True:
@@ -432,7 +478,7 @@ class Trainer(object):
                         self.val_stats(step, val_x, val_y, True)
                     if step % self.checkpoint_space == 0 and step > 10000:
                         if self.rank == 0:
-                            self.net.save(os.path.join(output_path, "checkpoint.npz"))
+                            self.save_checkpoint(output_path)
                         self.opt.lr = self.opt.lr * 0.9
                 if pending is not None:
                     self._log_step(pending)
@@ -443,7 +489,7 @@ class Trainer(object):
             feed_val.close()
         logging.info("Optimization Finished!")
         if self.rank == 0:      # replicas hold identical weights; BN moving statistics are rank 0's (per-replica statistics)
-            self.net.save(os.path.join(output_path, "checkpoint.npz"))
+            self.save_checkpoint(output_path)
         barrier()
         return save_path
 

@@ -106,6 +106,9 @@ def test_gan_training_schedule_with_stub_steps(tmp_path):
     class Opt(object):
         lr = 1.0
 
+        def state_dict(self):
+            return {"ms": np.ones(4, np.float32), "lr": np.float64(self.lr)}
+
     class Net(object):
         device = torch.device("cpu")
         n_class = 5

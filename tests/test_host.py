@@ -311,6 +311,9 @@ def test_segmenter_training_schedule_with_stub_step(tmp_path):
     class Opt(object):
         lr = 1e-3
 
+        def state_dict(self):
+            return {"m": np.zeros(4, np.float32), "v": np.zeros(4, np.float32), "t": np.int64(7), "lr": np.float64(self.lr)}
+
     tr = ss.Trainer(Net(), Src(), Src(), num_cls=5, batch_size=2, optimizer="adam", opt_kwargs={"learning_rate": 1e-3})
     tr.opt = Opt()
     tr.train_step = lambda bx, by, dropout, step: (events.append(("step", step, float(bx[0, 0, 0, 0]), dropout)), torch.tensor(float(step)))[1]
@@ -339,3 +342,65 @@ def test_segmenter_training_schedule_with_stub_step(tmp_path):
     losses = [m for m in logged if m.startswith("Training at step")]
     assert len(losses) == 7 and "step 6 " in losses[-1] and "6.0000" in losses[-1]
     assert len(tr.step_times) == 7
+    with np.load(str(tmp_path / "o" / "optimizer.npz")) as z:                 # tf.train.Saver semantics: slots, step and lr travel with the model
+        assert str(z["kind"]) == "adam" and int(z["t"]) == 7 and int(z["global_step"]) == 0 and float(z["lr"]) == 1e-3
+
+
+def test_optimizer_state_travels_with_checkpoints(tmp_path):
+    """Adam / momentum / RMSProp slots, step counters and learning rates are TF variables in the reference, i.e. saved and restored by
+    tf.train.Saver; restore honours lr_update_flag / clear_rms / lr_update (source_segmenter.py:460-462, adversarial.py:503-574, 803-805)"""
+    ss, adv = pkg("source_segmenter"), pkg("adversarial")
+    net = ss.Full_DRN(channels=3, n_class=5, batch_size=2, device="cpu", cost_kwargs={"regularizer": 1e-4})
+    out = str(tmp_path / "seg")
+    os.makedirs(out)
+    tr = ss.Trainer(net, None, None, num_cls=5, batch_size=2, optimizer="adam", opt_kwargs={"learning_rate": 1e-3})
+    tr.opt = tr._get_optimizer(10)
+    tr.opt.m.normal_()
+    tr.opt.v.uniform_()
+    tr.opt.t, tr.opt.lr, tr.global_step = 41, 5e-4, 41
+    tr.save_checkpoint(out)
+    for flag, lr_expected in ((False, 5e-4), (True, 1e-3)):
+        tr2 = ss.Trainer(net, None, None, num_cls=5, batch_size=2, optimizer="adam", opt_kwargs={"learning_rate": 1e-3}, lr_update_flag=flag)
+        tr2.opt = tr2._get_optimizer(10)
+        assert tr2.restore_optimizer(out)
+        assert torch.equal(tr2.opt.m, tr.opt.m) and torch.equal(tr2.opt.v, tr.opt.v) and tr2.opt.t == 41 and tr2.global_step == 41
+        assert tr2.opt.lr == lr_expected
+    trm = ss.Trainer(net, None, None, num_cls=5, batch_size=2, optimizer="momentum", opt_kwargs={"learning_rate": 0.2})
+    trm.opt = trm._get_optimizer(10)
+    assert not trm.restore_optimizer(out)                        # an Adam checkpoint does not feed a momentum optimiser
+    trm.opt.t = 25
+    trm.opt.lr = 0.05                                            # periodic decay assigns the rate (staircase factor divided out)
+    assert abs(trm.opt.lr - 0.05) < 1e-12
+    # adaptation trainer: two RMSProp optimisers
+    anet = adv.Full_DRN(channels=3, n_class=5, batch_size=2, device="cpu",
+                        cost_kwargs={"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.3},
+                        network_config={"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True,
+                                        "cls_trainable": True, "m_cls_trainable": True})
+    aout = str(tmp_path / "gan")
+    os.makedirs(aout)
+    at = adv.Trainer(anet, None, None, None, None, num_cls=5, batch_size=2, opt_kwargs={"learning_rate": 3e-4})
+    at._get_optimizer()
+    at.dis_optimizer.ms.uniform_(0.5, 2.0)
+    at.gen_optimizer.ms.uniform_(0.5, 2.0)
+    at.dis_optimizer.lr = at.gen_optimizer.lr = 1e-4
+    at.global_step = 9
+    at.save_checkpoint(aout)
+    for clear_rms, lr_update in ((False, False), (True, False), (False, True)):
+        a2 = adv.Trainer(anet, None, None, None, None, num_cls=5, batch_size=2, opt_kwargs={"learning_rate": 3e-4})
+        a2._get_optimizer()
+        assert a2.restore_optimizer(aout, clear_rms=clear_rms, lr_update=lr_update)
+        same = torch.equal(a2.dis_optimizer.ms, at.dis_optimizer.ms) and torch.equal(a2.gen_optimizer.ms, at.gen_optimizer.ms)
+        assert same == (not clear_rms)
+        if clear_rms:
+            assert torch.all(a2.dis_optimizer.ms == 1.0)                     # TF's RMSProp slot initial value
+        assert a2.dis_optimizer.lr == (3e-4 if lr_update else 1e-4) and a2.global_step == 9
+    assert not at.restore_optimizer(out, False, False)           # the segmenter's checkpoint folder has no RMSProp state for this graph
+    # no_gan restore: only the main ('group' / 'output') variables, neither adapt_* nor the critics
+    before = anet.store.state_dict()
+    tweaked = {k: v + 1.0 for k, v in before.items()}
+    np.savez(os.path.join(aout, "tweaked.npz"), **{k.replace("/", "|"): v for k, v in tweaked.items()})
+    anet.restore(None, os.path.join(aout, "tweaked.npz"), no_gan=True)
+    after = anet.store.state_dict()
+    for k in before:
+        moved = not np.array_equal(after[k], before[k])
+        assert moved == (("group" in k or "output" in k) and "adapt" not in k and "cls" not in k), k
