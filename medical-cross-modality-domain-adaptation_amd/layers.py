@@ -9,6 +9,7 @@ Each function cites the reference lines it replaces.
 """
 from math import floor  # noqa: F401  (the reference imports it; kept for parity of the module surface)
 
+import numpy as np
 import torch
 
 from . import kernels as K
@@ -137,6 +138,31 @@ def sharable_weight_variable(shape, stddev=0.1, trainable=True, name="IhaveNoNam
     """tf.get_variable(name, shape, truncated_normal_initializer(stddev)): shared by scope + name."""
     st = current_store()
     return st.get(st.scoped(name), shape, lambda rng, s: truncated_normal(rng, s, stddev), trainable, "weight").tensor
+
+
+# ---- helpers without a call site in the reference (SURVEY.md §2 row 15): exported so that `from layers import *` finds every name ----
+def weight_variable_deconv(shape, stddev=0.1):
+    """layers.py:57-58: tf.Variable(tf.truncated_normal(shape, stddev)) — a plain filter variable, no arithmetic involved"""
+    return weight_variable(shape, stddev=stddev)
+
+
+def bias_variable(shape):
+    """layers.py:60-62: tf.Variable(tf.constant(0.1, shape)) named like any other tf.Variable"""
+    st = current_store()
+    return st.get(st.unique("Variable"), shape, lambda rng, s: np.full(s, 0.1, np.float32), True, "weight").tensor
+
+
+def _dead(name, where):
+    def f(*a, **k):
+        raise NotImplementedError("%s has no call site in the reference (%s) and is not on the hot path" % (name, where))
+    f.__name__ = name
+    return f
+
+
+avg_pool2d = _dead("avg_pool2d", "layers.py:105-106")
+crop_and_concat = _dead("crop_and_concat", "layers.py:108-115")
+pixel_wise_softmax = _dead("pixel_wise_softmax", "layers.py:129-132")
+cross_entropy = _dead("cross_entropy", "layers.py:140-141")
 
 
 # ---- layers.py:117-127 -------------------------------------------------------------------------------

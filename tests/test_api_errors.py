@@ -58,6 +58,10 @@ def test_errors(store):
         L.residual_block(meta(2, 8, 8, 16), w1, w2, 1.0, inc_dim=True)   # 16 + 2*8 != 24
     with pytest.raises(NotImplementedError):
         L.conv_relu2d(meta(1, 4, 4, 16), w, 1.0)                 # dead helper of the reference (layers.py:77-82)
+    for name in ("avg_pool2d", "crop_and_concat", "pixel_wise_softmax", "cross_entropy"):      # the other dead helpers: exported, loud
+        with pytest.raises(NotImplementedError):
+            getattr(L, name)(meta(1, 4, 4, 2), 2)
+    assert tuple(L.bias_variable([8]).shape) == (8,) and tuple(L.weight_variable_deconv([2, 2, 4, 4]).shape) == (2, 2, 4, 4)
     V = pkg("variables")
     store.finalize()
     with pytest.raises(RuntimeError):
