@@ -19,3 +19,8 @@ def PS(X, r, n_channel=8, batch_size=10):
     if X.is_meta:   # symbolic build pass
         return torch.empty((X.shape[0], X.shape[1] * r, X.shape[2] * r, n_channel), device="meta")
     return PSFn.apply(X, r, n_channel)
+
+
+def _phase_shift(I, r, batch_size=10):
+    """ops.py:3-21, the per-channel-group helper of PS: [B,a,b,r*r] -> [B,a*r,b*r,1] (closed form with one output channel)"""
+    return PS(I, r, n_channel=1, batch_size=batch_size)
