@@ -122,3 +122,36 @@ def test_device_feeder_matches_host_one_hot(tmp_path):
     import pytest
     with pytest.raises(IOError):
         fb.next()
+
+
+def test_example_wire_format_known_answers():
+    """tf.train.Example bytes written out by hand from the protobuf wire format (Example.features=1 -> map<string,Feature> entries
+    {key=1, value=2} -> Feature{bytes_list=1 | float_list=2 | int64_list=3} -> value=1, int64 packed) — not through this codec's own
+    encoder — and the TFRecord framing of a record (u64 length, masked crc32c of the length, payload, masked crc32c of the payload)."""
+    import struct
+    t = pkg("tfrecord")
+    ex_int = bytes.fromhex("0a0c" "0a0a" "0a0161" "1205" "1a03" "0a0105")               # {"a": int64 5}
+    assert t.decode_example(ex_int) == {"a": 5}
+    assert t.encode_example({"a": 5}) == ex_int
+    ex_bytes = bytes.fromhex("0a0f" "0a0d" "0a026964" "1207" "0a05" "0a03" "78797a")    # {"id": b"xyz"}
+    assert t.decode_example(ex_bytes) == {"id": b"xyz"}
+    assert t.encode_example({"id": b"xyz"}) == ex_bytes
+    # int64 300 = varint ac 02; UNPACKED encoding (tag 08 per value) and a two-value packed list must decode too
+    assert t.decode_example(bytes.fromhex("0a0d" "0a0b" "0a0161" "1206" "1a04" "0a02ac02")) == {"a": 300}
+    assert t.decode_example(bytes.fromhex("0a0c" "0a0a" "0a0161" "1205" "1a03" "08ac02")) == {"a": 300}            # unpacked varint
+    assert t.decode_example(bytes.fromhex("0a0e" "0a0c" "0a0161" "1207" "1a05" "0a03" "05ac02")) == {"a": [5, 300]}
+    # float_list (not produced by the reference's writer, accepted by the reader): {"f": [1.0]}
+    got = t.decode_example(bytes.fromhex("0a0f" "0a0d" "0a0166" "1208" "1206" "0a04" "0000803f"))
+    assert list(got["f"]) == [1.0]
+    # framing: crc32c("123456789") = e3069283 is the standard check value; mask = ((crc >> 15 | crc << 17) + a282ead8) mod 2^32
+    assert t.crc32c(b"123456789") == 0xE3069283
+    crc = 0xE3069283
+    assert t.masked_crc(b"123456789") == ((((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF)
+    import tempfile, os
+    d = tempfile.mkdtemp()
+    f = os.path.join(d, "r.tfrecords")
+    t.write_records(f, [ex_int])
+    raw = open(f, "rb").read()
+    assert raw[:8] == struct.pack("<Q", len(ex_int)) and raw[12:12 + len(ex_int)] == ex_int and len(raw) == 8 + 4 + len(ex_int) + 4
+    assert struct.unpack("<I", raw[8:12])[0] == t.masked_crc(raw[:8]) and struct.unpack("<I", raw[-4:])[0] == t.masked_crc(ex_int)
+    assert t.read_records(f, verify=True) == [ex_int]
