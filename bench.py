@@ -1,19 +1,23 @@
 #!/usr/bin/env python
-"""bench.py — BASELINE.json metric: training slices/sec (256x256x3) of the PnP-AdaNet segmenter train step on MI355X.
+"""bench.py — BASELINE.json metric: training slices/sec (256x256x3, B=16) of PnP-AdaNet's segmenter+GAN step on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): source segmenter fwd + bwd + Adam, B=16 slices per GPU, fp32, dropout keep 0.75,
-BN in training mode — exactly `sess.run(optimizer)` of source_segmenter.py:484-489, on synthetic N(0,1) slices with blob label
-maps already resident in HBM.  Weak scaling: every rank processes its own 16 slices; gradients are all-reduced over RCCL.
-One JSON line is printed by rank 0, carrying `roofline` (dominant kernel: the 3x3 fp32-MFMA forward convolution, timed live
-with HIP events around each of its launches inside the timed region) and `cpu_baseline` (the CPU oracle on the host cores).
-
-`--workload gan` measures BASELINE configs[3] on the same contract instead: the joint step (1 discriminator update on B MR + B CT
-slices, weight clip, 1 generator update on B CT slices; adversarial.py:839-882), B slices counted per step; no cpu_baseline there.
+Headline workload (default, BASELINE.json configs[3]): the JOINT step of `train_gan.py --phase train-gan` — one discriminator
+update on B MR + B CT slices (both critics, RMSProp, weight clip; adversarial.py:839-862) followed by one generator update on the
+B CT slices (adversarial.py:866-882) — B=16 slices of each domain per GPU, fp32, dropout keep 0.75, synthetic N(0,1) slices already
+resident in HBM; B slices are counted per step.  Weak scaling: every rank processes its own 16+16 slices, gradients are
+all-reduced (RCCL).  Rank 0 prints ONE JSON line carrying
+  * `roofline`          the kernel symbol with the largest share of the timed region's convolution time, timed live with HIP
+                        events recorded by libpnp_hip.so around each of its launches (pnp_prof_*), against the fp32-MFMA peak;
+  * `roofline_kernels`  the same for every MFMA convolution symbol of the step (forward, data gradient, filter gradient);
+  * `segmenter_step`    BASELINE configs[1] (source segmenter fwd + bwd + Adam, source_segmenter.py:484-489) timed the same way;
+  * `cpu_baseline`      the CPU oracle's joint step (oracle/nets_adv.py, torch-CPU fp32) on this host's cores, bounded sample.
+`--workload segmenter` makes configs[1] the headline line instead (same contract).
 """
 import argparse
+import glob
 import importlib
 import json
 import os
@@ -28,7 +32,11 @@ sys.path.insert(0, ROOT)
 PKG = "medical-cross-modality-domain-adaptation_amd"
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
 COST = {"cross_flag": True, "miu_cross": 1.0, "dice_flag": True, "miu_dice": 1.0, "regularizer": 1e-4}
+GAN_COST = {"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.3}
+GAN_NETCFG = {"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True, "cls_trainable": True,
+              "m_cls_trainable": True}
 
 
 def blob_labels(rng, B):
@@ -49,94 +57,134 @@ def one_hot(lab, ncls=5):
     return out
 
 
-class ConvFwdProbe(object):
-    """HIP-event timing of every pnp_conv2d_fwd launch (forward 3x3 convolutions) inside the timed region."""
-
-    def __init__(self, K):
-        self.K = K
-        self.orig = K.conv2d_fwd
-        self.records = []      # (flops, bytes, tile_class, ev0, ev1)
-        self.enabled = False
-
-    def install(self):
-        probe = self
-
-        def wrapped(x, w, g, keep_prob=1.0, seed=0, stream_id=0, out=None, naive=False):
-            if not probe.enabled:
-                return probe.orig(x, w, g, keep_prob, seed, stream_id, out, naive)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            y = probe.orig(x, w, g, keep_prob, seed, stream_id, out, naive)
-            e1.record()
-            flops = 2.0 * g.N * g.OH * g.OW * g.R * g.S * g.C * g.K
-            nbytes = 4.0 * (g.N * g.H * g.W * g.C + g.N * g.OH * g.OW * g.K + g.R * g.S * g.C * g.K)
-            # launches served by the kernel symbol conv_taps_kernel<128,128,2,2,0,3> (csrc/conv_igemm.hip::launch_fwd_tile):
-            # 3x3, stride 1, zero/VALID padding, C % 32 == 0, K % 4 == 0, >= 384 tiles of 128x128
-            big = (g.R == 3 and g.S == 3 and g.stride == 1 and g.pad_mode == 0 and g.K > 64 and g.K % 4 == 0 and g.C % 32 == 0
-                   and (-(-g.N * g.OH * g.OW // 128) * -(-g.K // 128) >= 384))
-            probe.records.append((flops, nbytes, big, e0, e1))
-            return y
-        self.K.conv2d_fwd = wrapped
-
-    def summary(self):
-        tot = {True: [0.0, 0.0, 0.0, 0], False: [0.0, 0.0, 0.0, 0]}
-        for flops, nbytes, big, e0, e1 in self.records:
-            ms = e0.elapsed_time(e1)
-            t = tot[big]
-            t[0] += flops
-            t[1] += nbytes
-            t[2] += ms
-            t[3] += 1
-        return tot
+def he_state(sd, seed=7):
+    """He-scaled weights (the reference's stddev=.01 init gives vanishing activations after 30 layers; either is "random init")"""
+    wr = np.random.default_rng(seed)
+    for k in sd:
+        if "Variable" in k:
+            s = sd[k].shape
+            if len(s) == 4 and "cls" not in k:      # segmenter conv filters: rescale the truncated-normal(0.01) init
+                sd[k] = (sd[k] * (np.sqrt(2.0 / (s[0] * s[1] * s[2])) / 0.01)).astype(np.float32)
+            else:                                   # critic convs / FC (stddev 0.1 shared variables): fresh He-normal draw
+                sd[k] = (wr.standard_normal(s) * np.sqrt(2.0 / np.prod(s[:-1]))).astype(np.float32)
+    return sd
 
 
 def pmc_traffic_bytes(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed PMC summary (collected offline with rocprofv3 --pmc in separate
-    passes, corrected as MI355X_MICROARCH.md prescribes); None when the summary is not there."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC summary (collected offline with rocprofv3 --pmc in
+    separate passes, corrected as MI355X_MICROARCH.md prescribes: 2 x FETCH_SIZE + WRITE_SIZE); None when there is none."""
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")), reverse=True):
+        try:
+            k = json.load(open(p))["kernels"][kernel]
+            return (k["hbm_read_MB_per_launch_corrected_x2"] + k["hbm_write_MB_per_launch"]) * 1e6, os.path.basename(p)
+        except Exception:
+            continue
+    return None, None
+
+
+def cpu_model():
     try:
-        k = json.load(open(p))["kernels"][kernel]
-        return (k["hbm_read_MB_per_launch_corrected_x2"] + k["hbm_write_MB_per_launch"]) * 1e6
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except Exception:
-        return None
+        pass
+    return "unknown"
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The CPU oracle (a port: TF-1.4 cannot run here) timed on this host's cores on a bounded sample of the same workload:
-    ONE segmenter train step (fwd+bwd+Adam) at B=2 slices, all cores."""
-    from oracle import nets
+def cpu_baseline(workload, timed_steps=3):
+    """The CPU oracle (a port: TF-1.4 cannot run here) on this host's cores, same step definition as the GPU line, on a BOUNDED
+    sample: B=2 slices per domain, 1 warm-up step + `timed_steps` timed steps, median reported."""
     # torch's default intra-op thread count honours the cgroup / affinity mask of the box (os.cpu_count() does not:
     # forcing 256 threads onto a restricted mask made this sample 50x slower)
     ncores = torch.get_num_threads()
     rng = np.random.default_rng(0)
     Bc = 2
-    x = torch.from_numpy(rng.standard_normal((Bc, 256, 256, 3)).astype(np.float32))
-    y = torch.from_numpy(one_hot(blob_labels(rng, Bc)))
-    shapes = nets.segmenter_variable_shapes()
-    state = {}
-    for k, s in shapes.items():
-        if "Variable" in k:
-            state[k] = (rng.standard_normal(s) * np.sqrt(2.0 / (s[0] * s[1] * s[2]))).astype(np.float32)
-        elif k.endswith("gamma") or k.endswith("moving_variance"):
-            state[k] = np.ones(s, np.float32)
-        else:
-            state[k] = np.zeros(s, np.float32)
-    V = nets.make_variables(state)
-    opt = {}
-    t0 = time.time()
-    nets.segmenter_train_step(V, opt, x, y, 0.75, seed=1, lr=1e-3, t=1)
-    t1 = time.time()
-    steps = 1
-    el = t1 - t0
-    if el < seconds_budget / 3:       # fast host: take a second, warm sample
-        t0 = time.time()
-        nets.segmenter_train_step(V, opt, x, y, 0.75, seed=2, lr=1e-3, t=2)
-        el = time.time() - t0
-        steps = 2
-    return {"value": Bc / el, "unit": "slices/s", "cores": ncores, "kind": "port",
-            "sample": "oracle.nets.segmenter_train_step (torch-CPU fp32 restatement of source_segmenter.py:484-489), B=%d, "
-                      "%d step(s), last one timed: %.2f s" % (Bc, steps, el)}
+    times = []
+    if workload == "segmenter":
+        from oracle import nets
+        x = torch.from_numpy(rng.standard_normal((Bc, 256, 256, 3)).astype(np.float32))
+        y = torch.from_numpy(one_hot(blob_labels(rng, Bc)))
+        state = {}
+        for k, s in nets.segmenter_variable_shapes().items():
+            if "Variable" in k:
+                state[k] = (rng.standard_normal(s) * np.sqrt(2.0 / (s[0] * s[1] * s[2]))).astype(np.float32)
+            elif k.endswith("gamma") or k.endswith("moving_variance"):
+                state[k] = np.ones(s, np.float32)
+            else:
+                state[k] = np.zeros(s, np.float32)
+        V = nets.make_variables(state)
+        opt = {}
+        for i in range(1 + timed_steps):
+            t0 = time.time()
+            nets.segmenter_train_step(V, opt, x, y, 0.75, seed=1 + i, lr=1e-3, t=1 + i)
+            times.append(time.time() - t0)
+        what = "oracle.nets.segmenter_train_step (torch-CPU fp32 restatement of source_segmenter.py:484-489)"
+    else:
+        from oracle import nets_adv
+        adv = importlib.import_module(PKG + ".adversarial")
+        # variable names / shapes from the product's symbolic build pass (meta tensors: no kernel runs, no GPU touched)
+        net = adv.Full_DRN(channels=3, n_class=5, batch_size=Bc, device="cpu", seed=0, cost_kwargs=dict(GAN_COST),
+                           network_config=dict(GAN_NETCFG))
+        sd = he_state(net.store.state_dict())
+        V = {k: torch.from_numpy(np.array(a)) for k, a in sd.items()}
+        mr = torch.from_numpy(rng.standard_normal((Bc, 256, 256, 3)).astype(np.float32))
+        ct = torch.from_numpy((rng.standard_normal((Bc, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32))
+        ms_d, ms_g = {}, {}
+        for i in range(1 + timed_steps):
+            t0 = time.time()
+            nets_adv.joint_train_step(V, ms_d, ms_g, mr, ct, 0.75, seed=1 + 2 * i)
+            times.append(time.time() - t0)
+        what = "oracle.nets_adv.joint_train_step (torch-CPU fp32 restatement of adversarial.py:839-882: 1 dis update + clip + 1 gen update)"
+    med = float(np.median(times[1:]))
+    return {"value": Bc / med, "unit": "slices/s", "cores": ncores, "cpu_model": cpu_model(), "kind": "port",
+            "sample": "%s, B=%d per domain, 1 warm-up + %d timed steps, median %.2f s/step (all: %s)" % (
+                what, Bc, timed_steps, med, ", ".join("%.2f" % t for t in times))}
+
+
+def timed_loop(step_fn, warmup, steps, world, dev, prof=None):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds = max over ranks, last loss)"""
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    k = 0
+    for _ in range(warmup):
+        step_fn(k)
+        k += 1
+    barrier()
+    if prof is not None:
+        prof(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step_fn(k)
+        k += 1
+    barrier()
+    el = time.perf_counter() - t0
+    if prof is not None:
+        prof(False)
+    if world > 1:
+        el = importlib.import_module(PKG + ".parallel").all_max_scalar(el, dev)
+    lossv = float(loss)
+    assert np.isfinite(lossv), "training diverged: loss=%r" % lossv
+    return el, lossv
+
+
+def roofline_records(rows, peak):
+    """per kernel symbol: achieved TFLOP/s of ALGORITHMIC flops / summed launch duration (live HIP events), fraction of peak"""
+    out = []
+    tot_ms = sum(r["ms"] for r in rows) or 1.0
+    for r in sorted(rows, key=lambda r: -r["ms"]):
+        if r["ms"] <= 0 or not r["launches"]:
+            continue
+        ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        traffic, src = pmc_traffic_bytes(r["name"])
+        out.append({"kernel": r["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "traffic": traffic, "traffic_source": src, "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
+                    "share_of_conv_time": r["ms"] / tot_ms,
+                    "algorithmic_gflop_per_launch": r["flops"] / r["launches"] / 1e9,
+                    "algorithmic_mbytes_per_launch": r["bytes"] / r["launches"] / 1e6})
+    return out
 
 
 def main():
@@ -144,13 +192,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="slices per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="slices per GPU (of each domain for the joint step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="no per-kernel HIP events (no roofline objects)")
     ap.add_argument("--no-overlap", action="store_true")
-    ap.add_argument("--workload", choices=["segmenter", "gan"], default="segmenter",
-                    help="segmenter: BASELINE configs[1] (the default, the headline line); gan: configs[3] joint step = 1 dis + clip + 1 gen")
+    ap.add_argument("--no-sub", action="store_true", help="skip the secondary workload's sub-record")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: BASELINE configs[4] arithmetic (bf16 MFMA conv operands, fp32 accumulation / master weights / BN); a separate "
+                         "line, never the headline")
+    ap.add_argument("--workload", choices=["joint", "gan", "segmenter"], default="joint",
+                    help="joint (= gan): BASELINE configs[3], the headline; segmenter: configs[1]")
     args = ap.parse_args()
+    if args.workload == "gan":
+        args.workload = "joint"
 
     par = importlib.import_module(PKG + ".parallel")
     if os.environ.get("PNP_SAME_DEVICE"):        # test mode: every rank on GPU 0 (with PNP_DIST_BACKEND=gloo); never used for results
@@ -162,114 +216,93 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    ss = importlib.import_module(PKG + ".source_segmenter")
-    K = importlib.import_module(PKG + ".kernels")
+    L = importlib.import_module(PKG + "._lib")
+    if args.dtype == "bf16":
+        importlib.import_module(PKG + ".functional").set_conv_dtype("bf16")
     B = args.batch
     rng = np.random.default_rng(100 + rank)
     x = torch.from_numpy(rng.standard_normal((B, 256, 256, 3)).astype(np.float32)).to(dev)
+    peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
 
-    def he_scale(net):
-        # He-scaled weights (the reference's stddev=.01 init gives vanishing activations after 30 layers; either is "random init")
-        sd = net.store.state_dict()
-        wr = np.random.default_rng(7)
-        for k in sd:
-            if "Variable" in k:
-                s = sd[k].shape
-                if len(s) == 4 and "cls" not in k:      # segmenter conv filters: rescale the truncated-normal(0.01) init
-                    sd[k] = (sd[k] * (np.sqrt(2.0 / (s[0] * s[1] * s[2])) / 0.01)).astype(np.float32)
-                else:                                   # critic convs / FC (stddev 0.1 shared variables): fresh He-normal draw
-                    sd[k] = (wr.standard_normal(s) * np.sqrt(2.0 / np.prod(s[:-1]))).astype(np.float32)
-        net.store.load_state_dict(sd)
-
-    if args.workload == "segmenter":
+    def make_segmenter():
+        ss = importlib.import_module(PKG + ".source_segmenter")
         net = ss.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, cost_kwargs=dict(COST), seed=0, world_size=world)
-        he_scale(net)
+        net.store.load_state_dict(he_state(net.store.state_dict()))
         reducer = par.GradReducer(net.store, overlap=not args.no_overlap) if world > 1 else None
         tr = ss.Trainer(net, None, None, num_cls=5, batch_size=B, optimizer="adam", opt_kwargs={"learning_rate": 1e-3}, reducer=reducer)
         tr.opt = tr._get_optimizer(10)
         y = torch.from_numpy(one_hot(blob_labels(rng, B))).to(dev)
+        return lambda i: tr.train_step(x, y, 0.75, i * world + rank)
 
-        def train_step(i):
-            return tr.train_step(x, y, 0.75, i * world + rank)
-        metric = "training slices/sec (256x256x3, B=16 per GPU) segmenter train step (fwd+bwd+Adam)"
-        workload = "BASELINE configs[1]: source segmenter fwd+bwd+Adam, B=%d/GPU, 256x256x3, fp32, dropout .75, BN train" % B
-    else:
+    def make_joint():
         adv = importlib.import_module(PKG + ".adversarial")
-        net = adv.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, seed=0, world_size=world,
-                           cost_kwargs={"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.3},
-                           network_config={"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True,
-                                           "cls_trainable": True, "m_cls_trainable": True})
-        he_scale(net)
+        net = adv.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, seed=0, world_size=world, cost_kwargs=dict(GAN_COST),
+                           network_config=dict(GAN_NETCFG))
+        net.store.load_state_dict(he_state(net.store.state_dict()))
         reducer = par.GradReducer(net.store, overlap=not args.no_overlap) if world > 1 else None
         tr = adv.Trainer(net, None, None, None, None, num_cls=5, batch_size=B, opt_kwargs={"learning_rate": 3e-4},
                          train_config={"dis_sub_iter": 1, "gen_sub_iter": 1}, reducer=reducer)
         tr._get_optimizer()
         ct = torch.from_numpy((rng.standard_normal((B, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32)).to(dev)
 
-        def train_step(i):
+        def step(i):
             tr.dis_step(x, ct, 0.75, 2 * (i * world + rank) + 1)
             return tr.gen_step(ct, 0.75, 2 * (i * world + rank) + 2)
-        metric = "training slices/sec (256x256x3, B=16 per GPU) joint segmenter+GAN step (1 dis update on B MR + B CT, clip, 1 gen update on B CT)"
-        workload = "BASELINE configs[3]: train_gan.py --phase train-gan joint step, B=%d/GPU of each domain, fp32, dropout .75, mask critic on" % B
+        return step
 
-    probe = ConvFwdProbe(K)
-    if not args.no_probe:
-        probe.install()
+    names = {
+        "joint": ("training slices/sec (256x256x3, B=16 per GPU) joint segmenter+GAN step (1 dis update on B MR + B CT, clip, 1 gen update on B CT)",
+                  "BASELINE configs[3]: train_gan.py --phase train-gan joint step, B=%d/GPU of each domain, %s, dropout .75, mask critic on" % (B, args.dtype)),
+        "segmenter": ("training slices/sec (256x256x3, B=16 per GPU) segmenter train step (fwd+bwd+Adam)",
+                      "BASELINE configs[1]: source segmenter fwd+bwd+Adam, B=%d/GPU, 256x256x3, %s, dropout .75, BN train" % (B, args.dtype)),
+    }
+    makers = {"joint": make_joint, "segmenter": make_segmenter}
+    other = "segmenter" if args.workload == "joint" else "joint"
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    def prof(on):
+        if not args.no_probe:
+            L.prof_enable((L.PROF_CONV_FWD | L.PROF_CONV_DGRAD | L.PROF_CONV_WGRAD) if on else 0)
 
-    step = 0
-    for _ in range(args.warmup):
-        train_step(step)
-        step += 1
-    barrier()
-    probe.enabled = not args.no_probe
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step(step)
-        step += 1
-    barrier()
-    el = time.perf_counter() - t0
-    probe.enabled = False
-    if world > 1:
-        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        el = float(tmax.item())
-    lossv = float(loss)
-    assert np.isfinite(lossv), "training diverged: loss=%r" % lossv
+    step_fn = makers[args.workload]()
+    el, lossv = timed_loop(step_fn, args.warmup, args.steps, world, dev, prof)
+    rows = [] if args.no_probe else L.prof_summary()
+    del step_fn
+    sub = None
+    if not args.no_sub:
+        sub_steps, sub_warm = max(5, min(args.steps, 10)), 2
+        el2, loss2 = timed_loop(makers[other](), sub_warm, sub_steps, world, dev, None)
+        sub = {"workload": names[other][1], "value": world * B * sub_steps / el2, "unit": "slices/s", "ms_per_step": 1e3 * el2 / sub_steps,
+               "steps": sub_steps, "warmup": sub_warm, "final_loss": loss2}
 
     if rank == 0:
         res = {
-            "metric": metric,
+            "metric": names[args.workload][0],
             "value": world * B * args.steps / el, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload,
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": lossv},
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": names[args.workload][1], "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "final_loss": lossv, "comm": par.transport() if world > 1 else None},
         }
-        if not args.no_probe:
-            tot = probe.summary()
-            fl, by, ms, n = tot[True]
-            if n:
-                ach = fl / (ms * 1e-3) / 1e12
-                res["roofline"] = {"bound": "mfma", "kernel": "conv_taps_kernel<128,128,2,2,0,3,3> (forward 3x3 convs on the 128x128 fp32-MFMA tile: 256->512, 512->512 (+dilated), 512->2560)",
-                                   "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                                   "traffic": pmc_traffic_bytes("conv_taps_kernel<128, 128, 2, 2, 0, 3, 3>"), "launches": n, "avg_launch_ms": ms / n,
-                                   "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mbytes_per_launch": by / n / 1e6,
-                                   "traffic_note": "HBM-side bytes per launch of this kernel symbol from the committed rocprofv3 PMC passes "
-                                                   "(profiles/r01_pmc_counters.json: 2*FETCH_SIZE + WRITE_SIZE, separate passes); null if absent"}
-            fl2, by2, ms2, n2 = tot[False]
-            if n2:
-                res["roofline_small_convs"] = {"launches": n2, "avg_launch_ms": ms2 / n2, "achieved_tflops": fl2 / (ms2 * 1e-3) / 1e12,
-                                               "algorithmic_GBps": by2 / (ms2 * 1e-3) / 1e9}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "segmenter":     # the oracle sample is the segmenter step
-            res["cpu_baseline"] = cpu_baseline()
+        if rows:
+            recs = roofline_records(rows, peak)
+            if recs:
+                top = dict(recs[0])
+                top["note"] = ("the kernel symbol with the largest share of the timed region's convolution time; `achieved` = sum of "
+                               "algorithmic FLOP (2*N*OH*OW*R*S*C*K) / sum of launch durations, HIP events recorded by libpnp_hip.so on the "
+                               "launch stream around every launch of this symbol inside the timed region; `traffic` = HBM-side bytes per "
+                               "launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, separate passes), null if absent")
+                res["roofline"] = top
+                res["roofline_kernels"] = recs
+                fl, ms = sum(r["flops"] for r in rows), sum(r["ms"] for r in rows)
+                res["roofline_all_mfma_convs"] = {"achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "frac": fl / (ms * 1e-3) / 1e12 / peak,
+                                                  "unit": "TFLOP/s", "ms_per_step": ms / args.steps, "launches_per_step": sum(r["launches"] for r in rows) / args.steps}
+        if sub is not None:
+            res["segmenter_step" if other == "segmenter" else "joint_step"] = sub
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(res))
     if world > 1:
-        torch.distributed.destroy_process_group()
+        par.shutdown()
 
 
 if __name__ == "__main__":

@@ -29,6 +29,12 @@ extern "C" {
 #define PNP_EINVAL (-1)   /* bad argument / unsupported geometry */
 #define PNP_ELAUNCH (-2)  /* hip launch error */
 #define PNP_EWORKSPACE (-3) /* workspace too small */
+#define PNP_ECOMM (-4)    /* RCCL missing or an RCCL call failed */
+
+/* element types named at the ABI (convolution operand storage, collectives) */
+#define PNP_DTYPE_F32 0
+#define PNP_DTYPE_BF16 1
+#define PNP_DTYPE_F64 2
 
 #define PNP_PAD_ZERO 0      /* tf.nn.conv2d(padding='SAME') zero padding, layers.py:18,67 */
 #define PNP_PAD_SYMMETRIC 1 /* tf.pad(x, k//2, 'SYMMETRIC') + VALID conv, layers.py:19-24,68-73 */
@@ -37,6 +43,23 @@ int pnp_abi_version(void);
 const char* pnp_last_error(void);
 /* cu_count, max clock (kHz), LDS bytes per CU, gcn arch name (<=63 chars) of `device` */
 int pnp_device_info(int device, int* cu_count, int* clock_khz, int* lds_bytes, char* arch, int arch_len);
+
+/* Kernel-level timing for the roofline figures of bench.py: while a class is enabled, the library records HIP events on the
+ * launch stream around every launch of that class's main kernel (not around its helper kernels: filter flips, partial sums).
+ * pnp_prof_summary waits for the events, returns one row per kernel symbol (named as rocprofv3 --kernel-trace prints it) with the
+ * launch count, the summed duration and the summed ALGORITHMIC flops / bytes (2*N*OH*OW*R*S*C*K; 4*(|x|+|y|+|w|)), and clears
+ * the records.  Returns the number of distinct symbols (may exceed max_rows; only max_rows are written). */
+#define PNP_PROF_CONV_FWD 1   /* MFMA forward convolutions */
+#define PNP_PROF_CONV_DGRAD 2 /* MFMA data gradients */
+#define PNP_PROF_CONV_WGRAD 4 /* MFMA filter gradients */
+#define PNP_PROF_CONV_DIRECT 8 /* vector-ALU convolutions for K <= 16 */
+typedef struct pnp_prof_row {
+    char name[128];
+    int64_t launches;
+    double ms, flops, bytes;
+} pnp_prof_row;
+int pnp_prof_enable(int32_t mask);
+int pnp_prof_summary(pnp_prof_row* rows, int32_t max_rows);
 
 /* Geometry shared by the three conv entry points (all describe the FORWARD convolution):
  *   x [N,H,W,C]  w [R,S,C,K]  y [N,OH,OW,K]
@@ -203,6 +226,21 @@ int pnp_wgan_loss(const float* ct_cls, const float* mr_cls, const float* ct_mask
                   float c_ct_cls, float c_mr_cls, float c_ct_mask, float c_mr_mask, float* out, void* stream);
 /* p[0..n) = value  (constant gradient of a mean: coef / B) */
 int pnp_fill(float* p, size_t n, float value, void* stream);
+
+/* Data-parallel exchange step (new with respect to the single-GPU reference, train_segmenter.py:20 / train_gan.py:18): in-place
+ * SUM all-reduce over RCCL (xGMI), one communicator per process / GPU.  librccl.so is resolved at run time: pnp_comm_load(path)
+ * names the copy to bind (NULL: the one already mapped in this process, else the default search path); the other calls load it
+ * on first use.  Bring-up: rank 0 calls pnp_comm_unique_id and ships the PNP_COMM_ID_BYTES to every rank out of band (the host
+ * side uses the torchrun rendezvous store); then EVERY rank calls pnp_comm_init (collective; binds the current HIP device).
+ * pnp_comm_allreduce enqueues on `stream` and returns; ordering against producers / consumers of `buf` is the caller's business
+ * (events on that stream).  buf: n elements of dtype PNP_DTYPE_F32 or PNP_DTYPE_F64. */
+#define PNP_COMM_ID_BYTES 128
+int pnp_comm_load(const char* librccl_path /*nullable*/);
+int pnp_comm_version(int* version);
+int pnp_comm_unique_id(uint8_t* id /*[PNP_COMM_ID_BYTES]*/);
+int pnp_comm_init(int32_t rank, int32_t world, const uint8_t* id, void** comm_out);
+int pnp_comm_allreduce(void* comm, void* buf, size_t n, int32_t dtype, void* stream);
+int pnp_comm_destroy(void* comm);
 
 /* y = a*x + b*y elementwise (gradient fan-in adds) */
 int pnp_axpby(const float* x, float* y, size_t n, float a, float b, void* stream);

@@ -20,6 +20,9 @@ LIB_PATH = os.environ.get("PNP_LIB") or os.path.join(_HERE, "libpnp_hip.so")   #
 PAD_ZERO = 0
 PAD_SYMMETRIC = 1
 OPT_CHUNK = 1024
+DTYPE_F32, DTYPE_BF16, DTYPE_F64 = 0, 1, 2
+COMM_ID_BYTES = 128
+ABI_VERSION = 2
 
 
 class ConvGeom(ctypes.Structure):
@@ -29,6 +32,15 @@ class ConvGeom(ctypes.Structure):
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+class ProfRow(ctypes.Structure):
+    """mirror of `pnp_prof_row` (include/pnp_hip.h)"""
+    _fields_ = [("name", ctypes.c_char * 128), ("launches", c_int64), ("ms", ctypes.c_double), ("flops", ctypes.c_double),
+                ("bytes", ctypes.c_double)]
+
+
+PROF_CONV_FWD, PROF_CONV_DGRAD, PROF_CONV_WGRAD, PROF_CONV_DIRECT = 1, 2, 4, 8
 
 
 class PnpError(RuntimeError):
@@ -43,6 +55,8 @@ PROTOTYPES = {
     "pnp_abi_version": (c_int, []),
     "pnp_last_error": (c_char_p, []),
     "pnp_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "pnp_prof_enable": (c_int, [c_int32]),
+    "pnp_prof_summary": (c_int, [POINTER(ProfRow), c_int32]),
     "pnp_conv2d_fwd": (c_int, [_F, _F, _F, _G, c_float, c_uint64, c_uint32, c_void_p]),
     "pnp_conv2d_dgrad_workspace_bytes": (c_size_t, [_G]),
     "pnp_conv2d_dgrad": (c_int, [_F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
@@ -86,6 +100,12 @@ PROTOTYPES = {
     "pnp_axpby": (c_int, [_F, _F, c_size_t, c_float, c_float, c_void_p]),
     "pnp_wgan_loss": (c_int, [_F, _F, _F, _F, c_int32, c_float, c_float, c_float, c_float, _F, c_void_p]),
     "pnp_fill": (c_int, [_F, c_size_t, c_float, c_void_p]),
+    "pnp_comm_load": (c_int, [c_char_p]),
+    "pnp_comm_version": (c_int, [POINTER(c_int)]),
+    "pnp_comm_unique_id": (c_int, [c_void_p]),
+    "pnp_comm_init": (c_int, [c_int32, c_int32, c_void_p, POINTER(c_void_p)]),
+    "pnp_comm_allreduce": (c_int, [c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "pnp_comm_destroy": (c_int, [c_void_p]),
 }
 
 _lib = None
@@ -105,8 +125,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError here == ABI drift; let it propagate loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.pnp_abi_version() != 1:
-        raise PnpError("libpnp_hip.so ABI version %d != 1" % lib.pnp_abi_version())
+    if lib.pnp_abi_version() != ABI_VERSION:
+        raise PnpError("libpnp_hip.so ABI version %d != %d (rebuild: python __graft_entry__.py)" % (lib.pnp_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -115,6 +135,18 @@ def check(code, what):
     if code != 0:
         msg = load().pnp_last_error()
         raise PnpError("%s failed (%d): %s" % (what, code, msg.decode() if msg else "?"))
+
+
+def prof_enable(mask):
+    check(load().pnp_prof_enable(int(mask)), "pnp_prof_enable")
+
+
+def prof_summary(max_rows=256):
+    """[{name, launches, ms, flops, bytes}] per kernel symbol since the last call (waits for the recorded events)"""
+    rows = (ProfRow * max_rows)()
+    n = load().pnp_prof_summary(rows, max_rows)
+    return [{"name": rows[i].name.decode(), "launches": int(rows[i].launches), "ms": rows[i].ms, "flops": rows[i].flops,
+             "bytes": rows[i].bytes} for i in range(min(n, max_rows))]
 
 
 def device_info(device=0):

@@ -1444,6 +1444,12 @@ int choose_split(long long M, int K, int Kred, int tile) {
     return nsplit < 1 ? 1 : nsplit;
 }
 
+inline double conv_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.K * a.Kred; }
+inline double conv_bytes(const ConvArgs& a) {
+    return 4.0 * ((double)a.N * a.H * a.W * a.C + (double)a.M * a.K + (double)a.Kred * a.K);
+}
+inline int prof_class(int kind) { return kind == 0 ? PNP_PROF_CONV_FWD : PNP_PROF_CONV_DGRAD; }
+
 // filter shapes the tap-unrolled kernel is instantiated for: forward 3x3 / 5x5; data gradient 3x3 and the stride-phase sub-filters
 constexpr bool taps_shape(int kind, int R, int S) {
     if (R == 3 && S == 3) return true;
@@ -1456,6 +1462,8 @@ template <int BM, int BN, int WM, int WN, int KIND>
 bool launch_taps(const ConvArgs& a, dim3 grid, hipStream_t st) {
 #define PNP_TAPS(RR, SS)                                                                                                   \
     if (a.R == RR && a.S == SS) {                                                                                          \
+        PnpProfScope ps(prof_class(KIND), st, conv_flops(a), conv_bytes(a), "conv_taps_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, \
+                        WM, WN, KIND, RR, SS);                                                                              \
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, WM, WN, KIND, RR, SS>), grid, dim3(NTHREADS), 0, st, a);               \
         return true;                                                                                                       \
     }
@@ -1499,12 +1507,16 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
             PNP_CHECK_LAUNCH("conv_taps_kernel");
         }
     }
-    if (taps) {
-    } else if (mode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
-    else if (mode == 1 && KIND != 2 && a.pad_mode == PNP_PAD_ZERO && a.C >= 16 && !getenv("PNP_CONV_NOINCR"))
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 4, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 1, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
-    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 2, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    if (!taps) {
+        static const int env_noincr = getenv("PNP_CONV_NOINCR") ? 1 : 0;
+        const int kmode = mode == 0 ? 0 : (mode == 2 ? 2 : ((KIND != 2 && a.pad_mode == PNP_PAD_ZERO && a.C >= 16 && !env_noincr) ? 4 : 1));
+        PnpProfScope ps(prof_class(KIND), st, conv_flops(a), conv_bytes(a), "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %s>", BM, BN, WM, WN,
+                        kmode, KIND, VECB ? "true" : "false");
+        if (kmode == 0) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 0, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
+        else if (kmode == 4) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 4, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
+        else if (kmode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 1, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
+        else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 2, KIND, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    }
     PNP_CHECK_LAUNCH("conv_fwd_kernel");
     if (nsplit > 1) {
         const size_t nout = (size_t)a.M * a.K;
@@ -1576,9 +1588,14 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     static const int env_nolin = getenv("PNP_CONV_NOLIN") ? 1 : 0;
     const bool lin = !env_nolin && a.stride == 1 && a.pad_mode == PNP_PAD_ZERO && (a.C % 4) == 0 && a.OW >= BK &&
                      a.x_bytes < 0x80000000u && a.w_bytes < 0x80000000u;
-    if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 3, VECB>), grid, dim3(NTHREADS), 0, st, a);
-    else if (a.C % 4 == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 1, VECB>), grid, dim3(NTHREADS), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 2, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    {
+        const int kmode = lin ? 3 : ((a.C % 4 == 0) ? 1 : 2);
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "conv_wgrad_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, WM, WN,
+                        kmode, VECB ? "true" : "false");
+        if (lin) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 3, VECB>), grid, dim3(NTHREADS), 0, st, a);
+        else if (a.C % 4 == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 1, VECB>), grid, dim3(NTHREADS), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 2, VECB>), grid, dim3(NTHREADS), 0, st, a);
+    }
     PNP_CHECK_LAUNCH("conv_wgrad_kernel");
     if (nsplit > 1) {
         int nb = pnp_cdiv((long long)nout, 256);
@@ -1609,6 +1626,9 @@ int launch_narrow_inst(const NarrowArgs& na, dim3 grid, size_t lds, hipStream_t 
     PNP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_narrow_kernel<KK, EXACT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
                 "conv_fwd_narrow_kernel: cannot reserve %zu bytes of LDS", lds);
+    const double npx = (double)na.N * na.OH * na.OW, red = (double)na.R * na.S * na.C;
+    PnpProfScope ps(PNP_PROF_CONV_DIRECT, st, 2.0 * npx * red * na.K, 4.0 * ((double)na.N * na.H * na.W * na.C + npx * na.K + red * na.K),
+                    "conv_fwd_narrow_kernel<%d, %s>", KK, EXACT ? "true" : "false");
     hipLaunchKernelGGL((conv_fwd_narrow_kernel<KK, EXACT>), grid, dim3(256), lds, st, na);
     PNP_CHECK_LAUNCH("conv_fwd_narrow_kernel");
     return PNP_OK;
@@ -1657,6 +1677,8 @@ int launch_wgd(const WgdArgs& a, const WgdPlan& pl, hipStream_t st) {
     const size_t lds = pl.G > 1 ? (size_t)pl.G * a.npairs * a.K * sizeof(float) : 0;
     dim3 grid((unsigned)pl.nblk), blk(256);
     const int nquads = a.npairs / 4;
+    PnpProfScope ps(PNP_PROF_CONV_DIRECT, st, 2.0 * (double)a.P * a.npairs * a.K,
+                    4.0 * ((double)a.N * a.H * a.W * a.C + (double)a.P * a.K + (double)a.npairs * a.K), "wgrad_direct_kernel<%d> (all variants)", KK);
     if ((a.C % 4) == 0 && nquads >= 128 && nquads <= 512 && KK <= 8) {      // quads: one 16-byte x load per 4 pairs
         if (nquads <= 256) hipLaunchKernelGGL((wgrad_direct4_kernel<KK, 1, EXACT>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL((wgrad_direct4_kernel<KK, 2, EXACT>), grid, blk, 0, st, a);

@@ -1,6 +1,10 @@
 // core.hip — error channel, ABI version and device query of libpnp_hip.so.
 #include <stdarg.h>
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 #include "pnp_common.h"
 
 static thread_local char g_err[512] = "";
@@ -12,9 +16,85 @@ void pnp_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- kernel-level timing (bench.py's roofline): HIP events on the launch stream around the dominant kernel of a call -----------
+namespace {
+struct ProfRec {
+    std::string name;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_recs;
+int g_prof_mask = 0;
+constexpr size_t kProfCap = 1u << 18;
+}  // namespace
+
+PnpProfScope::PnpProfScope(int cls, hipStream_t st, double flops, double bytes, const char* fmt, ...) : idx_(-1), st_(st) {
+    if (!(g_prof_mask & cls)) return;
+    char name[128];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(name, sizeof(name), fmt, ap);
+    va_end(ap);
+    ProfRec r{name, flops, bytes, nullptr, nullptr};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_recs.size() >= kProfCap) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+        return;
+    }
+    idx_ = (int)g_prof_recs.size();
+    g_prof_recs.push_back(r);
+}
+
+PnpProfScope::~PnpProfScope() {
+    if (idx_ < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if ((size_t)idx_ < g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx_].e1, st_);
+}
+
 extern "C" {
 
-int pnp_abi_version(void) { return 1; }
+int pnp_abi_version(void) { return 2; }
+
+int pnp_prof_enable(int mask) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_mask = mask;
+    return PNP_OK;
+}
+
+int pnp_prof_summary(pnp_prof_row* rows, int max_rows) {
+    std::vector<ProfRec> recs;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        recs.swap(g_prof_recs);
+    }
+    std::map<std::string, pnp_prof_row> agg;
+    for (ProfRec& r : recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            pnp_prof_row& row = agg[r.name];
+            if (row.launches == 0) {
+                memset(&row, 0, sizeof(row));
+                strncpy(row.name, r.name.c_str(), sizeof(row.name) - 1);
+            }
+            row.launches += 1;
+            row.ms += ms;
+            row.flops += r.flops;
+            row.bytes += r.bytes;
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    int n = 0;
+    for (auto& kv : agg) {
+        if (rows && n < max_rows) rows[n] = kv.second;
+        ++n;
+    }
+    return n;
+}
 
 const char* pnp_last_error(void) { return g_err; }
 

@@ -58,4 +58,14 @@ __host__ __device__ __forceinline__ bool pnp_drop_keep(uint32_t idx, uint32_t ke
     return (h >> 8) >= thresh;
 }
 
+// Times one kernel launch with HIP events on its own stream when pnp_prof_enable(mask) selects its class (core.hip); a no-op otherwise.
+// name = the kernel symbol as rocprofv3 prints it, so that bench.py's live numbers and the committed --kernel-trace summaries line up.
+struct PnpProfScope {
+    PnpProfScope(int cls, hipStream_t st, double flops, double bytes, const char* fmt, ...) __attribute__((format(printf, 6, 7)));
+    ~PnpProfScope();
+    PnpProfScope(const PnpProfScope&) = delete;
+    int idx_;
+    hipStream_t st_;
+};
+
 static inline int pnp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -244,3 +244,15 @@ class WganLossFn(Function):
                     n *= d
                 grads.append(K.filled(shp, ctx.coefs[i] * ctx.gscale / n, ctx.dev))
         return grads[0], grads[1], grads[2], grads[3], None, None
+
+
+# ---- arithmetic type of the convolution operands (BASELINE configs[4]) ----------------------------------------------------------
+CONV_DTYPE = "f32"
+
+
+def set_conv_dtype(name):
+    """'f32' (the reference's arithmetic; default) or 'bf16' (bf16 MFMA operands, fp32 accumulation, fp32 master weights)"""
+    global CONV_DTYPE
+    if name not in ("f32", "bf16"):
+        raise ValueError("conv dtype must be 'f32' or 'bf16', got %r" % (name,))
+    CONV_DTYPE = name

@@ -13,28 +13,118 @@ over the 8 GPUs of a node is new functionality required by BASELINE.json.  Desig
     all-reduced (tiny, latency-bound messages: ~2 per BN layer per pass), which makes W ranks x B slices compute exactly the
     single-GPU step on W*B slices.  It exists for that parity test (tests/test_gpu_dp.py); production keeps it off.
 """
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
+
+class NativeComm(object):
+    """One RCCL communicator per process behind the C-ABI (pnp_comm_*, csrc/comm.hip): the gradient / statistics all-reduces are
+    enqueued by libpnp_hip.so directly on the HIP stream the caller names — no torch.distributed on the data path.  The 128-byte
+    RCCL unique id travels from rank 0 over the torchrun rendezvous (a gloo broadcast of a CPU tensor: control plane only)."""
+
+    def __init__(self, rank, world, group=None):
+        lib = _lib.load()
+        # bind the librccl.so that ships inside the PyTorch wheel: it links the HIP runtime this process already uses (see _lib.py)
+        cand = os.environ.get("PNP_RCCL_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        _lib.check(lib.pnp_comm_load(cand.encode() if os.path.exists(cand) else None), "pnp_comm_load")
+        ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            _lib.check(lib.pnp_comm_unique_id(ctypes.c_void_p(ident.data_ptr())), "pnp_comm_unique_id")
+        if world > 1:
+            dist.broadcast(ident, src=0, group=group)
+        self.handle = ctypes.c_void_p()
+        _lib.check(lib.pnp_comm_init(rank, world, ctypes.c_void_p(ident.data_ptr()), ctypes.byref(self.handle)), "pnp_comm_init")
+        self.rank, self.world = rank, world
+        v = ctypes.c_int()
+        _lib.check(lib.pnp_comm_version(ctypes.byref(v)), "pnp_comm_version")
+        self.version = v.value
+
+    def allreduce_(self, t, stream=None):
+        """in-place sum of a contiguous float32 / float64 device tensor, enqueued on `stream` (default: the current stream)"""
+        if not (t.is_cuda and t.is_contiguous()):
+            raise _lib.PnpError("pnp_comm_allreduce needs a contiguous device tensor")
+        dt = {torch.float32: _lib.DTYPE_F32, torch.float64: _lib.DTYPE_F64}.get(t.dtype)
+        if dt is None:
+            raise _lib.PnpError("pnp_comm_allreduce: unsupported dtype %s" % t.dtype)
+        st = stream if stream is not None else torch.cuda.current_stream()
+        _lib.check(_lib.load().pnp_comm_allreduce(self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(), dt, ctypes.c_void_p(st.cuda_stream)),
+                   "pnp_comm_allreduce")
+        return t
+
+    def destroy(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            _lib.check(_lib.load().pnp_comm_destroy(self.handle), "pnp_comm_destroy")
+            self.handle = ctypes.c_void_p()
+
+
+_COMM = None     # NativeComm while the native RCCL transport is up
+
+
+def native_comm():
+    return _COMM
+
+
+def transport():
+    """what carries the data-path collectives of this process"""
+    if _COMM is not None:
+        return "rccl-native %d (pnp_comm_*, control plane: torch.distributed/%s)" % (_COMM.version, dist.get_backend() if dist.is_initialized() else "-")
+    if dist.is_initialized():
+        return "torch.distributed/%s" % dist.get_backend()
+    return None
+
 
 def init_distributed(backend=None):
-    """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world_size)."""
+    """Initialise the process group from the torchrun environment; returns (rank, local_rank, world_size).
+
+    On GPUs the DATA path is native RCCL through the C-ABI (NativeComm); torch.distributed (gloo) only carries the rendezvous, the
+    unique-id broadcast and host-side barriers.  PNP_COMM=torch selects torch.distributed's own nccl(=RCCL) backend instead;
+    PNP_DIST_BACKEND=gloo (tests) lets several ranks share ONE GPU, which RCCL refuses, with gloo on the data path too."""
+    global _COMM
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            # PNP_DIST_BACKEND=gloo lets the overlapped reducer be exercised with several ranks sharing ONE GPU (RCCL refuses
-            # duplicate devices); production is always nccl (= RCCL over xGMI)
-            backend = os.environ.get("PNP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
+        forced = backend or os.environ.get("PNP_DIST_BACKEND")
+        want_native = (forced is None and torch.cuda.is_available() and os.environ.get("PNP_COMM", "rccl") != "torch")
+        if want_native:
+            backend = "gloo"
+        elif forced is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        else:
+            backend = forced
+        if torch.cuda.is_available() and not os.environ.get("PNP_SAME_DEVICE"):
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if want_native:
+            _COMM = NativeComm(rank, world)
     return rank, local, world
+
+
+def shutdown():
+    global _COMM
+    if _COMM is not None:
+        _COMM.destroy()
+        _COMM = None
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def all_max_scalar(value, device=None):
+    """max over the ranks of a host scalar (bench timing); host tensors over gloo, a device tensor when the group is nccl"""
+    if not dist.is_initialized():
+        return float(value)
+    on_dev = dist.get_backend() == "nccl"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if on_dev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 _SYNC = None     # (process group, world size) while batch statistics and loss normalisers are synchronised across replicas
@@ -59,7 +149,10 @@ def sync_world():
 def all_sum_(t):
     """in-place sum over the replicas of the sync group (no-op when synchronisation is off)"""
     if _SYNC:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_SYNC[0])
+        if _COMM is not None and _SYNC[0] is None and t.is_cuda:
+            _COMM.allreduce_(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_SYNC[0])
     return t
 
 
@@ -121,6 +214,7 @@ class GradReducer(object):
                 cur_end = None
         if cur_end is not None:
             self._close(cur_start, cur_end, members)
+        self.native = _COMM if (group is None and store.arena.is_cuda) else None      # data path: pnp_comm_allreduce on OUR stream
         self.side = torch.cuda.Stream() if self.overlap else None
         if self.overlap:
             for v in tr:
@@ -158,8 +252,11 @@ class GradReducer(object):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.side.wait_event(ev)
-        with torch.cuda.stream(self.side):
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        if self.native is not None:
+            self.native.allreduce_(view, self.side)       # RCCL's kernel is enqueued on the side stream itself: the event above is the fence
+        else:
+            with torch.cuda.stream(self.side):
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
 
     def allreduce(self, grad_arena=None):
         """call after backward: finishes every outstanding bucket; afterwards the arena holds the summed gradients."""
@@ -177,4 +274,7 @@ class GradReducer(object):
         else:
             for b, (s, e) in enumerate(self.buckets):
                 if any(v.tensor.requires_grad for v in self._members[b]):
-                    dist.all_reduce(self.store.grad_arena[s:e], op=dist.ReduceOp.SUM, group=self.group)
+                    if self.native is not None:
+                        self.native.allreduce_(self.store.grad_arena[s:e])
+                    else:
+                        dist.all_reduce(self.store.grad_arena[s:e], op=dist.ReduceOp.SUM, group=self.group)

@@ -154,3 +154,55 @@ def l2_coefficient(name, which, miu=0.002, gan_reg=1e-4, lam=0.3, sub_iter=1):
             return gan_reg * miu * 2.0 * lam / sub_iter
         return 0.0
     return gan_reg * miu / sub_iter if name.startswith("adapt_") else 0.0
+
+
+def _set_grad(V, pred):
+    for k, v in V.items():
+        v.requires_grad_(bool(pred(k)) and not k.endswith(("moving_mean", "moving_variance")))
+        v.grad = None
+
+
+def dis_train_step(V, ms, mr, ct, keep_prob, seed, lr=3e-4, lam=0.3, miu=0.002, sub_iter=1):
+    """sess.run(dis_optimizer) + sess.run(clip_op) of adversarial.py:852-861: segmenter frozen with every BN in inference mode, both
+    critics on batch statistics, RMSProp over cls_vars, then the +-0.03 clip of the critics' filters.  ms: dict of RMSProp slots
+    (created at 1.0 on first use).  Returns (dis_loss, grads)."""
+    _set_grad(V, lambda k: "cls" in k)
+    o = adv_forward(V, mr, ct, keep_prob, seed=seed, segmenter_no_grad=True)
+    dis, _ = wgan_losses(o, miu_dis=miu, lam=lam)
+    dis.backward()
+    grads = {}
+    with torch.no_grad():
+        for k, v in V.items():
+            if not v.requires_grad:
+                continue
+            g = (v.grad if v.grad is not None else torch.zeros_like(v)) + l2_coefficient(k, "dis", miu=miu, lam=lam, sub_iter=sub_iter) * v
+            grads[k] = g
+            T.rmsprop_update(v, g, ms.setdefault(k, torch.ones_like(v)), lr)
+            if "Variable" in k:
+                v.clamp_(-0.03, 0.03)
+    return dis.detach(), grads, o
+
+
+def gen_train_step(V, ms, ct, keep_prob, seed, lr=3e-4, lam=0.3, miu=0.002, sub_iter=1):
+    """sess.run(gen_optimizer) of adversarial.py:875-881: CT front in BN-training mode, RMSProp over adapt_vars"""
+    _set_grad(V, lambda k: k.startswith("adapt_"))
+    o = adv_forward(V, None, ct, keep_prob, ct_front_bn=True, seed=seed)
+    _, gen = wgan_losses(o, miu_gen=miu, lam=lam)
+    gen.backward()
+    grads = {}
+    with torch.no_grad():
+        for k, v in V.items():
+            if not v.requires_grad:
+                continue
+            g = (v.grad if v.grad is not None else torch.zeros_like(v)) + l2_coefficient(k, "gen", miu=miu, lam=lam, sub_iter=sub_iter) * v
+            grads[k] = g
+            T.rmsprop_update(v, g, ms.setdefault(k, torch.ones_like(v)), lr)
+    return gen.detach(), grads, o
+
+
+def joint_train_step(V, ms_dis, ms_gen, mr, ct, keep_prob, seed, lr=3e-4):
+    """the joint step BASELINE.json's metric is quoted on: 1 discriminator update on (B MR, B CT) + clip, then 1 generator update on
+    the B CT slices (adversarial.py:839-882 with dis_sub_iter = gen_sub_iter = 1)"""
+    d, _, _ = dis_train_step(V, ms_dis, mr, ct, keep_prob, seed, lr)
+    g, _, _ = gen_train_step(V, ms_gen, ct, keep_prob, seed + 1, lr)
+    return d, g

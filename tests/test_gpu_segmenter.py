@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from conftest import pkg
+from parity_util import assert_argmax_exact
 from oracle import nets
 from oracle import tf_ops as T
 
@@ -91,14 +92,8 @@ def test_segmenter_train_step_parity(dev, keep_prob, logit_scale):
     assert abs(float(loss) - float(cost64)) < 1e-4 * max(1.0, abs(float(cost64)))
 
     # argmax label map must be bit exact; a mismatch is tolerated only where the fp64 top-2 margin is itself within fp32 noise
-    lab, lab64 = logits.argmax(-1), logits64.argmax(-1)
-    top2 = torch.topk(logits64, 2, dim=-1).values
-    margin = top2[..., 0] - top2[..., 1]
-    mism = lab != lab64
-    noise = 1e-5 * float(logits64.abs().max())
-    print("argmax mismatches %d of %d (fp64 margin at mismatches <= %.3e, noise floor %.3e); cpu-fp32 mismatches %d" % (
-        int(mism.sum()), lab.numel(), float(margin[mism].max()) if mism.any() else 0.0, noise, int((logits32.argmax(-1) != lab64).sum())))
-    assert int((mism & (margin > noise)).sum()) == 0
+    assert_argmax_exact(logits, logits64, "HIP label map vs float64 oracle")
+    print("cpu-fp32 oracle mismatches vs fp64: %d" % int((logits32.argmax(-1) != logits64.argmax(-1)).sum()))
 
     rows = []
     for k, g in g64.items():
