@@ -393,8 +393,8 @@ class Full_DRN(object):
 
     # ---- checkpoints / phase hand-off (own .npz format keyed by the TF names) -------------------------------------
     def save(self, path):
-        np.savez(path, **{k.replace("/", "|"): v for k, v in self.store.state_dict().items()})
-        return path
+        from .lib import atomic_savez
+        return atomic_savez(path, **{k.replace("/", "|"): v for k, v in self.store.state_dict().items()})
 
     def restore(self, sess_or_none, model_path, no_gan=False, clear_rms=False):
         """adversarial.py:503-574: name-matched restore.  no_gan: only the main variables — names containing 'group' or 'output' and
@@ -457,19 +457,32 @@ class RMSPropOptimizer(object):
         self.store, self.lr, self.decay, self.eps = store, float(learning_rate), decay, epsilon
         self.ms = torch.ones_like(store.arena)
         self.l2, self.mask = l2_table, mask
+        self._mask_host = mask.detach().cpu().numpy() if mask is not None else None
 
     def step(self):
         K.rmsprop_step(self.store.arena, self.store.grad_arena, self.ms, self.l2, self.mask, self.lr, self.decay, self.eps)
 
     # the slot and the learning rate are TF variables in the reference, i.e. part of every checkpoint (tf.train.Saver)
+    def _mine(self, v):
+        """variables of this optimiser's var_list (the chunks its mask selects)"""
+        from ._lib import OPT_CHUNK
+        return bool(self._mask_host[v.offset // OPT_CHUNK]) if self._mask_host is not None else True
+
     def state_dict(self):
-        return {"ms": self.ms.detach().cpu().numpy(), "lr": np.float64(self.lr)}
+        """'<variable>|RMSProp' per variable of the var_list — keyed by NAME: the arena layout changes between the pre-train graph
+        (adapt_* frozen) and the train-gan graph, the names do not"""
+        d = {"lr": np.float64(self.lr)}
+        d.update(self.store.slots_to_dict(self.ms, "RMSProp", self._mine))
+        return d
 
     def load_state_dict(self, sd, slots=True, lr=True):
+        """-> (restored, missing) variable names of the var_list"""
+        done, missing = ([], [])
         if slots:
-            self.ms.copy_(torch.from_numpy(np.asarray(sd["ms"], dtype=np.float32)).reshape(self.ms.shape))
-        if lr:
+            done, missing = self.store.slots_from_dict(self.ms, sd, "RMSProp", self._mine)
+        if lr and "lr" in sd:
             self.lr = float(sd["lr"])
+        return done, missing
 
 
 class Trainer(object):
@@ -498,11 +511,13 @@ class Trainer(object):
         self.step_times = []
         self.loss_dict = {}
 
-    def next_batch(self, source):
+    def next_batch(self, source, capacity=120, num_threads=2, min_after_dequeue=30):
+        """adversarial.py:607-631 (shuffle_batch: 2 reader threads, capacity 120, min_after_dequeue 30)"""
         from .tfrecord import SliceQueue
         if hasattr(source, "next_batch"):
             return source
-        return SliceQueue(source, self.batch_size, shard=self.shard)
+        return SliceQueue(source, self.batch_size, capacity=capacity, min_after_dequeue=min_after_dequeue, num_threads=num_threads,
+                          shard=self.shard)
 
     def _feeder(self, source):
         from .feeder import DeviceFeeder
@@ -527,23 +542,36 @@ class Trainer(object):
     def save_checkpoint(self, output_path):
         """lib._save (tf.train.Saver over ALL variables, lib.py:23-29): the model variables plus the RMSProp slots, the two learning
         rates and the global step"""
-        self.net.save(os.path.join(output_path, "checkpoint.npz"))
+        from .lib import atomic_savez
+        ck = os.path.join(output_path, "checkpoint.npz")
+        self.net.save(ck)
         d, g = self.dis_optimizer.state_dict(), self.gen_optimizer.state_dict()
-        np.savez(os.path.join(output_path, "optimizer.npz"), dis_ms=d["ms"], dis_lr=d["lr"], gen_ms=g["ms"], gen_lr=g["lr"],
-                 global_step=np.int64(self.global_step))
+        slots = {k: v for src in (d, g) for k, v in src.items() if k != "lr"}       # the two var_lists are disjoint (cls* / adapt*)
+        atomic_savez(os.path.join(output_path, "optimizer.npz"), kind="rmsprop", dis_lr=d["lr"], gen_lr=g["lr"],
+                     global_step=np.int64(self.global_step), **slots)
+        return ck
 
     def restore_optimizer(self, restored_path, clear_rms, lr_update):
-        """adversarial.py:503-574, 803-805: RMSProp slots come back unless clear_rms; the learning rates come back unless lr_update
-        (then the configured rate replaces the checkpoint's, LR_refresh)"""
+        """adversarial.py:503-574, 803-805: RMSProp slots come back unless clear_rms, matched BY VARIABLE NAME like tf.train.Saver
+        (so the critic slots warmed up by --phase pre-train survive into --phase train-gan, whose graph also trains adapt_* and
+        therefore lays its arena out differently); the learning rates come back unless lr_update (LR_refresh replaces them)."""
         f = os.path.join(restored_path, "optimizer.npz")
         if not os.path.exists(f):
             return False
         with np.load(f) as z:
-            if "dis_ms" not in z.files or z["dis_ms"].size != self.dis_optimizer.ms.numel():
+            if "kind" not in z.files or str(z["kind"]) != "rmsprop":
+                logging.warning("optimizer state in %s is not RMSProp state of the adaptation graph: slots start fresh" % f)
                 return False                                   # a checkpoint of another graph (e.g. the source segmenter's)
-            self.dis_optimizer.load_state_dict({"ms": z["dis_ms"], "lr": z["dis_lr"]}, slots=not clear_rms, lr=not lr_update)
-            self.gen_optimizer.load_state_dict({"ms": z["gen_ms"], "lr": z["gen_lr"]}, slots=not clear_rms, lr=not lr_update)
+            sd = {k: z[k] for k in z.files}
+            dd, dm = self.dis_optimizer.load_state_dict(dict(sd, lr=sd["dis_lr"]), slots=not clear_rms, lr=not lr_update)
+            gd, gm = self.gen_optimizer.load_state_dict(dict(sd, lr=sd["gen_lr"]), slots=not clear_rms, lr=not lr_update)
             self.global_step = int(z["global_step"])
+        if not clear_rms:
+            if not (dd or gd):
+                raise RuntimeError("restore with clear_rms=False asked for the RMSProp slots, but %s holds none for this graph" % f)
+            if dm or gm:
+                logging.warning("RMSProp slots not in %s for %d variables (e.g. %s): they start at 1.0 like a fresh tf slot" % (
+                    f, len(dm) + len(gm), (dm + gm)[0]))
         return True
 
     def dis_step(self, mr_batch, ct_batch, dropout, seed):
@@ -569,7 +597,7 @@ class Trainer(object):
         """adversarial.py:767-946 (schedule, sub-iteration growth, periodic save + lr decay)"""
         self.output_path = output_path
         os.makedirs(output_path, exist_ok=True)
-        save_path = os.path.join(output_path, "model.cpkt")
+        save_path = os.path.join(output_path, "checkpoint.npz")      # the reference returns a Saver prefix (model.cpkt); this is the real file
         if epochs == 0:
             return save_path
         if self.dis_optimizer is None:
@@ -588,36 +616,38 @@ class Trainer(object):
         dis_inc, gen_inc = tc.get('dis_sub_iter_inc', 0), tc.get('gen_sub_iter_inc', 0)
         upd = tc.get('iter_upd_interval', 999999999999)
         seed = 1 + rank_seed(self.rank)
-        for epoch in range(epochs):
-            for step in range(epoch * training_iters, (epoch + 1) * training_iters):
-                start = time.time()
-                if dis_interval != 0 and (step % dis_interval == 0) and step != 0:
-                    for _ in range(dis_sub_iter):
-                        ct_x = ct_feed.next()[0]
-                        mr_x = mr_feed.next()[0]
-                        self.dis_step(mr_x, ct_x, dropout, seed)
-                        seed += 1
-                if gen_interval != 0 and (step % gen_interval == 0) and step != 0:
-                    for _ in range(gen_sub_iter):
-                        ct_x = ct_feed.next()[0]
-                        self.gen_step(ct_x, dropout, seed)
-                        seed += 1
-                if (step % upd == 0) and step != 0:
-                    dis_sub_iter += dis_inc
-                    gen_sub_iter += gen_inc
-                self.step_times.append(time.time() - start)
-                logging.info("Training step %s epoch %s has been finished! Time elapsed %s seconds" % (step, epoch, time.time() - start))
-                if step % display_step == 0:
-                    self.output_minibatch_stats(step, *ct_feed.next()[:2], *mr_feed.next()[:2])                # a training batch ...
-                    self.output_minibatch_stats(step, *ct_val.next()[:2], *mr_val.next()[:2], detail=True)     # ... and a validation batch
-                if step % tc.get("checkpoint_space", 100) == 0 and step != 0:
-                    if self.rank == 0:
-                        self.save_checkpoint(output_path)
-                    f = tc.get('lr_decay_factor', 1.0)
-                    self.dis_optimizer.lr *= f
-                    self.gen_optimizer.lr *= f
-        for f in (ct_feed, mr_feed, ct_val, mr_val):
-            f.close()
+        try:
+            for epoch in range(epochs):
+                for step in range(epoch * training_iters, (epoch + 1) * training_iters):
+                    start = time.time()
+                    if dis_interval != 0 and (step % dis_interval == 0) and step != 0:
+                        for _ in range(dis_sub_iter):
+                            ct_x = ct_feed.next()[0]
+                            mr_x = mr_feed.next()[0]
+                            self.dis_step(mr_x, ct_x, dropout, seed)
+                            seed += 1
+                    if gen_interval != 0 and (step % gen_interval == 0) and step != 0:
+                        for _ in range(gen_sub_iter):
+                            ct_x = ct_feed.next()[0]
+                            self.gen_step(ct_x, dropout, seed)
+                            seed += 1
+                    if (step % upd == 0) and step != 0:
+                        dis_sub_iter += dis_inc
+                        gen_sub_iter += gen_inc
+                    self.step_times.append(time.time() - start)
+                    logging.info("Training step %s epoch %s has been finished! Time elapsed %s seconds" % (step, epoch, time.time() - start))
+                    if step % display_step == 0:
+                        self.output_minibatch_stats(step, *ct_feed.next()[:2], *mr_feed.next()[:2])                # a training batch ...
+                        self.output_minibatch_stats(step, *ct_val.next()[:2], *mr_val.next()[:2], detail=True)     # ... and a validation batch
+                    if step % tc.get("checkpoint_space", 100) == 0 and step != 0:
+                        if self.rank == 0:
+                            self.save_checkpoint(output_path)
+                        f = tc.get('lr_decay_factor', 1.0)
+                        self.dis_optimizer.lr *= f
+                        self.gen_optimizer.lr *= f
+        finally:                 # reader threads, pinned buffers and copy streams go away also when a step raises
+            for f in (ct_feed, mr_feed, ct_val, mr_val):
+                f.close()
         if self.rank == 0:
             self.save_checkpoint(output_path)
         barrier()

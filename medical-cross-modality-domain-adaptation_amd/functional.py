@@ -9,6 +9,7 @@ Fused units (what TF-1.4 lowers layers.py's chains to, restated as one forward +
 """
 import os
 
+import torch
 from torch.autograd import Function
 
 from . import kernels as K
@@ -20,6 +21,13 @@ LEAK = 0.2         # tf.nn.leaky_relu default alpha (layers.py:12,35,166,187)
 # inference-mode conv -> dropout -> BN -> shortcut -> activation in one kernel (pnp_conv2d_fwd_bn) whenever the BN parameters take no
 # gradient (monitoring forwards, frozen-BN forwards of the GAN steps, volume inference); False: separate kernels
 FUSE_BN_INFER = os.environ.get("PNP_FUSE_BN_INFER", "1") != "0"
+
+
+def sync_now():
+    """Synchronised statistics only inside training steps (a tape is being recorded): monitoring / evaluation forwards run under
+    no_grad and may be rank-asymmetric (rank-0-only test_eval) — a collective there would deadlock the job.  Evaluated by the CALLER
+    of Function.apply (inside Function.forward grad mode is always off) and passed in as `sync`."""
+    return par.sync_world() > 1 and torch.is_grad_enabled()
 
 
 def _contig(t):
@@ -62,7 +70,7 @@ class ConvBNActFn(Function):
     """y = act( BN( dropout( conv(x,w) ) ) + pad_channels(shortcut) )"""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, shortcut, geom, keep_prob, seed, stream_id, is_train, alpha):
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, shortcut, geom, keep_prob, seed, stream_id, is_train, alpha, sync=False):
         x = _contig(x)
         w_ = _contig(w)
         sc = _contig(shortcut) if shortcut is not None else None
@@ -82,7 +90,7 @@ class ConvBNActFn(Function):
         ctx.P_norm = P
         if is_train:
             mean, var = K.bn_stats(xc)
-            if par.sync_world() > 1:        # opt-in SyncBN: statistics of the batch concatenated over the replicas
+            if sync:                  # opt-in SyncBN: statistics of the batch concatenated over the replicas
                 mean, var = par.sync_bn_stats(mean, var)
                 ctx.P_norm = P * par.sync_world()
             K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
@@ -106,20 +114,20 @@ class ConvBNActFn(Function):
         dx = K.conv2d_dgrad(dxc, w, ctx.geom) if ctx.needs_input_grad[0] else None
         dw = K.conv2d_wgrad(x, dxc, ctx.geom) if ctx.needs_input_grad[1] else None
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, None, None,
-                dsc, None, None, None, None, None, None)
+                dsc, None, None, None, None, None, None, None)
 
 
 class BNActFn(Function):
     """batch_norm alone (layers.batch_norm, layers.py:95-100), optional activation; no conv in front."""
 
     @staticmethod
-    def forward(ctx, xc, gamma, beta, moving_mean, moving_var, is_train, alpha):
+    def forward(ctx, xc, gamma, beta, moving_mean, moving_var, is_train, alpha, sync=False):
         xc = _contig(xc)
         P = xc.numel() // xc.shape[-1]
         ctx.P_norm = P
         if is_train:
             mean, var = K.bn_stats(xc)
-            if par.sync_world() > 1:        # opt-in SyncBN: statistics of the batch concatenated over the replicas
+            if sync:                  # opt-in SyncBN: statistics of the batch concatenated over the replicas
                 mean, var = par.sync_bn_stats(mean, var)
                 ctx.P_norm = P * par.sync_world()
             K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
@@ -135,7 +143,7 @@ class BNActFn(Function):
     def backward(ctx, dout):
         xc, out, mean, var, gamma = ctx.saved_tensors
         dxc, dgamma, dbeta, _ = _bn_bwd(ctx, _contig(dout), out, xc, mean, var, gamma, 0, 1.0, 0, 0)
-        return dxc, dgamma, dbeta, None, None, None, None
+        return dxc, dgamma, dbeta, None, None, None, None, None
 
 
 class MaxPool2Fn(Function):
@@ -184,12 +192,12 @@ class SegLossFn(Function):
     data parallelism) and is applied inside the HIP kernel — no torch arithmetic on the gradient path."""
 
     @staticmethod
-    def forward(ctx, logits, y, miu_cross, miu_dice, gscale):
+    def forward(ctx, logits, y, miu_cross, miu_dice, gscale, sync=False):
         logits = _contig(logits)
         y = _contig(y)
         out, ws = K.seg_loss_fwd(logits, y, miu_cross, miu_dice)
         ctx.P_norm = None
-        w = par.sync_world()
+        w = par.sync_world() if sync else 1
         if w > 1:       # opt-in batch-global normalisers: class counts and Dice sums of all replicas, mean over all pixels;
             par.all_sum_(K.seg_loss_sums(ws))      # `out` stays this replica's value (logging only)
             ctx.P_norm = w * (logits.numel() // logits.shape[-1])
@@ -202,7 +210,7 @@ class SegLossFn(Function):
     def backward(ctx, dout):
         logits, y, ws = ctx.saved_tensors
         g = K.seg_loss_bwd(logits, y, ws, ctx.mc, ctx.md, ctx.gscale, ctx.P_norm)
-        return g, None, None, None, None
+        return g, None, None, None, None, None
 
 
 class CriticInputFn(Function):

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
-from .functional import BNActFn, Conv2dDropFn, ConvBNActFn, LEAK, MaxPool2Fn, SymPadFn
+from .functional import BNActFn, Conv2dDropFn, ConvBNActFn, LEAK, MaxPool2Fn, SymPadFn, sync_now
 from .variables import current_store, truncated_normal
 
 
@@ -80,7 +80,7 @@ def _conv_bn(x, W, keep_prob, padding, stride, dil, is_train, scope, bn_trainabl
     keep, seed, sid = _drop_ids(keep_prob)
     if x.is_meta:
         return _meta_out(g)
-    return ConvBNActFn.apply(x, W, gamma, beta, mm, mv, shortcut, g, keep, seed, sid, bool(is_train), float(alpha))
+    return ConvBNActFn.apply(x, W, gamma, beta, mm, mv, shortcut, g, keep, seed, sid, bool(is_train), float(alpha), sync_now())
 
 
 # ---- layers.py:16-27 ---------------------------------------------------------------------------------
@@ -114,7 +114,7 @@ def batch_norm(x, is_training=True, scope=None, trainable=True):
     gamma, beta, mm, mv = _bn_vars(scope, x.shape[-1], trainable)
     if x.is_meta:
         return torch.empty(tuple(x.shape), device="meta")
-    return BNActFn.apply(x, gamma, beta, mm, mv, bool(is_training), -1.0)
+    return BNActFn.apply(x, gamma, beta, mm, mv, bool(is_training), -1.0, sync_now())
 
 
 # ---- layers.py:102-103 -------------------------------------------------------------------------------

@@ -138,3 +138,12 @@ def _indicator_eval(cm, verbose=True):
                 print("dice: %s" % dice[int(ind)])
                 print("jaccard: %s" % jaccard[int(ind)])
     return dice, jaccard
+
+
+def atomic_savez(path, **arrays):
+    """np.savez into `path` through a temporary file in the same directory + os.replace (periodic checkpoints overwrite in place)"""
+    import os
+    tmp = path + ".tmp.npz"
+    np.savez(tmp, **arrays)
+    os.replace(tmp, path)
+    return path

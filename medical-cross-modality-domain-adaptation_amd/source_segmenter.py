@@ -17,7 +17,7 @@ import torch
 
 from . import kernels as K
 from . import lib
-from .functional import SegLossFn
+from .functional import SegLossFn, sync_now
 from .layers import (DR_block, conv2d, conv_bn_relu2d, max_pool2d, pixel_wise_softmax_2, residual_block, weight_variable)
 from .lib import _dice_eval, _indicator_eval, _label_decomp
 from .ops import PS
@@ -229,7 +229,7 @@ class Full_DRN(object):
         """source_segmenter.py:211-239: returns (loss vector [total, xent, dice]); element 0 is the backward root."""
         mc = float(self.miu_cross) if self.cross_flag is True else 0.0
         md = float(self.miu_dice) if self.dice_flag is True else 0.0
-        out = SegLossFn.apply(logits, y, mc, md, 1.0 / self.world_size)
+        out = SegLossFn.apply(logits, y, mc, md, 1.0 / self.world_size, sync_now())
         return out
 
     def evaluate(self, x, y, keep_prob=1.0, main_bn=True, adapt_bn=True, want_confusion=False):
@@ -263,8 +263,7 @@ class Full_DRN(object):
 
     # -- checkpoints (own format, keyed by the TF variable names) ------------------------------
     def save(self, path):
-        np.savez(path, **{k.replace("/", "|"): v for k, v in self.store.state_dict().items()})
-        return path
+        return lib.atomic_savez(path, **{k.replace("/", "|"): v for k, v in self.store.state_dict().items()})
 
     def restore(self, sess_or_none, model_path):
         """source_segmenter.py:275-300 (relaxed name-matched restore); reads this package's .npz checkpoints."""
@@ -290,14 +289,20 @@ class AdamOptimizer(object):
 
     # slots, beta powers (t) and the learning-rate variable are part of every TF checkpoint (tf.train.Saver, lib.py:23-29)
     def state_dict(self):
-        return {"m": self.m.detach().cpu().numpy(), "v": self.v.detach().cpu().numpy(), "t": np.int64(self.t), "lr": np.float64(self.lr)}
+        """slots by variable name ('<variable>|Adam', '<variable>|Adam_1': TF's slot names), never by arena position"""
+        d = {"t": np.int64(self.t), "lr": np.float64(self.lr)}
+        d.update(self.store.slots_to_dict(self.m, "Adam"))
+        d.update(self.store.slots_to_dict(self.v, "Adam_1"))
+        return d
 
     def load_state_dict(self, sd, lr=True):
-        self.m.copy_(torch.from_numpy(np.asarray(sd["m"], dtype=np.float32)).reshape(self.m.shape))
-        self.v.copy_(torch.from_numpy(np.asarray(sd["v"], dtype=np.float32)).reshape(self.v.shape))
+        """-> (restored, missing) variable names"""
+        done, missing = self.store.slots_from_dict(self.m, sd, "Adam")
+        done_v, missing_v = self.store.slots_from_dict(self.v, sd, "Adam_1")
         self.t = int(sd["t"])
         if lr:
             self.lr = float(sd["lr"])
+        return [n for n in done if n in set(done_v)], sorted(set(missing) | set(missing_v))
 
 
 class MomentumOptimizer(object):
@@ -322,13 +327,16 @@ class MomentumOptimizer(object):
         self.t += 1
 
     def state_dict(self):
-        return {"acc": self.acc.detach().cpu().numpy(), "t": np.int64(self.t), "lr0": np.float64(self.lr0)}
+        d = {"t": np.int64(self.t), "lr0": np.float64(self.lr0)}
+        d.update(self.store.slots_to_dict(self.acc, "Momentum"))
+        return d
 
     def load_state_dict(self, sd, lr=True):
-        self.acc.copy_(torch.from_numpy(np.asarray(sd["acc"], dtype=np.float32)).reshape(self.acc.shape))
+        done, missing = self.store.slots_from_dict(self.acc, sd, "Momentum")
         self.t = int(sd["t"])
         if lr:
             self.lr0 = float(sd["lr0"])
+        return done, missing
 
 
 class Trainer(object):
@@ -371,23 +379,34 @@ class Trainer(object):
                           shard=self.shard)
 
     def save_checkpoint(self, output_path):
-        """lib._save (tf.train.Saver over ALL variables): model variables + optimiser slots / step / learning rate"""
-        self.net.save(os.path.join(output_path, "checkpoint.npz"))
-        np.savez(os.path.join(output_path, "optimizer.npz"), kind=self.optimizer, global_step=np.int64(self.global_step),
-                 **self.opt.state_dict())
+        """lib._save (tf.train.Saver over ALL variables, lib.py:23-29): model variables + optimiser slots / step / learning rate.
+        Each file is written next to its destination and renamed into place, so a reader never sees a half-written checkpoint;
+        `checkpoint-<global_step>.npz` keeps the per-step history the reference's `global_step=` argument produces."""
+        ck = os.path.join(output_path, "checkpoint.npz")
+        self.net.save(ck)
+        lib.atomic_savez(os.path.join(output_path, "optimizer.npz"), kind=self.optimizer, global_step=np.int64(self.global_step),
+                         **self.opt.state_dict())
+        if os.path.exists(ck):
+            shutil.copyfile(ck, os.path.join(output_path, "checkpoint-%d.npz" % self.global_step))
+        return ck
 
     def restore_optimizer(self, restored_path):
-        """source_segmenter.py:275-300, 460-462: whatever the checkpoint holds comes back; lr_update_flag keeps the configured rate"""
+        """source_segmenter.py:275-300, 460-462: whatever the checkpoint holds comes back, matched BY VARIABLE NAME (as tf.train.Saver
+        does); lr_update_flag keeps the configured rate.  False when the folder holds no state for this kind of optimiser."""
         f = os.path.join(restored_path, "optimizer.npz")
         if not os.path.exists(f):
             return False
         with np.load(f) as z:
             if "kind" not in z.files or str(z["kind"]) != self.optimizer:
+                logging.warning("optimizer state in %s is not %s state: slots start fresh" % (f, self.optimizer))
                 return False
-            slot = "m" if self.optimizer == "adam" else "acc"
-            if z[slot].size != self.net.store.arena.numel():
-                return False                                   # a checkpoint of another graph
-            self.opt.load_state_dict({k: z[k] for k in z.files if k not in ("kind", "global_step")}, lr=self.lr_update_flag is not True)
+            done, missing = self.opt.load_state_dict({k: z[k] for k in z.files if k not in ("kind", "global_step")},
+                                                     lr=self.lr_update_flag is not True)
+            if not done:
+                logging.warning("optimizer state in %s matches no variable of this graph: slots start fresh" % f)
+                return False
+            if missing:
+                logging.warning("optimizer slots not found in %s for %d variables (e.g. %s): they start fresh" % (f, len(missing), missing[0]))
             self.global_step = int(z["global_step"])
         return True
 
@@ -435,7 +454,9 @@ class Trainer(object):
     def train(self, output_path, restored_path=None, restore=False, training_iters=100, epochs=100, display_step=5,
               dropout=0.75):
         """source_segmenter.py:429-523"""
-        save_path = os.path.join(output_path, "model.cpkt")
+        # the reference returns "<output_path>/model.cpkt" (a tf.train.Saver prefix); here the checkpoint is this package's .npz,
+        # and the returned path is the file test_choose_model / restore can be handed
+        save_path = os.path.join(output_path, "checkpoint.npz")
         if epochs == 0:
             return save_path
         output_path = os.path.abspath(output_path)

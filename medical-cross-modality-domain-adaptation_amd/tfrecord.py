@@ -203,6 +203,9 @@ class SliceQueue(object):
         self.rng = np.random.default_rng(seed)
         self._pick = np.random.default_rng(seed + 7919)     # consumer-side shuffle (the file-order rng belongs to the readers)
         self.capacity = max(capacity, batch_size)
+        # tf.train.shuffle_batch(min_after_dequeue): a batch is only drawn while at least this many slices stay behind in the buffer
+        # (the mixing depth of the shuffle); bounded by what the capacity and the dataset can ever hold
+        self.min_after_dequeue = max(0, min(int(min_after_dequeue), self.capacity - batch_size, len(files) - batch_size))
         self._buf, self._cv = [], threading.Condition()
         self._order, self._order_lock, self._stop = [], threading.Lock(), False
         self._threads = []
@@ -244,7 +247,7 @@ class SliceQueue(object):
                 items.append((read_slice(f, self.raw_size), f))
         else:
             with self._cv:
-                while len(self._buf) < B:
+                while len(self._buf) < min(B + self.min_after_dequeue, self.capacity):
                     if getattr(self, "_error", None) is not None:
                         raise IOError("SliceQueue reader thread failed: %r" % (self._error,))
                     self._cv.wait(0.05)

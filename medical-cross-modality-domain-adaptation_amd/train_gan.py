@@ -92,7 +92,11 @@ def main(phase, argv=None):
 
     net = drn.Full_DRN(channels=3, batch_size=batch_size, n_class=num_cls, cost_kwargs=ck, network_config=nc, device=device, world_size=world)
     print("Network has been built ...")
-    if tc["restore_from_baseline"] and args.baseline:
+    if tc["restore_from_baseline"] and not args.baseline:
+        # the reference cannot get past this point either: _load_batch_norm_weights / restore raise without a baseline checkpoint
+        # (adversarial.py:706-765, 790-801); warming a critic up against a randomly initialised segmenter is never what was asked for
+        raise SystemExit("--phase %s starts from the source segmenter: pass --baseline <train_segmenter output>/checkpoint.npz" % args.phase)
+    if tc["restore_from_baseline"]:
         with np.load(args.baseline) as z:
             seg = {k.replace("|", "/"): z[k] for k in z.files}
         net.load_baseline(seg, old_bn_list, new_bn_list, adapt_var_list, mr_var_list)

@@ -186,6 +186,31 @@ class VariableStore(object):
             tab[c0:c1] = fn(v)
         return torch.from_numpy(tab).to(self.device)
 
+    # ---- optimiser slots, keyed by variable name like tf.train.Saver keys them ('<variable>/<slot>') ---------------------------------
+    def slots_to_dict(self, slot_arena, slot, select=None):
+        """{'<variable name>|<slot>': values} for every trainable variable (optionally only those `select(var)` accepts).  The arena
+        LAYOUT depends on which variables are trainable (it differs between the pre-train and train-gan graphs), names do not."""
+        out = OrderedDict()
+        for v in self.trainable():
+            if select is None or select(v):
+                out["%s|%s" % (v.name.replace("/", "|"), slot)] = slot_arena[v.offset:v.offset + v.numel].detach().cpu().numpy().reshape(v.shape)
+        return out
+
+    def slots_from_dict(self, slot_arena, sd, slot, select=None):
+        """inverse of slots_to_dict; name-matched and relaxed like tf.train.Saver.restore over a variable subset.
+        Returns (restored names, missing names)."""
+        done, missing = [], []
+        for v in self.trainable():
+            if select is not None and not select(v):
+                continue
+            key = "%s|%s" % (v.name.replace("/", "|"), slot)
+            if key in sd and tuple(np.shape(sd[key])) == v.shape:
+                slot_arena[v.offset:v.offset + v.numel].copy_(torch.from_numpy(np.asarray(sd[key], dtype=np.float32)).reshape(-1))
+                done.append(v.name)
+            else:
+                missing.append(v.name)
+        return done, missing
+
     def zero_grad(self):
         self.grad_arena.zero_()
 

@@ -1,4 +1,5 @@
-"""worker for tests/test_gpu_dp.py: 2 ranks, both on cuda:0, gloo backend (RCCL refuses duplicate devices on a 1-GPU box).
+"""worker for tests/test_gpu_dp.py: 2 ranks.  Default: both on cuda:0 over gloo (RCCL refuses duplicate devices on a 1-GPU box).
+PNP_DP_NATIVE=1 (boxes with >= 2 GPUs): one GPU per rank, native RCCL through pnp_comm_* — the production transport.
 Checks that the backward-overlapped bucketed all-reduce equals a plain all-reduce of the locally computed gradients."""
 import importlib
 import os
@@ -14,9 +15,12 @@ PKG = "medical-cross-modality-domain-adaptation_amd"
 par = importlib.import_module(PKG + ".parallel")
 ss = importlib.import_module(PKG + ".source_segmenter")
 
-rank, local, world = par.init_distributed("gloo")
-torch.cuda.set_device(0)
-dev = torch.device("cuda:0")
+NATIVE = os.environ.get("PNP_DP_NATIVE") == "1"
+rank, local, world = par.init_distributed(None if NATIVE else "gloo")
+if NATIVE:
+    assert par.native_comm() is not None and "rccl-native" in par.transport(), par.transport()
+torch.cuda.set_device(local if NATIVE else 0)
+dev = torch.device("cuda", local if NATIVE else 0)
 B = 2
 COST = {"cross_flag": True, "miu_cross": 1.0, "dice_flag": True, "miu_dice": 1.0, "regularizer": 1e-4}
 net = ss.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, cost_kwargs=dict(COST), seed=0, world_size=world)
@@ -34,11 +38,14 @@ y = torch.from_numpy(np.eye(5, dtype=np.float32)[lab]).to(dev)
 # reference: local gradients, then one plain all-reduce
 net.loss_and_grads(x, y, 0.75, drop_seed=5 + rank)
 ref = net.store.grad_arena.clone()
-dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+if NATIVE:
+    par.native_comm().allreduce_(ref)
+else:
+    dist.all_reduce(ref, op=dist.ReduceOp.SUM)
 torch.cuda.synchronize()
 
 red = par.GradReducer(net.store, bucket_bytes=16 << 20, overlap=True)
-assert red.overlap and len(red.buckets) >= 5
+assert red.overlap and len(red.buckets) >= 5 and (red.native is not None) == NATIVE
 for it in range(2):                       # twice: the hook counters must re-arm
     net.loss_and_grads(x, y, 0.75, drop_seed=5 + rank)
     red.allreduce()
@@ -50,4 +57,4 @@ for it in range(2):                       # twice: the hook counters must re-arm
 assert net.world_size == world
 dist.barrier()
 print("rank %d ok (buckets %d)" % (rank, len(red.buckets)))
-dist.destroy_process_group()
+par.shutdown()

@@ -25,8 +25,44 @@ def test_overlapped_allreduce_equals_plain(dev):
     assert p.stdout.count(" ok ") == 2
 
 
+def test_native_rccl_single_rank(dev):
+    """pnp_comm_* (csrc/comm.hip) on the one GPU of the test box: bring-up through the unique id, a sum all-reduce over a 1-rank
+    communicator enqueued on a SIDE stream behind an event (the GradReducer pattern), float32 and float64, tear-down"""
+    import torch
+    from conftest import pkg
+    par = pkg("parallel")
+    comm = par.NativeComm(0, 1)
+    assert comm.version >= 20000 and bool(comm.handle)
+    side = torch.cuda.Stream()
+    for dt in (torch.float32, torch.float64):
+        t = torch.randn(3 << 20, device=dev, dtype=dt)
+        ref = t.clone()
+        t.mul_(2.0)                                   # producer on the current stream
+        ev = torch.cuda.Event()
+        ev.record()
+        side.wait_event(ev)
+        comm.allreduce_(t, side)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(t, ref * 2.0)
+    with pytest.raises(pkg("_lib").PnpError):
+        comm.allreduce_(torch.zeros(4, device=dev, dtype=torch.int32))
+    comm.destroy()
+
+
+def test_native_rccl_two_ranks(dev):
+    """the production transport end to end: 2 ranks on 2 GPUs, overlapped bucketed pnp_comm_allreduce == one plain all-reduce
+    (skipped on 1-GPU boxes: RCCL refuses two ranks on one device)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    p = _run([os.path.join(ROOT, "tests", "dp_worker.py")], {"PNP_DP_NATIVE": "1"})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.stdout.count(" ok ") == 2
+
+
 def test_bench_two_rank_launch_line(dev):
-    p = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"],
+    p = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--workload", "segmenter",
+              "--no-sub"],
              {"PNP_DIST_BACKEND": "gloo", "PNP_SAME_DEVICE": "1"})
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
@@ -41,6 +77,7 @@ def test_bench_two_rank_gan_workload(dev):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 2 and "joint" in r["metric"] and r["value"] > 0 and "cpu_baseline" not in r
+    assert r["segmenter_step"]["value"] > 0 and r["roofline"]["launches"] > 0 and len(r["roofline_kernels"]) >= 3
 
 
 def test_train_segmenter_two_ranks(dev, tmp_path):

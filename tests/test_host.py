@@ -346,6 +346,12 @@ def test_segmenter_training_schedule_with_stub_step(tmp_path):
         assert str(z["kind"]) == "adam" and int(z["t"]) == 7 and int(z["global_step"]) == 0 and float(z["lr"]) == 1e-3
 
 
+def _same_slots(store, a, b, select=None):
+    """slot arenas agree on every (selected) variable's range — the chunk-alignment gaps between variables are not state"""
+    return all(torch.equal(a[v.offset:v.offset + v.numel], b[v.offset:v.offset + v.numel]) for v in store.trainable()
+               if select is None or select(v))
+
+
 def test_optimizer_state_travels_with_checkpoints(tmp_path):
     """Adam / momentum / RMSProp slots, step counters and learning rates are TF variables in the reference, i.e. saved and restored by
     tf.train.Saver; restore honours lr_update_flag / clear_rms / lr_update (source_segmenter.py:460-462, adversarial.py:503-574, 803-805)"""
@@ -363,7 +369,7 @@ def test_optimizer_state_travels_with_checkpoints(tmp_path):
         tr2 = ss.Trainer(net, None, None, num_cls=5, batch_size=2, optimizer="adam", opt_kwargs={"learning_rate": 1e-3}, lr_update_flag=flag)
         tr2.opt = tr2._get_optimizer(10)
         assert tr2.restore_optimizer(out)
-        assert torch.equal(tr2.opt.m, tr.opt.m) and torch.equal(tr2.opt.v, tr.opt.v) and tr2.opt.t == 41 and tr2.global_step == 41
+        assert _same_slots(net.store, tr2.opt.m, tr.opt.m) and _same_slots(net.store, tr2.opt.v, tr.opt.v) and tr2.opt.t == 41 and tr2.global_step == 41
         assert tr2.opt.lr == lr_expected
     trm = ss.Trainer(net, None, None, num_cls=5, batch_size=2, optimizer="momentum", opt_kwargs={"learning_rate": 0.2})
     trm.opt = trm._get_optimizer(10)
@@ -389,12 +395,47 @@ def test_optimizer_state_travels_with_checkpoints(tmp_path):
         a2 = adv.Trainer(anet, None, None, None, None, num_cls=5, batch_size=2, opt_kwargs={"learning_rate": 3e-4})
         a2._get_optimizer()
         assert a2.restore_optimizer(aout, clear_rms=clear_rms, lr_update=lr_update)
-        same = torch.equal(a2.dis_optimizer.ms, at.dis_optimizer.ms) and torch.equal(a2.gen_optimizer.ms, at.gen_optimizer.ms)
+        same = (_same_slots(anet.store, a2.dis_optimizer.ms, at.dis_optimizer.ms, lambda v: "cls" in v.name) and
+                _same_slots(anet.store, a2.gen_optimizer.ms, at.gen_optimizer.ms, lambda v: "adapt" in v.name))
         assert same == (not clear_rms)
         if clear_rms:
             assert torch.all(a2.dis_optimizer.ms == 1.0)                     # TF's RMSProp slot initial value
         assert a2.dis_optimizer.lr == (3e-4 if lr_update else 1e-4) and a2.global_step == 9
     assert not at.restore_optimizer(out, False, False)           # the segmenter's checkpoint folder has no RMSProp state for this graph
+    # the documented hand-off --phase pre-train -> --phase train-gan: the pre-train graph freezes adapt_* (its arena holds the critics
+    # only), the train-gan graph trains adapt_* as well (another arena layout).  tf.train.Saver restores slots BY NAME: the critics'
+    # warmed-up RMSProp slots and the global step must arrive, the adapt_* slots start at TF's initial value 1.0
+    pnet = adv.Full_DRN(channels=3, n_class=5, batch_size=2, device="cpu",
+                        cost_kwargs={"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.0},
+                        network_config={"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": False,
+                                        "cls_trainable": True, "m_cls_trainable": True})
+    assert pnet.store.arena.numel() != anet.store.arena.numel()
+    pt = adv.Trainer(pnet, None, None, None, None, num_cls=5, batch_size=2, opt_kwargs={"learning_rate": 3e-4})
+    pt._get_optimizer()
+    pt.dis_optimizer.ms.uniform_(0.5, 2.0)
+    pt.global_step = 123
+    pout = str(tmp_path / "pre")
+    os.makedirs(pout)
+    pt.save_checkpoint(pout)
+    g2 = adv.Trainer(anet, None, None, None, None, num_cls=5, batch_size=2, opt_kwargs={"learning_rate": 3e-4})
+    g2._get_optimizer()
+    assert g2.restore_optimizer(pout, clear_rms=False, lr_update=True) and g2.global_step == 123
+    pv = {v.name: v for v in pnet.store.trainable()}
+    n_cls = 0
+    for v in anet.store.trainable():
+        got = g2.dis_optimizer.ms[v.offset:v.offset + v.numel]
+        if "cls" in v.name:
+            want = pt.dis_optimizer.ms[pv[v.name].offset:pv[v.name].offset + v.numel]
+            assert torch.equal(got, want), v.name
+            n_cls += 1
+        elif "adapt" in v.name:
+            assert torch.all(g2.gen_optimizer.ms[v.offset:v.offset + v.numel] == 1.0), v.name
+    assert n_cls > 40
+    # a restore that asks for slots (clear_rms=False) from a folder that holds none for this graph says so instead of dropping them
+    np.savez(os.path.join(pout, "optimizer.npz"), kind="rmsprop", dis_lr=np.float64(1e-4), gen_lr=np.float64(1e-4), global_step=np.int64(1))
+    with pytest.raises(RuntimeError):
+        g2.restore_optimizer(pout, clear_rms=False, lr_update=False)
+    assert g2.restore_optimizer(pout, clear_rms=True, lr_update=False)
     # no_gan restore: only the main ('group' / 'output') variables, neither adapt_* nor the critics
     before = anet.store.state_dict()
     tweaked = {k: v + 1.0 for k, v in before.items()}
