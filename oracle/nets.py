@@ -79,47 +79,68 @@ def l2_multiplicity(name):
     return 1 if "/Variable" in name else 0
 
 
-def segmenter_forward(V, x, keep_prob=1.0, main_bn=True, adapt_bn=True, seed=0, n_class=5, taps=None, operand_round=None):
+def segmenter_forward(V, x, keep_prob=1.0, main_bn=True, adapt_bn=True, seed=0, n_class=5, taps=None, operand_round=None, units=None):
     """logits of Full_DRN.create_network.  V: dict of torch tensors (moving stats are updated in place when training).
     operand_round (e.g. tf_ops.round_bf16): applied to both operands of every convolution, accumulation stays float32 — the
-    arithmetic of a bf16-MFMA mixed-precision path (BASELINE config 5), used to budget its tolerance on the CPU."""
+    arithmetic of a bf16-MFMA mixed-precision path (BASELINE config 5), used to budget its tolerance on the CPU.
+    units: a list that receives one record per conv(-BN-shortcut-activation) unit — its input, filter, BN names, shortcut, output
+    and dropout stream id, each activation a distinct autograd node with retain_grad() — so that after backward() a test can feed
+    every unit's OWN upstream gradient and saved input to the kernels under test (teacher-forced per-layer backward check)."""
     nm = _Namer()
     sid = [0]
 
-    def conv(x, w, stride=1, dil=1, padding="SAME", keep=keep_prob):
-        if operand_round is not None:
-            x, w = operand_round(x), operand_round(w)
-        y = T.conv2d(x, w, stride, dil, padding)
+    def tap(t):
+        """a distinct node for `t` whose .grad is the gradient flowing into THIS use of it (a tensor feeding a conv and a shortcut
+        otherwise accumulates both)"""
+        if units is None or not t.requires_grad:
+            return t
+        u = t + 0
+        u.retain_grad()
+        return u
+
+    def unit(x, wname, group_train, dil=1, padding="SAME", keep=keep_prob, bn=True, shortcut=None, act=True):
+        w = V[wname]
+        xin, sc = tap(x), (tap(shortcut) if shortcut is not None else None)
+        xo, wo = (operand_round(xin), operand_round(w)) if operand_round is not None else (xin, w)
         s = sid[0]
         sid[0] += 1
-        return T.dropout(y, keep, seed, s)
-
-    def bn(x, is_train):
-        b = nm.bn()
-        return T.batch_norm(x, V[b + "/gamma"], V[b + "/beta"], V[b + "/moving_mean"], V[b + "/moving_variance"], is_train)
+        y = T.dropout(T.conv2d(xo, wo, 1, dil, padding), keep, seed, s)
+        b = None
+        if bn:
+            b = nm.bn()
+            y = T.batch_norm(y, V[b + "/gamma"], V[b + "/beta"], V[b + "/moving_mean"], V[b + "/moving_variance"], group_train)
+        if sc is not None:
+            cin, cout = sc.shape[-1], y.shape[-1]
+            y = (T.pad_channels(sc, cin // 2) if cout != cin else sc) + y
+        if act:
+            y = T.leaky_relu(y)
+        if units is not None:
+            if y.requires_grad:
+                y.retain_grad()
+            units.append({"w": wname, "bn": b, "x": xin, "shortcut": sc, "out": y, "dil": dil, "padding": padding, "keep": keep,
+                          "sid": s, "act": act, "is_train": group_train})
+        return y
 
     h = x
     for group, blocks, pool in SEGMENTER_SPEC:
         is_train = adapt_bn if group in ADAPT_GROUPS else main_bn
         for kind, cin, cout in blocks:
             if kind == "conv":
-                h = conv(h, V[nm.weight(group)])
+                h = unit(h, nm.weight(group), is_train, bn=False, act=False)
             elif kind in ("rb", "drb"):
                 dil = 2 if kind == "drb" else 1
-                w1, w2 = V[nm.weight(group)], V[nm.weight(group)]
-                inner = T.leaky_relu(bn(conv(h, w1, 1, dil), is_train))
-                inner = bn(conv(inner, w2, 1, dil), is_train)
-                sc = T.pad_channels(h, cin // 2) if cout != cin else h
-                h = T.leaky_relu(sc + inner)
+                w1, w2 = nm.weight(group), nm.weight(group)
+                inner = unit(h, w1, is_train, dil)
+                h = unit(inner, w2, is_train, dil, shortcut=h)
             else:
-                h = T.leaky_relu(bn(conv(h, V[nm.weight(group)]), is_train))
+                h = unit(h, nm.weight(group), is_train)
             if taps is not None:
                 taps.append((group, kind, h))
         if pool:
             h = T.max_pool2(h)
-    h = conv(h, V[nm.weight("group_10")], padding="SYMMETRIC")
+    h = unit(h, nm.weight("group_10"), True, padding="SYMMETRIC", bn=False, act=False)
     h = T.PS(h, 8, n_class * 8)
-    logits = conv(h, V[nm.weight("output")], padding="SYMMETRIC", keep=1.0)
+    logits = unit(h, nm.weight("output"), True, padding="SYMMETRIC", keep=1.0, bn=False, act=False)
     return logits
 
 

@@ -12,6 +12,7 @@ PKG = "medical-cross-modality-domain-adaptation_amd"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: BASELINE-batch (B=16) oracle comparisons, ~1 min of host time each (still part of -m gpu)")
 
 
 def pkg(sub=None):

@@ -159,3 +159,66 @@ def test_discriminator_and_generator_steps(dev):
     for k in before:
         if not k.startswith("adapt_"):
             assert np.array_equal(before[k], after[k]), k
+
+
+@pytest.mark.slow
+def test_joint_step_B16_vs_float32_oracle(dev):
+    """BASELINE configs[2]/[3] at their own batch (16 MR + 16 CT): discriminator step, clip, generator step of the HIP path against
+    oracle.nets_adv.joint_train_step in float32 — losses, both domains' logits, which variables move and by how much"""
+    adv = pkg("adversarial")
+    B = 16
+    rng = np.random.default_rng(50)
+    mr = rng.standard_normal((B, 256, 256, 3)).astype(np.float32)
+    ct = (rng.standard_normal((B, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32)
+    net = adv.Full_DRN(channels=3, n_class=5, batch_size=B, cost_kwargs=dict(COST), network_config=dict(NETCFG), device=dev, seed=2)
+    sd = he_state(net, 9)
+    net.store.load_state_dict(sd)
+    tr = adv.Trainer(net, None, None, None, None, num_cls=5, batch_size=B, opt_kwargs={"learning_rate": 3e-4},
+                     train_config={"dis_sub_iter": 1, "gen_sub_iter": 1})
+    tr._get_optimizer()
+    mrd, ctd = torch.from_numpy(mr).to(dev), torch.from_numpy(ct).to(dev)
+    dl = tr.dis_step(mrd, ctd, 0.75, 21)
+    ct_logits_dis, mr_logits_dis = net.ct_logits.cpu(), net.mr_logits.cpu()
+    g_dis = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if "cls" in v.name}
+    mid = net.store.state_dict()
+    gl = tr.gen_step(ctd, 0.75, 22)
+    g_gen = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if v.name.startswith("adapt_")}
+    after = net.store.state_dict()
+
+    V = {k: torch.from_numpy(np.array(a)) for k, a in sd.items()}
+    ms_d, ms_g = {}, {}
+    d32, gd32, o = nets_adv.dis_train_step(V, ms_d, torch.from_numpy(mr), torch.from_numpy(ct), 0.75, 21)
+    Vmid = {k: v.detach().clone() for k, v in V.items()}
+    g32, gg32, o2 = nets_adv.gen_train_step(V, ms_g, torch.from_numpy(ct), 0.75, 22)
+    print("B=16 dis loss hip %.9f cpu %.9f | gen loss hip %.9f cpu %.9f" % (float(dl), float(d32), float(gl), float(g32)))
+    assert _rel(ct_logits_dis, o["ct_logits"]) < 1e-4 and _rel(mr_logits_dis, o["mr_logits"]) < 1e-4
+    assert abs(float(dl) - float(d32)) < 2e-4 * abs(float(d32)) + 1e-8
+    assert abs(float(gl) - float(g32)) < 2e-4 * abs(float(g32)) + 1e-8
+    for tag, gh, gc, coef in (("dis", g_dis, gd32, "dis"), ("gen", g_gen, gg32, "gen")):
+        # the oracle's grads carry the L2 term (it is inside its update), the product applies it in the optimiser kernel: add it
+        cs, er = {}, []
+        for k in gh:
+            ref = gc[k]
+            src = sd[k] if tag == "dis" else mid[k]
+            got = gh[k] + nets_adv.l2_coefficient(k, coef) * torch.from_numpy(src)
+            cs[k] = _cos(got, ref)
+            er.append(_rel(got, ref))
+        print("B=16 %s gradients hip vs cpu-fp32 over %d variables: median %.3e max %.3e, min cosine %.8f (%s)" % (
+            tag, len(er), np.median(er), max(er), min(cs.values()), min(cs, key=cs.get)))
+        assert min(cs.values()) > 0.9999 and np.median(er) < 1e-2
+    # which variables moved: critics in the dis step (clipped to +-0.03), adapt_* in the gen step, nothing else ever
+    for k in sd:
+        moved_dis = not np.array_equal(mid[k], sd[k])
+        moved_gen = not np.array_equal(after[k], mid[k])
+        is_stat = k.endswith(("moving_mean", "moving_variance"))
+        if "cls" in k:
+            assert (not moved_gen) or is_stat, k        # the critics' BN moving statistics move in every forward (batch statistics)
+        elif k.startswith("adapt_"):
+            assert not moved_dis, k
+        else:
+            assert not moved_dis and not moved_gen, k
+    assert max(float(np.abs(mid[k]).max()) for k in mid if "cls" in k and "Variable" in k) <= 0.03 + 1e-9
+    # the updates themselves against the oracle's (RMSProp is sign-like at the first step: lr * g / sqrt(.9 + .1 g^2))
+    worst = max(float(np.abs(mid[k] - Vmid[k].numpy()).max()) for k in sd if "cls" in k and "Variable" in k)
+    print("B=16 dis update: worst critic weight difference vs oracle %.3e (lr 3e-4)" % worst)
+    assert worst < 3e-5

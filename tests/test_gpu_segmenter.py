@@ -151,3 +151,44 @@ def test_segmenter_eval_outputs(dev):
     for k in sd:
         if k.endswith("moving_mean") or k.endswith("moving_variance"):
             assert np.array_equal(after[k], sd[k]), k
+
+
+@pytest.mark.slow
+def test_segmenter_train_step_B16_vs_float32_oracle(dev):
+    """BASELINE configs[1] at its own batch: at B=16 the planners pick 128x128 tiles, 7-way filter-gradient splits and reduction-split
+    data gradients that no B=2 test reaches; the whole step is held to the float32 CPU oracle here (float64 at this size costs
+    minutes; the per-kernel 1e-4 pins at B=16 live in test_gpu_teacher_forced.py)"""
+    ss = pkg("source_segmenter")
+    B = 16
+    rng = np.random.default_rng(40)
+    x = rng.standard_normal((B, 256, 256, 3)).astype(np.float32)
+    y = T.label_decomp(5, _blob_labels(rng, B))
+    net = ss.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, cost_kwargs=dict(COST), seed=5)
+    sd = he_scaled(net.store.state_dict())
+    net.store.load_state_dict(sd)
+    tr = ss.Trainer(net, None, None, num_cls=5, batch_size=B, optimizer="adam", opt_kwargs={"learning_rate": 1e-3})
+    tr.opt = tr._get_optimizer(10)
+    loss = tr.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), 0.75, step=0)
+    logits = net.logits.detach().cpu()
+    grads = {v.name: v.tensor.grad.detach().cpu().clone() + COST["regularizer"] * nets.l2_multiplicity(v.name) * torch.from_numpy(sd[v.name])
+             for v in net.store.trainable()}
+    after = net.store.state_dict()
+    V32 = nets.make_variables(sd)
+    cost32, g32, logits32 = nets.segmenter_train_step(V32, {}, torch.from_numpy(x), torch.from_numpy(y), 0.75, seed=1, lr=1e-3, t=1)
+    e = _rel(logits, logits32)
+    print("B=16 logits hip vs cpu-fp32 %.3e ; loss hip %.7f cpu %.7f" % (e, float(loss), float(cost32)))
+    assert e < 1e-4 and abs(float(loss) - float(cost32)) < 1e-5 * max(1.0, abs(float(cost32)))
+    # label map: identical wherever the oracle's own top-2 margin is above the float32 noise of two evaluations
+    top2 = torch.topk(logits32, 2, dim=-1).values
+    far = (top2[..., 0] - top2[..., 1]) > 3e-5 * float(logits32.abs().max())
+    mism = logits.argmax(-1) != logits32.argmax(-1)
+    print("B=16 argmax mismatches %d of %d, away from near-ties %d" % (int(mism.sum()), mism.numel(), int((mism & far).sum())))
+    assert int((mism & far).sum()) == 0
+    cs = {k: _cos(grads[k], g32[k]) for k in g32}
+    er = np.array([_rel(grads[k], g32[k]) for k in g32])
+    print("B=16 gradients hip vs cpu-fp32 over %d variables: median %.3e max %.3e, min cosine %.8f (%s)" % (
+        len(er), np.median(er), er.max(), min(cs.values()), min(cs, key=cs.get)))
+    assert min(cs.values()) > 0.9999 and np.median(er) < 1e-2
+    for k, v in V32.items():
+        if k.endswith("moving_mean") or k.endswith("moving_variance"):
+            assert _rel(after[k], v.detach()) < 1e-4, k
