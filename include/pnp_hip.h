@@ -76,6 +76,10 @@ typedef struct pnp_conv_geom {
     int32_t stride, dil;    /* same in both spatial dims (reference only uses square) */
     int32_t pad_t, pad_l;   /* pad before (top / left) */
     int32_t pad_mode;       /* PNP_PAD_* */
+    int32_t dtype;          /* PNP_DTYPE_F32: the reference's arithmetic.  PNP_DTYPE_BF16 (BASELINE configs[4]): both operands of the
+                             * contraction are rounded to bfloat16 (nearest-even) as they are staged, products accumulate in fp32;
+                             * x / w / y / gradients stay float32 in memory (w = the fp32 master weights).  Layers off the MFMA fast
+                             * paths (C not a multiple of 32, K <= 16, strided filter gradients) compute in fp32 either way. */
 } pnp_conv_geom;
 
 /* replaces tf.nn.conv2d (layers.py:18,24,67,73) and tf.nn.atrous_conv2d (layers.py:86,92) + tf.nn.dropout */

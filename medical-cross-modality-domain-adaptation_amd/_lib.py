@@ -28,7 +28,7 @@ ABI_VERSION = 2
 class ConvGeom(ctypes.Structure):
     """mirror of `pnp_conv_geom` (include/pnp_hip.h)"""
     _fields_ = [(n, c_int32) for n in
-                ("N", "H", "W", "C", "K", "R", "S", "OH", "OW", "stride", "dil", "pad_t", "pad_l", "pad_mode")]
+                ("N", "H", "W", "C", "K", "R", "S", "OH", "OW", "stride", "dil", "pad_t", "pad_l", "pad_mode", "dtype")]
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)

@@ -1,0 +1,153 @@
+// conv_common.h — what the convolution translation units share: the kernel argument block, tile / XCD mapping, accumulators and the
+// buffer-descriptor loads (conv_igemm.hip: fp32 MFMA + vector-ALU kernels and ALL host planning; conv_bf16.hip: bf16-operand MFMA kernels).
+#pragma once
+#include "pnp_common.h"
+
+namespace pnpconv {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+#ifndef PNP_CONV_ABLATE
+#define PNP_CONV_ABLATE 0
+#endif
+constexpr int kAblate = PNP_CONV_ABLATE;
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    float* y;
+    int N, H, W, C, K, R, S, OH, OW, stride, dil, pad_t, pad_l, pad_mode;
+    int ups;    // zero-upsampling factor of the input (dgrad of a strided conv); 1 otherwise
+    int M;      // N*OH*OW
+    int Kred;   // R*S*C
+    int OHW;    // OH*OW
+    int nblk_m, nblk_n;
+    int gn;                       // filter-tile group width of the workgroup -> tile order (0: plain row-major)
+    int nsplit, chunks_per_split;   // wgrad only
+    long long split_stride;          // wgrad only: elements between split partials
+    uint32_t drop_thresh, drop_key;
+    float drop_scale;
+    int do_drop;
+    int xcd_swizzle;
+    unsigned x_bytes, w_bytes;   // sizes of the tensors behind a.x / a.w (buffer descriptors)
+    int stagger;                 // s_sleep units (64 clk) by which every second dispatch wave of workgroups starts late
+    // output scatter of one stride-phase of a strided data gradient (o_s = 0: plain [M][K] rows): GEMM row (n, i, j) is the
+    // image pixel (n, o_h0 + i*o_s, o_w0 + j*o_s) of an o_H x o_W image
+    int o_s, o_H, o_W, o_h0, o_w0;
+    // fused inference-mode batch norm (+ shortcut + leaky-ReLU) behind the convolution (monitoring / frozen-BN forwards):
+    //   y = act( drop(acc) * ep_scale[k] + ep_shift[k] + pad_channels(ep_res) ),  act(v) = v > 0 ? v : ep_alpha * v  (ep_alpha < 0: none)
+    const float* ep_scale;
+    const float* ep_shift;
+    const float* ep_res;        // [M][ep_cs] or null
+    int ep_cs;                   // shortcut channels, zero-padded (K - ep_cs)/2 on each side
+    float ep_alpha;
+    int dtype;                   // PNP_DTYPE_F32 / PNP_DTYPE_BF16: arithmetic type of the MFMA operands (tensors in HBM are fp32 either way)
+};
+
+__device__ __forceinline__ float bn_epilogue(const ConvArgs& a, float v, int m, int n) {
+    v = fmaf(v, a.ep_scale[n], a.ep_shift[n]);
+    if (a.ep_res) {
+        const int cs = n - ((a.K - a.ep_cs) >> 1);
+        if ((unsigned)cs < (unsigned)a.ep_cs) v += a.ep_res[(size_t)m * a.ep_cs + cs];
+    }
+    return (a.ep_alpha >= 0.f && v < 0.f) ? v * a.ep_alpha : v;
+}
+
+__device__ __forceinline__ size_t out_row(const ConvArgs& a, int m, bool scatter) {
+    if (!scatter) return (size_t)m * a.K;
+    const int n = m / a.OHW;
+    const int rem = m - n * a.OHW;
+    const int oh = rem / a.OW;
+    const int ow = rem - oh * a.OW;
+    return ((size_t)(n * a.o_H + a.o_h0 + oh * a.o_s) * a.o_W + a.o_w0 + ow * a.o_s) * a.K;
+}
+
+// virtual coordinate -> real coordinate; returns false when the tap reads zero.  Branch-free on purpose (selects only):
+// a scalar branch here would split the main-loop body into basic blocks and pin the address arithmetic in front of the MFMAs.
+// UPS: the input is zero-upsampled by `ups` (dgrad of a strided convolution); sym: tf.pad SYMMETRIC mirror (edge included).
+template <bool UPS>
+__device__ __forceinline__ bool map_coord(int v, int H, int ups, int sym, int& i) {
+    const int vs = v < 0 ? -1 - v : (v >= H ? 2 * H - 1 - v : v);
+    const int vv = sym ? vs : v;
+    if constexpr (UPS) {
+        const int q = vv / ups;
+        i = q;
+        return (vv >= 0) & (q * ups == vv) & (q < H);
+    } else {
+        i = vv;
+        return (unsigned)vv < (unsigned)H;
+    }
+}
+
+// bijective XCD-aware remap: consecutive tiles (which share the A rows / filter panel) land on one XCD's L2
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int NX = 8;
+    int q = nblk / NX, r = nblk % NX;
+    int xcd = bid % NX, idx = bid / NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// Logical workgroup id -> (pixel tile, filter tile).  Plain order is filter-tile fastest; with gn > 0 the filter tiles are walked in
+// groups of gn (a "super-column"): all pixel tiles of one group before the next, so the workgroups in flight on an XCD touch at most gn
+// filter panels however wide the layer is (512->2560: 20 panels in flight without it).
+__device__ __forceinline__ void tile_coords(int bid, int nblk_m, int nblk_n, int gn, int& mt, int& nt) {
+    if (gn <= 0 || gn >= nblk_n) { mt = bid / nblk_n; nt = bid - mt * nblk_n; return; }
+    const int span = nblk_m * gn;
+    const int sc = bid / span, rem = bid - sc * span;
+    const int left = nblk_n - sc * gn;
+    const int width = left < gn ? left : gn;
+    mt = rem / width;
+    nt = sc * gn + rem - mt * width;
+}
+
+template <int TM, int TN>
+struct Acc {
+    f32x16 v[TM][TN];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[i][j][e] = 0.f;
+    }
+};
+
+// ---- global loads go through buffer descriptors ---------------------------------------------------
+// An out-of-range byte offset returns 0 in hardware, so TF zero padding, ragged tile edges, the k tail and the
+// (unused) prefetch past the last stage need neither branches nor selects: the main-loop body is ONE basic block,
+// which is what lets the MFMA / ds_read / buffer_load interleave below be scheduled at all.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const float __attribute__((address_space(4))) pnp_cfloat;     // constant address space: uniform reads become s_load
+constexpr unsigned OOB = 0xFFFFFF00u;   // beyond any legal offset (host checks tensors are < 2^30 elements)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+
+constexpr unsigned OOB2 = 0x80000000u;     // host guarantees both tensors are < 2 GiB on this path
+
+__device__ __forceinline__ f32x4 bload4s(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// bf16-operand kernels (conv_bf16.hip), dispatched from conv_igemm.hip's planners when ConvArgs::dtype == PNP_DTYPE_BF16 and the
+// layer is on the tap-unrolled / linear-wgrad fast paths; every other layer keeps the fp32 kernels.  grid / nsplit / chunks_per_split are
+// planned by the caller exactly as for the fp32 kernels.  tile: 0 = 128x128, 1 = 128x64, 2 = 128x32.  Return false: no instance.
+bool launch_taps_bf16(const ConvArgs& a, int tile, int kind, dim3 grid, hipStream_t st);
+bool launch_wgrad_bf16(const ConvArgs& a, int tile, dim3 grid, hipStream_t st);
+inline double conv_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.K * a.Kred; }
+inline double conv_bytes(const ConvArgs& a) {
+    return 4.0 * ((double)a.N * a.H * a.W * a.C + (double)a.M * a.K + (double)a.Kred * a.K);
+}
+inline int prof_class(int kind) { return kind == 0 ? PNP_PROF_CONV_FWD : PNP_PROF_CONV_DGRAD; }
+
+}  // namespace pnpconv

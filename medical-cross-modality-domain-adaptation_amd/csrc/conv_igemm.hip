@@ -32,135 +32,11 @@
 //                             a bijection over each b128 lane group => conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured).
 //   B tile       [32][BN+4]   row = k, n contiguous; fragment = ds_read_b32, lanes 0-31 consecutive => conflict-free.
 //   wgrad A tile [32][BM+4]   row = pixel (reduction index), m' contiguous; ds_read_b32 like B.
-#include "pnp_common.h"
+#include "conv_common.h"
+
+using namespace pnpconv;
 
 namespace {
-
-constexpr int BK = 32;
-constexpr int NTHREADS = 256;
-#ifndef PNP_CONV_ABLATE
-#define PNP_CONV_ABLATE 0
-#endif
-constexpr int kAblate = PNP_CONV_ABLATE;
-
-struct ConvArgs {
-    const float* x;
-    const float* w;
-    float* y;
-    int N, H, W, C, K, R, S, OH, OW, stride, dil, pad_t, pad_l, pad_mode;
-    int ups;    // zero-upsampling factor of the input (dgrad of a strided conv); 1 otherwise
-    int M;      // N*OH*OW
-    int Kred;   // R*S*C
-    int OHW;    // OH*OW
-    int nblk_m, nblk_n;
-    int gn;                       // filter-tile group width of the workgroup -> tile order (0: plain row-major)
-    int nsplit, chunks_per_split;   // wgrad only
-    long long split_stride;          // wgrad only: elements between split partials
-    uint32_t drop_thresh, drop_key;
-    float drop_scale;
-    int do_drop;
-    int xcd_swizzle;
-    unsigned x_bytes, w_bytes;   // sizes of the tensors behind a.x / a.w (buffer descriptors)
-    int stagger;                 // s_sleep units (64 clk) by which every second dispatch wave of workgroups starts late
-    // output scatter of one stride-phase of a strided data gradient (o_s = 0: plain [M][K] rows): GEMM row (n, i, j) is the
-    // image pixel (n, o_h0 + i*o_s, o_w0 + j*o_s) of an o_H x o_W image
-    int o_s, o_H, o_W, o_h0, o_w0;
-    // fused inference-mode batch norm (+ shortcut + leaky-ReLU) behind the convolution (monitoring / frozen-BN forwards):
-    //   y = act( drop(acc) * ep_scale[k] + ep_shift[k] + pad_channels(ep_res) ),  act(v) = v > 0 ? v : ep_alpha * v  (ep_alpha < 0: none)
-    const float* ep_scale;
-    const float* ep_shift;
-    const float* ep_res;        // [M][ep_cs] or null
-    int ep_cs;                   // shortcut channels, zero-padded (K - ep_cs)/2 on each side
-    float ep_alpha;
-};
-
-__device__ __forceinline__ float bn_epilogue(const ConvArgs& a, float v, int m, int n) {
-    v = fmaf(v, a.ep_scale[n], a.ep_shift[n]);
-    if (a.ep_res) {
-        const int cs = n - ((a.K - a.ep_cs) >> 1);
-        if ((unsigned)cs < (unsigned)a.ep_cs) v += a.ep_res[(size_t)m * a.ep_cs + cs];
-    }
-    return (a.ep_alpha >= 0.f && v < 0.f) ? v * a.ep_alpha : v;
-}
-
-__device__ __forceinline__ size_t out_row(const ConvArgs& a, int m, bool scatter) {
-    if (!scatter) return (size_t)m * a.K;
-    const int n = m / a.OHW;
-    const int rem = m - n * a.OHW;
-    const int oh = rem / a.OW;
-    const int ow = rem - oh * a.OW;
-    return ((size_t)(n * a.o_H + a.o_h0 + oh * a.o_s) * a.o_W + a.o_w0 + ow * a.o_s) * a.K;
-}
-
-// virtual coordinate -> real coordinate; returns false when the tap reads zero.  Branch-free on purpose (selects only):
-// a scalar branch here would split the main-loop body into basic blocks and pin the address arithmetic in front of the MFMAs.
-// UPS: the input is zero-upsampled by `ups` (dgrad of a strided convolution); sym: tf.pad SYMMETRIC mirror (edge included).
-template <bool UPS>
-__device__ __forceinline__ bool map_coord(int v, int H, int ups, int sym, int& i) {
-    const int vs = v < 0 ? -1 - v : (v >= H ? 2 * H - 1 - v : v);
-    const int vv = sym ? vs : v;
-    if constexpr (UPS) {
-        const int q = vv / ups;
-        i = q;
-        return (vv >= 0) & (q * ups == vv) & (q < H);
-    } else {
-        i = vv;
-        return (unsigned)vv < (unsigned)H;
-    }
-}
-
-// bijective XCD-aware remap: consecutive tiles (which share the A rows / filter panel) land on one XCD's L2
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int NX = 8;
-    int q = nblk / NX, r = nblk % NX;
-    int xcd = bid % NX, idx = bid / NX;
-    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
-
-// Logical workgroup id -> (pixel tile, filter tile).  Plain order is filter-tile fastest; with gn > 0 the filter tiles are walked in
-// groups of gn (a "super-column"): all pixel tiles of one group before the next, so the workgroups in flight on an XCD touch at most gn
-// filter panels however wide the layer is (512->2560: 20 panels in flight without it).
-__device__ __forceinline__ void tile_coords(int bid, int nblk_m, int nblk_n, int gn, int& mt, int& nt) {
-    if (gn <= 0 || gn >= nblk_n) { mt = bid / nblk_n; nt = bid - mt * nblk_n; return; }
-    const int span = nblk_m * gn;
-    const int sc = bid / span, rem = bid - sc * span;
-    const int left = nblk_n - sc * gn;
-    const int width = left < gn ? left : gn;
-    mt = rem / width;
-    nt = sc * gn + rem - mt * width;
-}
-
-template <int TM, int TN>
-struct Acc {
-    f32x16 v[TM][TN];
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[i][j][e] = 0.f;
-    }
-};
-
-// ---- global loads go through buffer descriptors ---------------------------------------------------
-// An out-of-range byte offset returns 0 in hardware, so TF zero padding, ragged tile edges, the k tail and the
-// (unused) prefetch past the last stage need neither branches nor selects: the main-loop body is ONE basic block,
-// which is what lets the MFMA / ds_read / buffer_load interleave below be scheduled at all.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef const float __attribute__((address_space(4))) pnp_cfloat;     // constant address space: uniform reads become s_load
-constexpr unsigned OOB = 0xFFFFFF00u;   // beyond any legal offset (host checks tensors are < 2^30 elements)
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
-__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-}
 
 // ---- B tile (weights for fwd, dy for wgrad): row-major [rows][ncols] global matrix ------------
 template <int BN, bool VEC>
@@ -462,6 +338,27 @@ struct Frag {
     }
 };
 #define PNP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Slices 1..3 of a stage: the fragment reads of the NEXT slice and the MFMAs of THIS slice are independent (two Frag sets).
+// PNP_CONV_ILV = 0: all reads are issued in front of the MFMAs (the matrix pipe drains while 6..16 ds_reads issue);
+// PNP_CONV_ILV = 1: NDS reads ride behind each MFMA (a 32x32x2 fp32 MFMA occupies the pipe for 64 cycles = 16 issue slots).
+#ifndef PNP_CONV_ILV
+#define PNP_CONV_ILV 0
+#endif
+#define PNP_SLICE(LOAD, MMA, NMFMA, NDS)                                   \
+    if constexpr (PNP_CONV_ILV != 0) {                                      \
+        LOAD;                                                               \
+        MMA;                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < (NMFMA); ++i_) {            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
+            __builtin_amdgcn_sched_group_barrier(0x100, (NDS), 0);          \
+        }                                                                   \
+        PNP_SCHED_FENCE();                                                  \
+    } else {                                                                \
+        LOAD;                                                               \
+        PNP_SCHED_FENCE();                                                  \
+        MMA;                                                                \
+        PNP_SCHED_FENCE();                                                  \
+    }
 
 // ================================ forward / dgrad kernel ========================================
 // KIND 0 = forward, 1 = data gradient of a stride-1 convolution, 2 = data gradient of a strided convolution (input = dy
@@ -617,11 +514,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
 //       soffset = channel-group * 128 bytes      (scalar)
 //   B:  voffset = constant per thread, soffset = (tap*C + channel-group*32) * K * 4   (scalar)
 // i.e. ~16 VALU per stage instead of ~130 (the general kernel re-derives tap, mirror/zero test and pixel offset per row per stage).
-constexpr unsigned OOB2 = 0x80000000u;     // host guarantees both tensors are < 2 GiB on this path
-
-__device__ __forceinline__ f32x4 bload4s(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
 
 template <int BM, int BN, int WM, int WN, int KIND, int R, int S>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
@@ -740,14 +632,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
             PNP_SCHED_FENCE();
-            f0.load(As, Bs, 2, wm0, wn0, lane);
-            PNP_SCHED_FENCE();
-            f1.mma(acc);
-            PNP_SCHED_FENCE();
-            f1.load(As, Bs, 3, wm0, wn0, lane);
-            PNP_SCHED_FENCE();
-            f0.mma(acc);
-            PNP_SCHED_FENCE();
+            PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
+            PNP_SLICE(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
             f1.mma(acc);
             PNP_SCHED_FENCE();
             lstore(An, Bn);
@@ -851,14 +737,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
             PNP_SCHED_FENCE();
-            f0.load(As, Bs, 2, wm0, wn0, lane);
-            PNP_SCHED_FENCE();
-            f1.mma(acc);
-            PNP_SCHED_FENCE();
-            f1.load(As, Bs, 3, wm0, wn0, lane);
-            PNP_SCHED_FENCE();
-            f0.mma(acc);
-            PNP_SCHED_FENCE();
+            PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, (4 * TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
+            PNP_SLICE(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), 4 * TM * TN, (4 * TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
             f1.mma(acc);
             PNP_SCHED_FENCE();
             la.store(An);      // after the last MFMAs: gives the global loads a whole stage of latency cover (see conv_fwd_kernel)
@@ -1362,6 +1242,7 @@ int check_geom(const pnp_conv_geom* g, const char* who) {
                 "%s: non-positive dimension", who);
     PNP_REQUIRE(g->pad_mode == PNP_PAD_ZERO || g->pad_mode == PNP_PAD_SYMMETRIC, "%s: bad pad_mode %d", who, g->pad_mode);
     PNP_REQUIRE(g->pad_t >= 0 && g->pad_l >= 0, "%s: negative padding", who);
+    PNP_REQUIRE(g->dtype == PNP_DTYPE_F32 || g->dtype == PNP_DTYPE_BF16, "%s: dtype %d (PNP_DTYPE_F32 or PNP_DTYPE_BF16)", who, g->dtype);
     if (g->pad_mode == PNP_PAD_SYMMETRIC)
         PNP_REQUIRE(g->pad_t <= g->H && g->pad_l <= g->W, "%s: symmetric pad larger than the image", who);
     // last tap of the last output must not run past the (padded) input by more than the implicit zero region in
@@ -1383,6 +1264,7 @@ ConvArgs make_args(const float* x, const float* w, float* y, const pnp_conv_geom
     a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->C; a.K = g->K; a.R = g->R; a.S = g->S;
     a.OH = g->OH; a.OW = g->OW; a.stride = g->stride; a.dil = g->dil; a.pad_t = g->pad_t; a.pad_l = g->pad_l;
     a.pad_mode = g->pad_mode;
+    a.dtype = g->dtype;
     a.ups = 1;
     a.M = g->N * g->OH * g->OW;
     a.Kred = g->R * g->S * g->C;
@@ -1444,12 +1326,6 @@ int choose_split(long long M, int K, int Kred, int tile) {
     return nsplit < 1 ? 1 : nsplit;
 }
 
-inline double conv_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.K * a.Kred; }
-inline double conv_bytes(const ConvArgs& a) {
-    return 4.0 * ((double)a.N * a.H * a.W * a.C + (double)a.M * a.K + (double)a.Kred * a.K);
-}
-inline int prof_class(int kind) { return kind == 0 ? PNP_PROF_CONV_FWD : PNP_PROF_CONV_DGRAD; }
-
 // filter shapes the tap-unrolled kernel is instantiated for: forward 3x3 / 5x5; data gradient 3x3 and the stride-phase sub-filters
 constexpr bool taps_shape(int kind, int R, int S) {
     if (R == 3 && S == 3) return true;
@@ -1502,7 +1378,9 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
     const int mode = (a.C % 32 == 0) ? 0 : ((a.C % 4 == 0) ? 1 : 2);
     if constexpr (VECB && KIND != 2) {
         if (taps) {
-            const bool launched = launch_taps<BM, BN, WM, WN, KIND>(a, grid, st);
+            // bf16 MFMA operands (configs[4]): the same tiles, splits and epilogue, operands rounded while they are staged (conv_bf16.hip)
+            const bool launched = (a.dtype == PNP_DTYPE_BF16) ? launch_taps_bf16(a, BN == 128 ? 0 : (BN == 64 ? 1 : 2), KIND, grid, st)
+                                                              : launch_taps<BM, BN, WM, WN, KIND>(a, grid, st);
             PNP_REQUIRE(launched, "conv_taps_kernel: no instance for %dx%d", a.R, a.S);
             PNP_CHECK_LAUNCH("conv_taps_kernel");
         }
@@ -1588,7 +1466,10 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     static const int env_nolin = getenv("PNP_CONV_NOLIN") ? 1 : 0;
     const bool lin = !env_nolin && a.stride == 1 && a.pad_mode == PNP_PAD_ZERO && (a.C % 4) == 0 && a.OW >= BK &&
                      a.x_bytes < 0x80000000u && a.w_bytes < 0x80000000u;
-    {
+    if (lin && VECB && a.dtype == PNP_DTYPE_BF16) {
+        const bool launched = launch_wgrad_bf16(a, BN == 128 ? 0 : (BN == 64 ? 1 : 2), grid, st);
+        PNP_REQUIRE(launched, "conv_wgrad_bf16_kernel: no instance for a %dx%d tile", BM, BN);
+    } else {
         const int kmode = lin ? 3 : ((a.C % 4 == 0) ? 1 : 2);
         PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "conv_wgrad_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, WM, WN,
                         kmode, VECB ? "true" : "false");
@@ -1751,6 +1632,7 @@ pnp_conv_geom phase_geom(const pnp_conv_geom* g, const DgradPhase& p) {
     d.stride = 1; d.dil = 1;
     d.pad_t = p.pad_t; d.pad_l = p.pad_l;
     d.pad_mode = PNP_PAD_ZERO;
+    d.dtype = g->dtype;
     return d;
 }
 
@@ -1915,6 +1797,7 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
     d.pad_t = g->dil * (g->R - 1) - (sym ? 0 : g->pad_t);
     d.pad_l = g->dil * (g->S - 1) - (sym ? 0 : g->pad_l);
     d.pad_mode = PNP_PAD_ZERO;
+    d.dtype = g->dtype;
     PNP_REQUIRE(d.pad_t >= 0 && d.pad_l >= 0, "pnp_conv2d_dgrad: forward padding exceeds the filter extent");
     float* out = sym ? (float*)((char*)workspace + woff) : dx;
     ConvArgs a = make_args(dy, wt, out, &d);

@@ -37,7 +37,10 @@ PnpProfScope::PnpProfScope(int cls, hipStream_t st, double flops, double bytes, 
     vsnprintf(name, sizeof(name), fmt, ap);
     va_end(ap);
     ProfRec r{name, flops, bytes, nullptr, nullptr};
-    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    // timing only: no system-scope fence when the event completes (hipEventDisableSystemFence exists for exactly this)
+    if (hipEventCreateWithFlags(&r.e0, hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&r.e1, hipEventDisableSystemFence) != hipSuccess)
+        return;
     (void)hipEventRecord(r.e0, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof_recs.size() >= kProfCap) {

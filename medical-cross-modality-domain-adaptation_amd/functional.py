@@ -264,3 +264,5 @@ def set_conv_dtype(name):
     if name not in ("f32", "bf16"):
         raise ValueError("conv dtype must be 'f32' or 'bf16', got %r" % (name,))
     CONV_DTYPE = name
+    from . import _lib
+    K.CONV_DTYPE = _lib.DTYPE_BF16 if name == "bf16" else _lib.DTYPE_F32

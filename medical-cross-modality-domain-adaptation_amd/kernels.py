@@ -46,7 +46,10 @@ def same_pad(in_size, k, stride, dil=1):
     return out, total // 2, total - total // 2
 
 
-def conv_geom(x_shape, w_shape, stride=1, dil=1, padding="SAME"):
+CONV_DTYPE = _lib.DTYPE_F32      # arithmetic type new geometries ask for (functional.set_conv_dtype)
+
+
+def conv_geom(x_shape, w_shape, stride=1, dil=1, padding="SAME", dtype=None):
     """Geometry of layers.conv2d / dilate_conv2d (layers.py:64-74, 84-93)."""
     N, H, W, C = x_shape
     R, S, Cw, K = w_shape
@@ -55,6 +58,7 @@ def conv_geom(x_shape, w_shape, stride=1, dil=1, padding="SAME"):
     g = ConvGeom()
     g.N, g.H, g.W, g.C, g.K, g.R, g.S = N, H, W, C, K, R, S
     g.stride, g.dil = stride, dil
+    g.dtype = CONV_DTYPE if dtype is None else dtype
     if padding == "SAME":
         g.OH, g.pad_t, _ = same_pad(H, R, stride, dil)
         g.OW, g.pad_l, _ = same_pad(W, S, stride, dil)

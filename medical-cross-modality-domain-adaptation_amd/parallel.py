@@ -98,7 +98,7 @@ def init_distributed(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         else:
             backend = forced
-        if torch.cuda.is_available() and not os.environ.get("PNP_SAME_DEVICE"):
+        if backend == "nccl" or want_native:      # one GPU per rank (gloo test modes put several ranks on one device)
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -79,10 +79,12 @@ def l2_multiplicity(name):
     return 1 if "/Variable" in name else 0
 
 
-def segmenter_forward(V, x, keep_prob=1.0, main_bn=True, adapt_bn=True, seed=0, n_class=5, taps=None, operand_round=None, units=None):
+def segmenter_forward(V, x, keep_prob=1.0, main_bn=True, adapt_bn=True, seed=0, n_class=5, taps=None, operand_round=None, units=None,
+                      round_if=None):
     """logits of Full_DRN.create_network.  V: dict of torch tensors (moving stats are updated in place when training).
     operand_round (e.g. tf_ops.round_bf16): applied to both operands of every convolution, accumulation stays float32 — the
     arithmetic of a bf16-MFMA mixed-precision path (BASELINE config 5), used to budget its tolerance on the CPU.
+    round_if(filter_shape) -> bool restricts the rounding to the layers a given implementation runs on its bf16 kernels.
     units: a list that receives one record per conv(-BN-shortcut-activation) unit — its input, filter, BN names, shortcut, output
     and dropout stream id, each activation a distinct autograd node with retain_grad() — so that after backward() a test can feed
     every unit's OWN upstream gradient and saved input to the kernels under test (teacher-forced per-layer backward check)."""
@@ -101,10 +103,12 @@ def segmenter_forward(V, x, keep_prob=1.0, main_bn=True, adapt_bn=True, seed=0, 
     def unit(x, wname, group_train, dil=1, padding="SAME", keep=keep_prob, bn=True, shortcut=None, act=True):
         w = V[wname]
         xin, sc = tap(x), (tap(shortcut) if shortcut is not None else None)
-        xo, wo = (operand_round(xin), operand_round(w)) if operand_round is not None else (xin, w)
+        rnd = operand_round is not None and (round_if is None or round_if(tuple(w.shape)))
+        xo, wo = (operand_round(xin), operand_round(w)) if rnd else (xin, w)
         s = sid[0]
         sid[0] += 1
-        y = T.dropout(T.conv2d(xo, wo, 1, dil, padding), keep, seed, s)
+        yc = T.conv2d(xo, wo, 1, dil, padding)
+        yd = y = T.dropout(yc, keep, seed, s)
         b = None
         if bn:
             b = nm.bn()
@@ -115,10 +119,11 @@ def segmenter_forward(V, x, keep_prob=1.0, main_bn=True, adapt_bn=True, seed=0, 
         if act:
             y = T.leaky_relu(y)
         if units is not None:
-            if y.requires_grad:
-                y.retain_grad()
-            units.append({"w": wname, "bn": b, "x": xin, "shortcut": sc, "out": y, "dil": dil, "padding": padding, "keep": keep,
-                          "sid": s, "act": act, "is_train": group_train})
+            for t_ in (y, yc, yd):
+                if t_.requires_grad:
+                    t_.retain_grad()
+            units.append({"w": wname, "bn": b, "x": xin, "shortcut": sc, "out": y, "conv": yc, "dropped": yd, "dil": dil, "padding": padding,
+                          "keep": keep, "sid": s, "act": act, "is_train": group_train})
         return y
 
     h = x

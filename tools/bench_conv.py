@@ -8,8 +8,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 K = importlib.import_module("medical-cross-modality-domain-adaptation_amd.kernels")
+L = importlib.import_module("medical-cross-modality-domain-adaptation_amd._lib")
 
-PEAK = 157.3
+DTYPE = os.environ.get("DTYPE", "f32")          # bf16: bf16 MFMA operands (csrc/conv_bf16.hip) where the layer is on those kernels
+PEAK = 2500.0 if DTYPE == "bf16" else 157.3
 B = int(os.environ.get("B", 16))
 LAYERS = [  # name, H, C, K, R, dil, padding, count in segmenter fwd
     ("g1 3->16", 256, 3, 16, 3, 1, "SAME", 1),
@@ -64,7 +66,7 @@ def main():
         if padding == "SYMMETRIC":      # the model path: mirror-pad once (pnp_sympad_fwd), then a VALID convolution
             x = K.sympad_fwd(x, R // 2)
             padding = "VALID"
-        g = K.conv_geom(tuple(x.shape), tuple(w.shape), stride, dil, padding)
+        g = K.conv_geom(tuple(x.shape), tuple(w.shape), stride, dil, padding, dtype=L.DTYPE_BF16 if DTYPE == "bf16" else L.DTYPE_F32)
         dy = torch.randn((B, g.OH, g.OW, Kc), device=dev)
         flop = 2.0 * B * g.OH * g.OW * R * R * C * Kc
         tf = timeit(lambda: K.conv2d_fwd(x, w, g))
