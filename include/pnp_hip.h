@@ -199,6 +199,18 @@ int pnp_softmax_argmax(const float* logits, float* prob /*nullable*/, int64_t* l
 int pnp_dice_eval(const int64_t* label, const float* y, float* out, int64_t P, int32_t ncls,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* lib._label_decomp (lib.py:75-92): integer-valued float label map [P] -> one-hot float32 [P, ncls]; labels >= ncls give an all-zero
+ * row.  (The reference does this on the host per dequeued batch; here it runs behind the H2D copy of the feeder.) */
+int pnp_label_decomp(const float* label, float* onehot, int64_t P, int32_t ncls, void* stream);
+/* compact_y = tf.argmax(y, 3) of the one-hot labels (lowest index on ties; source_segmenter.py:83) and
+ * tf.confusion_matrix(compact_y, compact_pred, num_classes) (source_segmenter.py:85; rows = ground truth, columns = prediction) in one
+ * pass.  compact_y [P] (nullable), pred [P] / cm [ncls*ncls] int64 (both or neither). */
+int pnp_confusion_matrix(const float* y, const int64_t* pred, int64_t* compact_y, int64_t* cm, int64_t P, int32_t ncls, void* stream);
+/* Synchronised batch statistics (data-parallel replicas of equally many rows): moments[0..C) = mean, moments[C..2C) = var + mean^2 in
+ * double; the caller sums `moments` over the replicas (pnp_comm_allreduce, PNP_DTYPE_F64) and converts back with the replica count. */
+int pnp_bn_moments(const float* mean, const float* var, double* moments, int32_t C, void* stream);
+int pnp_bn_from_moments(const double* moments, int32_t world, float* mean, float* var, int32_t C, void* stream);
+
 /* Optimisers over ONE flat fp32 arena.  The arena is cut in chunks of PNP_OPT_CHUNK elements; chunk_l2[c] is the
  * L2 coefficient (reg_coeff * multiplicity, source_segmenter.py:132-135,237) applied to that chunk: g += l2 * w.
  * chunk_mask[c]==0 skips the chunk (frozen variables).  Either table may be NULL. */

@@ -100,6 +100,10 @@ PROTOTYPES = {
     "pnp_axpby": (c_int, [_F, _F, c_size_t, c_float, c_float, c_void_p]),
     "pnp_wgan_loss": (c_int, [_F, _F, _F, _F, c_int32, c_float, c_float, c_float, c_float, _F, c_void_p]),
     "pnp_fill": (c_int, [_F, c_size_t, c_float, c_void_p]),
+    "pnp_label_decomp": (c_int, [_F, _F, c_int64, c_int32, c_void_p]),
+    "pnp_confusion_matrix": (c_int, [_F, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "pnp_bn_moments": (c_int, [_F, _F, c_void_p, c_int32, c_void_p]),
+    "pnp_bn_from_moments": (c_int, [c_void_p, c_int32, _F, _F, c_int32, c_void_p]),
     "pnp_comm_load": (c_int, [c_char_p]),
     "pnp_comm_version": (c_int, [POINTER(c_int)]),
     "pnp_comm_unique_id": (c_int, [c_void_p]),

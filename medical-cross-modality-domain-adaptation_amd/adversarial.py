@@ -377,8 +377,7 @@ class Full_DRN(object):
             self.ct_dice_eval, self.ct_dice_eval_arr = _dice_eval(self.compact_pred, ct_y, self.n_class)
             self.mr_dice_eval, self.mr_dice_eval_arr = _dice_eval(self.compact_mr_valid, mr_y, self.n_class)
             if detail:
-                self.compact_y = torch.argmax(ct_y, 3)
-                self.confusion_matrix = lib.confusion_matrix(self.compact_y, self.compact_pred, self.n_class)
+                self.compact_y, self.confusion_matrix = lib.compact_and_confusion(ct_y, self.compact_pred)
         return float(self.ct_dice_eval), float(self.mr_dice_eval)
 
     def predict_ct(self, ct, ct_y):
@@ -387,8 +386,7 @@ class Full_DRN(object):
         with torch.no_grad():
             o = self._graph(None, ct, 1.0, mr_front_bn=False, joint_bn=False, ct_front_bn=False, critics=False)
             self.predicter, self.compact_pred = K.softmax_argmax(o["ct_logits"].contiguous())
-            self.compact_y = torch.argmax(ct_y, 3)
-            self.confusion_matrix = lib.confusion_matrix(self.compact_y, self.compact_pred, self.n_class)
+            self.compact_y, self.confusion_matrix = lib.compact_and_confusion(ct_y, self.compact_pred)
         return self.compact_pred, self.confusion_matrix
 
     # ---- checkpoints / phase hand-off (own .npz format keyed by the TF names) -------------------------------------

@@ -4,7 +4,7 @@
 // tile is staged into LDS and contracted by v_mfma_f32_32x32x16_bf16 (fp32 accumulation, 16x the fp32-MFMA rate).  Tensors in HBM stay
 // fp32 — activations, filters (= the fp32 master weights), gradients — so every other kernel of the step is untouched and the
 // arithmetic is exactly "both operands of every convolution rounded to bf16, products accumulated in fp32": what
-// oracle.tf_ops.round_bf16 restates and tests/test_bf16_budget.py budgets.
+// oracle/tf_ops.py (round_bf16) restates and tests/test_bf16_budget.py budgets.
 //
 //   conv_taps_bf16_kernel   forward (any stride) / stride-1 data gradient / stride-phase sub-filters: zero padding, C % 32 == 0, taps
 //                           unrolled (the layers conv_taps_kernel serves)

@@ -344,8 +344,26 @@ struct Frag {
 #ifndef PNP_CONV_ILV
 #define PNP_CONV_ILV 0
 #endif
+// last slice + the next stage's LDS stores.  PNP_CONV_ILV = 2: the stores ride behind the second half of the slice's MFMAs instead of
+// after them (the global loads they wait for were issued three slices earlier)
+#define PNP_LAST_SLICE(MMA, STORE, NMFMA)                                   \
+    if constexpr (PNP_CONV_ILV == 2) {                                      \
+        MMA;                                                                \
+        STORE;                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, (NMFMA) / 2, 0);        \
+        _Pragma("unroll") for (int i_ = 0; i_ < (NMFMA) / 2; ++i_) {        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);              \
+        }                                                                   \
+        PNP_SCHED_FENCE();                                                  \
+    } else {                                                                \
+        MMA;                                                                \
+        PNP_SCHED_FENCE();                                                  \
+        STORE;                                                              \
+        PNP_SCHED_FENCE();                                                  \
+    }
 #define PNP_SLICE(LOAD, MMA, NMFMA, NDS)                                   \
-    if constexpr (PNP_CONV_ILV != 0) {                                      \
+    if constexpr (PNP_CONV_ILV == 1) {                                      \
         LOAD;                                                               \
         MMA;                                                                \
         _Pragma("unroll") for (int i_ = 0; i_ < (NMFMA); ++i_) {            \
@@ -634,10 +652,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
             PNP_SCHED_FENCE();
             PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
             PNP_SLICE(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
-            f1.mma(acc);
-            PNP_SCHED_FENCE();
-            lstore(An, Bn);
-            PNP_SCHED_FENCE();
+            PNP_LAST_SLICE(f1.mma(acc), lstore(An, Bn), 4 * TM * TN)
             __syncthreads();
             f0.load(An, Bn, 0, wm0, wn0, lane);
         }
@@ -739,11 +754,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
             PNP_SCHED_FENCE();
             PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, (4 * TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
             PNP_SLICE(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), 4 * TM * TN, (4 * TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
-            f1.mma(acc);
-            PNP_SCHED_FENCE();
-            la.store(An);      // after the last MFMAs: gives the global loads a whole stage of latency cover (see conv_fwd_kernel)
-            lb.store(Bn);
-            PNP_SCHED_FENCE();
+            // stores after the last MFMAs: gives the global loads a whole stage of latency cover (see conv_fwd_kernel)
+            PNP_LAST_SLICE(f1.mma(acc), (la.store(An), lb.store(Bn)), 4 * TM * TN)
             __syncthreads();
             f0.load(An, Bn, 0, wm0, wn0, lane);
         }

@@ -342,9 +342,105 @@ int run_opt(OptArgs a, hipStream_t st, const char* who) {
     return PNP_OK;
 }
 
+
+// ---- label helpers of the step / monitoring path (lib.py:75-92, source_segmenter.py:85,479-481) ---------------------------------------
+// lib._label_decomp: integer-valued float label map -> one-hot float rows (labels >= ncls: all-zero row)
+__global__ void __launch_bounds__(NT) label_decomp_kernel(const float* __restrict__ label, float* __restrict__ onehot, long long P, int ncls) {
+    const long long n = P * ncls, gs = (long long)gridDim.x * NT;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += gs) {
+        const long long p = i / ncls;
+        onehot[i] = (label[p] == (float)(i - p * ncls)) ? 1.f : 0.f;
+    }
+}
+
+// tf.argmax(y, 3) of the one-hot labels (compact_y) and tf.confusion_matrix(compact_y, compact_pred) in one pass: per-block counts in
+// LDS, then integer atomics into cm[truth][pred] (integer sums: order-independent, deterministic).  compact_y may be null.
+__global__ void __launch_bounds__(NT) confusion_kernel(const float* __restrict__ y, const int64_t* __restrict__ pred,
+                                                       int64_t* __restrict__ compact_y, unsigned long long* __restrict__ cm, long long P, int ncls) {
+    __shared__ unsigned int cnt[MAXC * MAXC];
+    for (int i = threadIdx.x; i < MAXC * MAXC; i += NT) cnt[i] = 0;
+    __syncthreads();
+    const long long gs = (long long)gridDim.x * NT;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < P; i += gs) {
+        int am = 0;
+        float best = y[i * ncls];
+        for (int j = 1; j < ncls; ++j) {
+            const float v = y[i * ncls + j];
+            if (v > best) { best = v; am = j; }          // lowest index on ties, like tf.argmax's kernels
+        }
+        if (compact_y) compact_y[i] = am;
+        if (pred) {
+            const int pr = (int)pred[i];
+            if ((unsigned)pr < (unsigned)ncls) atomicAdd(&cnt[am * ncls + pr], 1u);
+        }
+    }
+    __syncthreads();
+    if (pred)
+        for (int i = threadIdx.x; i < ncls * ncls; i += NT)
+            if (cnt[i]) atomicAdd(&cm[i], (unsigned long long)cnt[i]);
+}
+
+// synchronised batch statistics (opt-in): per-replica (mean, biased variance) -> raw moments in double, and back after the
+// sum over `world` replicas of equally many rows:  E[x] = sum(mean_r)/W,  E[x^2] = sum(var_r + mean_r^2)/W
+__global__ void bn_moments_kernel(const float* __restrict__ mean, const float* __restrict__ var, double* __restrict__ mom, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = (double)mean[c];
+    mom[c] = m;
+    mom[C + c] = (double)var[c] + m * m;
+}
+__global__ void bn_from_moments_kernel(const double* __restrict__ mom, int world, float* __restrict__ mean, float* __restrict__ var, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = mom[c] / (double)world;
+    double v = mom[C + c] / (double)world - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)m;
+    var[c] = (float)v;
+}
+
 }  // namespace
 
 extern "C" {
+
+int pnp_label_decomp(const float* label, float* onehot, int64_t P, int32_t ncls, void* stream) {
+    PNP_REQUIRE(label && onehot && P > 0 && ncls > 0, "pnp_label_decomp: bad argument");
+    long long nb = (P * ncls + NT - 1) / NT;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(label_decomp_kernel, dim3((unsigned)nb), dim3(NT), 0, (hipStream_t)stream, label, onehot, (long long)P, ncls);
+    PNP_CHECK_LAUNCH("pnp_label_decomp");
+    return PNP_OK;
+}
+
+int pnp_confusion_matrix(const float* y, const int64_t* pred, int64_t* compact_y, int64_t* cm, int64_t P, int32_t ncls, void* stream) {
+    PNP_REQUIRE(y && P > 0 && ncls > 0 && ncls <= MAXC, "pnp_confusion_matrix: bad argument (1..%d classes)", MAXC);
+    PNP_REQUIRE((pred != nullptr) == (cm != nullptr), "pnp_confusion_matrix: pred and cm go together");
+    PNP_REQUIRE(pred || compact_y, "pnp_confusion_matrix: nothing to compute");
+    hipStream_t st = (hipStream_t)stream;
+    if (cm && hipMemsetAsync(cm, 0, sizeof(int64_t) * ncls * ncls, st) != hipSuccess) {
+        pnp_set_error("pnp_confusion_matrix: memset failed");
+        return PNP_ELAUNCH;
+    }
+    long long nb = (P + NT - 1) / NT;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)nb), dim3(NT), 0, st, y, pred, compact_y, (unsigned long long*)cm, (long long)P, ncls);
+    PNP_CHECK_LAUNCH("pnp_confusion_matrix");
+    return PNP_OK;
+}
+
+int pnp_bn_moments(const float* mean, const float* var, double* moments, int32_t C, void* stream) {
+    PNP_REQUIRE(mean && var && moments && C > 0, "pnp_bn_moments: bad argument");
+    hipLaunchKernelGGL(bn_moments_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, mean, var, moments, C);
+    PNP_CHECK_LAUNCH("pnp_bn_moments");
+    return PNP_OK;
+}
+
+int pnp_bn_from_moments(const double* moments, int32_t world, float* mean, float* var, int32_t C, void* stream) {
+    PNP_REQUIRE(mean && var && moments && C > 0 && world > 0, "pnp_bn_from_moments: bad argument");
+    hipLaunchKernelGGL(bn_from_moments_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, moments, world, mean, var, C);
+    PNP_CHECK_LAUNCH("pnp_bn_from_moments");
+    return PNP_OK;
+}
 
 size_t pnp_seg_loss_workspace_bytes(int64_t P, int32_t ncls) {
     (void)ncls;

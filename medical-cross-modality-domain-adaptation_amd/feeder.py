@@ -15,7 +15,7 @@ import threading
 import numpy as np
 import torch
 
-from .lib import label_decomp_device
+from .lib import _label_decomp, label_decomp_device
 
 
 class DeviceFeeder(object):
@@ -72,8 +72,9 @@ class DeviceFeeder(object):
                         done.record(self._stream)
                     ev[0] = done
                 else:
-                    xd, ld = xs.clone(), ls.clone()
-                    yd = label_decomp_device(self.num_cls, ld)
+                    # host tensors (CPU plumbing tests only): the reference's own host-side one-hot, lib._label_decomp (lib.py:75-92)
+                    xd = xs.clone()
+                    yd = torch.from_numpy(_label_decomp(self.num_cls, ls.numpy()))
                     done = None
                 item = (xd, yd, fids, done)
                 while not self._stop:

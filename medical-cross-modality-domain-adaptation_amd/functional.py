@@ -30,6 +30,33 @@ def sync_now():
     return par.sync_world() > 1 and torch.is_grad_enabled()
 
 
+# Inference-mode BN saves its statistics for the backward pass BY REFERENCE (a device copy of two [C] vectors per layer cost ~200
+# copy launches per GAN step).  The only writer of moving statistics is pnp_bn_update_moving below (a training-mode forward of the same
+# layer); it bumps this per-buffer counter, and a backward that finds its saved statistics bumped refuses to run.
+_STAT_VERSION = {}
+
+
+def _stat_version(t):
+    return _STAT_VERSION.get(t.data_ptr(), 0)
+
+
+def _bump_stat_version(*ts):
+    for t in ts:
+        _STAT_VERSION[t.data_ptr()] = _STAT_VERSION.get(t.data_ptr(), 0) + 1
+
+
+def _frozen_stats(ctx, moving_mean, moving_var):
+    ctx.stat_versions = (_stat_version(moving_mean), _stat_version(moving_var))
+    return moving_mean, moving_var
+
+
+def _check_frozen_stats(ctx, mean, var):
+    sv = getattr(ctx, "stat_versions", None)
+    if sv is not None and sv != (_stat_version(mean), _stat_version(var)):
+        raise RuntimeError("BN moving statistics were updated between an inference-mode forward and its backward pass "
+                           "(a training-mode forward of the same layer ran in between)")
+
+
 def _contig(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -79,8 +106,7 @@ class ConvBNActFn(Function):
         ctx.sc_channels = sc.shape[-1] if sc is not None else 0
         ctx.fused = (not is_train) and FUSE_BN_INFER and not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         if ctx.fused:
-            # inference statistics; snapshot only if a backward pass will read them after the moving averages may have moved
-            mean, var = (moving_mean.clone(), moving_var.clone()) if any(ctx.needs_input_grad) else (moving_mean, moving_var)
+            mean, var = _frozen_stats(ctx, moving_mean, moving_var)
             out = K.conv2d_fwd_bn(x, w_, geom, K.bn_fold(gamma, beta, mean, var, BN_EPS), sc, alpha, keep_prob, seed, stream_id)
             ctx.P_norm = out.numel() // out.shape[-1]
             ctx.save_for_backward(x, w_, out, out, mean, var, gamma)     # the pre-BN tensor is never read in inference mode
@@ -94,8 +120,9 @@ class ConvBNActFn(Function):
                 mean, var = par.sync_bn_stats(mean, var)
                 ctx.P_norm = P * par.sync_world()
             K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
+            _bump_stat_version(moving_mean, moving_var)
         else:
-            mean, var = (moving_mean.clone(), moving_var.clone()) if any(ctx.needs_input_grad) else (moving_mean, moving_var)
+            mean, var = _frozen_stats(ctx, moving_mean, moving_var)
         out = K.bn_apply(xc, mean, var, gamma, beta, sc, BN_EPS, alpha)
         ctx.save_for_backward(x, w_, xc, out, mean, var, gamma)
         return out
@@ -103,6 +130,7 @@ class ConvBNActFn(Function):
     @staticmethod
     def backward(ctx, dout):
         x, w, xc, out, mean, var, gamma = ctx.saved_tensors
+        _check_frozen_stats(ctx, mean, var)
         dout = _contig(dout)
         need_sc = ctx.sc_channels if ctx.needs_input_grad[6] else 0
         if ctx.fused:
@@ -131,9 +159,9 @@ class BNActFn(Function):
                 mean, var = par.sync_bn_stats(mean, var)
                 ctx.P_norm = P * par.sync_world()
             K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
+            _bump_stat_version(moving_mean, moving_var)
         else:
-            # inference statistics; snapshot only if a backward pass will read them after the moving averages may have moved
-            mean, var = (moving_mean.clone(), moving_var.clone()) if any(ctx.needs_input_grad) else (moving_mean, moving_var)
+            mean, var = _frozen_stats(ctx, moving_mean, moving_var)
         out = K.bn_apply(xc, mean, var, gamma, beta, None, BN_EPS, alpha)
         ctx.save_for_backward(xc, out, mean, var, gamma)
         ctx.is_train, ctx.alpha = is_train, alpha
@@ -142,6 +170,7 @@ class BNActFn(Function):
     @staticmethod
     def backward(ctx, dout):
         xc, out, mean, var, gamma = ctx.saved_tensors
+        _check_frozen_stats(ctx, mean, var)
         dxc, dgamma, dbeta, _ = _bn_bwd(ctx, _contig(dout), out, xc, mean, var, gamma, 0, 1.0, 0, 0)
         return dxc, dgamma, dbeta, None, None, None, None, None
 

@@ -320,6 +320,43 @@ def dice_eval(label, y):
     return out
 
 
+def label_decomp(label, ncls):
+    """lib._label_decomp (lib.py:75-92) on the device: integer-valued float label map [...] -> one-hot float32 [..., ncls]"""
+    lab = label if label.dtype == torch.float32 else label.to(torch.float32)
+    lab = lab.contiguous()
+    out = torch.empty(tuple(lab.shape) + (ncls,), dtype=torch.float32, device=lab.device)
+    check(_lib.load().pnp_label_decomp(_p(lab), _p(out), lab.numel(), int(ncls), _stream()), "pnp_label_decomp")
+    return out
+
+
+def confusion_matrix(y, pred=None, want_compact=True):
+    """(compact_y = argmax of the one-hot labels, confusion matrix [ncls, ncls] int64 rows = truth) — source_segmenter.py:83-85"""
+    ncls = y.shape[-1]
+    P = y.numel() // ncls
+    cy = torch.empty(y.shape[:-1], dtype=torch.int64, device=y.device) if want_compact else None
+    cm = torch.empty((ncls, ncls), dtype=torch.int64, device=y.device) if pred is not None else None
+    if pred is not None and (pred.dtype != torch.int64 or not pred.is_contiguous()):
+        raise _lib.PnpError("confusion_matrix: pred must be a contiguous int64 label map")
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    check(_lib.load().pnp_confusion_matrix(_p(y), vp(pred), vp(cy), vp(cm), P, ncls, _stream()), "pnp_confusion_matrix")
+    return cy, cm
+
+
+def bn_moments(mean, var):
+    C = mean.numel()
+    mom = torch.empty(2 * C, dtype=torch.float64, device=mean.device)
+    check(_lib.load().pnp_bn_moments(_p(mean), _p(var), ctypes.c_void_p(mom.data_ptr()), C, _stream()), "pnp_bn_moments")
+    return mom
+
+
+def bn_from_moments(mom, world):
+    C = mom.numel() // 2
+    mean = torch.empty(C, dtype=torch.float32, device=mom.device)
+    var = torch.empty(C, dtype=torch.float32, device=mom.device)
+    check(_lib.load().pnp_bn_from_moments(ctypes.c_void_p(mom.data_ptr()), int(world), _p(mean), _p(var), C, _stream()), "pnp_bn_from_moments")
+    return mean, var
+
+
 def _u8p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 

@@ -74,10 +74,8 @@ def _label_decomp(num_cls, label_vol):
 
 
 def label_decomp_device(num_cls, label_vol):
-    """same as _label_decomp for a device tensor (pure indexing, no arithmetic)"""
-    lab = label_vol.to(torch.float32)
-    cls = torch.arange(num_cls, device=lab.device, dtype=torch.float32)
-    return (lab.unsqueeze(-1) == cls).to(torch.float32).contiguous()
+    """same as _label_decomp for a device tensor: pnp_label_decomp"""
+    return K.label_decomp(label_vol, num_cls)
 
 
 def _dice_eval(compact_pred, labels, n_class):
@@ -86,11 +84,11 @@ def _dice_eval(compact_pred, labels, n_class):
     return out[0], [out[1 + i] for i in range(n_class)]
 
 
-def confusion_matrix(compact_y, compact_pred, num_classes):
-    """tf.confusion_matrix(labels, predictions) (source_segmenter.py:85): rows = ground truth, cols = prediction.
-    Monitoring only (every display_step); integer bincount on device."""
-    idx = compact_y.reshape(-1).to(torch.int64) * num_classes + compact_pred.reshape(-1).to(torch.int64)
-    return torch.bincount(idx, minlength=num_classes * num_classes).reshape(num_classes, num_classes).cpu().numpy()
+def compact_and_confusion(y, compact_pred=None):
+    """compact_y = tf.argmax(y, 3) and tf.confusion_matrix(compact_y, compact_pred) (source_segmenter.py:83-85; rows = ground truth,
+    cols = prediction) in one kernel (pnp_confusion_matrix).  Returns (compact_y device int64, confusion matrix as numpy or None)."""
+    cy, cm = K.confusion_matrix(y.contiguous(), compact_pred.contiguous() if compact_pred is not None else None)
+    return cy, (cm.cpu().numpy() if cm is not None else None)
 
 
 def _inverse_lookup(my_dict, _value):
@@ -102,27 +100,18 @@ def _inverse_lookup(my_dict, _value):
 
 
 def _jaccard(conf_matrix):
-    """lib.py:121-134"""
-    num_cls = conf_matrix.shape[0]
-    jac = np.zeros(num_cls)
-    for ii in range(num_cls):
-        pp = np.sum(conf_matrix[:, ii])
-        gp = np.sum(conf_matrix[ii, :])
-        hit = conf_matrix[ii, ii]
-        jac[ii] = 0 if (pp + gp - hit) == 0 else hit * 1.0 / (pp + gp - hit)
-    return jac
+    """lib.py:121-134: per-class intersection over union from a confusion matrix (rows = truth, cols = prediction); 0 for an empty class"""
+    cm = np.asarray(conf_matrix, dtype=np.float64)
+    hit = np.diag(cm)
+    union = cm.sum(axis=0) + cm.sum(axis=1) - hit
+    return np.divide(hit, union, out=np.zeros_like(hit), where=union != 0)
 
 
 def _dice(conf_matrix):
-    """lib.py:137-151"""
-    num_cls = conf_matrix.shape[0]
-    dic = np.zeros(num_cls)
-    for ii in range(num_cls):
-        pp = np.sum(conf_matrix[:, ii])
-        gp = np.sum(conf_matrix[ii, :])
-        hit = conf_matrix[ii, ii]
-        dic[ii] = 0 if (pp + gp) == 0 else 2.0 * hit / (pp + gp)
-    return dic
+    """lib.py:137-151: per-class Dice 2|P n G| / (|P| + |G|) from a confusion matrix; 0 for an empty class"""
+    cm = np.asarray(conf_matrix, dtype=np.float64)
+    total = cm.sum(axis=0) + cm.sum(axis=1)
+    return np.divide(2.0 * np.diag(cm), total, out=np.zeros(cm.shape[0]), where=total != 0)
 
 
 def _indicator_eval(cm, verbose=True):

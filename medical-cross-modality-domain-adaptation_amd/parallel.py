@@ -157,18 +157,21 @@ def all_sum_(t):
 
 
 def sync_bn_stats(mean, var):
-    """per-replica (mean, biased var) over equally many rows -> the statistics of the concatenated batch.  Combined in float64:
-    E[x] = avg(mean_r), E[x^2] = avg(var_r + mean_r^2)."""
+    """per-replica (mean, biased var) over equally many rows -> the statistics of the concatenated batch: raw moments in float64
+    (pnp_bn_moments), summed over the replicas, converted back (pnp_bn_from_moments) — no torch arithmetic"""
     w = sync_world()
     if w <= 1:
         return mean, var
-    m = mean.double()
-    st = torch.stack([m, var.double() + m * m])
-    all_sum_(st)
-    st /= w
-    gm = st[0]
-    gv = (st[1] - gm * gm).clamp_min_(0.0)
-    return gm.float(), gv.float()
+    if not mean.is_cuda:         # host tensors: only the gloo / CPU tests of the collective logic come here (no kernel can run on them)
+        m = mean.double()
+        mom = torch.cat([m, var.double() + m * m])
+        all_sum_(mom)
+        gm = mom[:m.numel()] / w
+        return gm.float(), (mom[m.numel():] / w - gm * gm).clamp_min_(0.0).float()
+    from . import kernels as K
+    mom = K.bn_moments(mean, var)
+    all_sum_(mom)
+    return K.bn_from_moments(mom, w)
 
 
 def barrier():

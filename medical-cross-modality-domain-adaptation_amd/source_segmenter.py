@@ -239,11 +239,11 @@ class Full_DRN(object):
             lv = self._get_cost(logits, y)
             self.cost, self.weighted_loss, self.dice_loss = lv[0], lv[1], lv[2]
             self.predicter, self.compact_pred = K.softmax_argmax(logits.contiguous(), want_prob=True)
-            self.compact_y = torch.argmax(y, 3)
+            self.compact_y, cm = lib.compact_and_confusion(y, self.compact_pred if want_confusion else None)
             self.dice_eval, self.dice_eval_arr = _dice_eval(self.compact_pred, y, self.n_class)
             self.regularizer_loss = self.l2_regularizer()
             if want_confusion:
-                self.confusion_matrix = lib.confusion_matrix(self.compact_y, self.compact_pred, self.n_class)
+                self.confusion_matrix = cm
         return self.cost
 
     def l2_regularizer(self):

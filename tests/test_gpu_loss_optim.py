@@ -120,3 +120,30 @@ def test_optimizers(dev):
     a = torch.from_numpy(w0.copy()).to(dev); b = torch.ones_like(a)
     K.axpby(a, b, 2.0, 0.5)
     assert _rel(b, torch.from_numpy(w0) * 2 + 0.5) < 1e-6
+
+
+def test_label_decomp_confusion_matrix_and_bn_moments(dev):
+    """the label / monitoring helpers of the step path as kernels (lib.py:75-92, source_segmenter.py:83-85) and the SyncBN moment
+    conversion, against plain numpy"""
+    K, lib = pkg("kernels"), pkg("lib")
+    rng = np.random.default_rng(3)
+    lab = rng.integers(0, 7, size=(3, 64, 48)).astype(np.float32)          # labels 5, 6 >= num_cls: all-zero rows
+    oh = K.label_decomp(torch.from_numpy(lab).to(dev), 5)
+    ref = lib._label_decomp(5, lab)
+    assert np.array_equal(oh.cpu().numpy(), ref)
+    pred = torch.from_numpy(rng.integers(0, 5, size=lab.shape)).to(dev)
+    cy, cm = lib.compact_and_confusion(oh, pred)
+    cy_ref = ref.argmax(-1)                                                # lowest index on ties: all-zero rows -> class 0
+    assert np.array_equal(cy.cpu().numpy(), cy_ref)
+    cm_ref = np.zeros((5, 5), np.int64)
+    np.add.at(cm_ref, (cy_ref.ravel(), pred.cpu().numpy().ravel()), 1)
+    assert np.array_equal(cm, cm_ref) and cm.sum() == lab.size
+    cy2, none = lib.compact_and_confusion(oh, None)
+    assert none is None and torch.equal(cy2, cy)
+    # SyncBN moments: two "replicas" with known statistics -> statistics of the concatenation
+    a, b = rng.standard_normal((1000, 8)) * 2 + 1, rng.standard_normal((1000, 8)) * 0.5 - 3
+    f = lambda t: torch.from_numpy(t.astype(np.float32)).to(dev)
+    mom = K.bn_moments(f(a.mean(0)), f(a.var(0))) + K.bn_moments(f(b.mean(0)), f(b.var(0)))
+    mean, var = K.bn_from_moments(mom, 2)
+    both = np.concatenate([a, b])
+    assert np.allclose(mean.cpu().numpy(), both.mean(0), rtol=1e-6, atol=1e-6) and np.allclose(var.cpu().numpy(), both.var(0), rtol=1e-5)
