@@ -107,6 +107,8 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const Acc<TM, TN>& a
 }
 
 // ======================= forward / stride-1 data gradient / stride-phase sub-filters (taps unrolled) ============================
+constexpr int DEPTH = 3;      // global-load stages in flight per workgroup (register ring)
+
 template <int BM, int BN, int WM, int WN, int KIND, int R, int S>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_bf16_kernel(ConvArgs a) {
     constexpr int NTAP = R * S;
@@ -166,59 +168,81 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_bf16_kernel(ConvArgs a)
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
-    f32x4 areg[NR];
-    auto gload = [&](int cc, int tap) {
-        const int tshift = (((tap / S) * a.dil * a.W + (tap % S) * a.dil) * a.C) * 4;
-        const int sa = cc * (BK * 4);
-        const int sb = ((tap * a.C + cc * BK) * a.K) * 4;
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const unsigned vo = ((amask[i] >> tap) & 1u) ? (unsigned)(abase[i] + tshift) : OOB2;
-            areg[i] = bload4s(rx, vo, sa);
-        }
-#pragma unroll
-        for (int p = 0; p < TransposedTile<BN>::PASSES; ++p)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) tb.reg[p][j] = bload4s(rw, boff[p][j], sb);
+    // Register ring of DEPTH stages: a 32-k stage is only 8 MFMAs (256 matrix-pipe cycles) per wave, a tenth of the global-load
+    // latency under load, so the loads of stage j + DEPTH are issued while stage j is contracted (first version: one stage ahead,
+    // stage time == load latency: 512->512 ran at 342 TF/s).  The ring is indexed with compile-time constants only (loop unrolled
+    // DEPTH times) so that it lives in VGPRs.  No stage is conditional inside the loop (a uniform "past the end?" select around a load
+    // makes hipcc branch around every load and wait vmcnt(0) in between — seen in the first attempt): fetches past the last stage
+    // simply re-read the last channel group (valid addresses, never stored), and the nst % DEPTH leftover stages run after the loop.
+    struct Stage {
+        f32x4 a[NR];
+        f32x4 b[TransposedTile<BN>::PASSES][4];
     };
-    auto lstore = [&](__bf16* An, __bf16* Bn) {
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-            *reinterpret_cast<bf16x4*>(An + (mrow + 32 * i) * LDH + 4 * kg) = cvt4(areg[i][0], areg[i][1], areg[i][2], areg[i][3]);
-        tb.store(Bn);
-    };
-
-    Acc<TM, TN> acc;
-    acc.zero();
+    Stage ring[DEPTH];
     const int ncc_total = a.C / BK;
     const int cc_begin = z * (a.chunks_per_split / NTAP);
     int cc_end = cc_begin + a.chunks_per_split / NTAP;
     if (cc_end > ncc_total) cc_end = ncc_total;
+    const int nst = (cc_end - cc_begin) * NTAP;
+    int l_cc = cc_begin, l_tap = 0;                        // (channel group, tap) of the next stage to fetch: uniform, scalar registers
+    auto gload = [&](Stage& st) {
+        const int tr = l_tap / S, ts = l_tap - tr * S;
+        const int tshift = ((tr * a.dil * a.W + ts * a.dil) * a.C) * 4;
+        const int sa = l_cc * (BK * 4);
+        const int sb = ((l_tap * a.C + l_cc * BK) * a.K) * 4;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const unsigned vo = ((amask[i] >> l_tap) & 1u) ? (unsigned)(abase[i] + tshift) : OOB2;
+            st.a[i] = bload4s(rx, vo, sa);
+        }
+#pragma unroll
+        for (int p = 0; p < TransposedTile<BN>::PASSES; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st.b[p][j] = bload4s(rw, boff[p][j], sb);
+        const int wrap = (l_tap + 1 == NTAP) ? 1 : 0;
+        l_tap = wrap ? 0 : l_tap + 1;
+        l_cc = min(l_cc + wrap, cc_end - 1);
+    };
+    auto lstore = [&](const Stage& st, __bf16* An, __bf16* Bn) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            *reinterpret_cast<bf16x4*>(An + (mrow + 32 * i) * LDH + 4 * kg) = cvt4(st.a[i][0], st.a[i][1], st.a[i][2], st.a[i][3]);
+#pragma unroll
+        for (int p = 0; p < TransposedTile<BN>::PASSES; ++p) {
+            if (!tb.active(p)) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<bf16x4*>(Bn + (4 * (tb.nb + 32 * p) + e) * LDH + 4 * tb.kb) = cvt4(st.b[p][0][e], st.b[p][1][e], st.b[p][2][e], st.b[p][3][e]);
+        }
+    };
 
-    gload(cc_begin, 0);
-    lstore(lds, lds + 2 * ASZ);
+    Acc<TM, TN> acc;
+    acc.zero();
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) gload(ring[d]);
+    lstore(ring[0], lds, lds + 2 * ASZ);
     __syncthreads();
     FragH<TM, TN> f;
-    int sc = 0;
-    for (int cc = cc_begin; cc < cc_end; ++cc) {
+    // stage j: LDS buffer j & 1; ring[j % DEPTH] is free (its stage was stored during stage j - 1) and takes stage j + DEPTH;
+    // ring[(j + 1) % DEPTH] holds stage j + 1, fetched DEPTH - 1 stages ago
+    auto stage = [&](int j, Stage& fetch_into, const Stage& store_from, bool fetch) {
+        const int cur = j & 1;
+        const __bf16* As = lds + cur * ASZ;
+        const __bf16* Bs = lds + 2 * ASZ + cur * BSZ;
+        f.load(As, Bs, wm0, wn0, lane);
+        if (fetch) gload(fetch_into);
+        f.mma(acc);
+        lstore(store_from, lds + (cur ^ 1) * ASZ, lds + 2 * ASZ + (cur ^ 1) * BSZ);
+        __syncthreads();
+    };
+    const int nmain = (nst / DEPTH) * DEPTH;
+    for (int j0 = 0; j0 < nmain; j0 += DEPTH) {
 #pragma unroll
-        for (int tap = 0; tap < NTAP; ++tap) {
-            const int cur = sc & 1;
-            ++sc;
-            const __bf16* As = lds + cur * ASZ;
-            const __bf16* Bs = lds + 2 * ASZ + cur * BSZ;
-            __bf16* An = lds + (cur ^ 1) * ASZ;
-            __bf16* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
-            const int ntap = (tap + 1 < NTAP) ? tap + 1 : 0;
-            int ncc = (tap + 1 < NTAP) ? cc : cc + 1;
-            ncc = (ncc < cc_end) ? ncc : cc;
-            gload(ncc, ntap);              // next stage's global loads fly under this stage's fragment reads and MFMAs
-            f.load(As, Bs, wm0, wn0, lane);
-            f.mma(acc);
-            lstore(An, Bn);
-            __syncthreads();
-        }
+        for (int d = 0; d < DEPTH; ++d) stage(j0 + d, ring[d], ring[(d + 1) % DEPTH], true);
     }
+    static_assert(DEPTH == 3, "tail below is written for a ring of three");
+    if (nst - nmain >= 1) stage(nmain, ring[0], ring[1], false);
+    if (nst - nmain >= 2) stage(nmain + 1, ring[1], ring[2], false);
     epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, a.M, true);
 }
 
@@ -284,12 +308,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_bf16_kernel(ConvArgs a
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
     // rows past the end of this split's pixel range: splits end on stage boundaries, and rows past the LAST pixel are past the end of
-    // dy (hardware zero) — same argument as conv_wgrad_kernel's MODE 3
-    auto gload = [&](int chunk) {
+    // dy (hardware zero) — same argument as conv_wgrad_kernel's MODE 3.  Fetches past this split's last stage (the ring runs DEPTH ahead)
+    // read the next split's rows, or zeros past the end of the tensors; those stages are never stored or contracted.
+    struct Stage {
+        f32x4 a[4];
+        f32x4 b[TransposedTile<BN>::PASSES][4];
+    };
+    Stage ring[DEPTH];
+    int l_chunk = c_begin;
+    auto gload = [&](Stage& st) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = mok & ((unsigned)(l_oh[j] + l_dh) < (unsigned)a.H) & ((unsigned)(l_ow[j] + l_dw) < (unsigned)a.W);
-            ta.reg[0][j] = bload4(rx, ok ? (unsigned)l_off[j] : OOB);
+            st.a[j] = bload4(rx, ok ? (unsigned)l_off[j] : OOB);
             l_ow[j] += BK;
             l_off[j] += BK * a.C * 4;
             const bool ww = l_ow[j] >= a.OW;                    // at most one wrap per step because OW >= 32
@@ -300,36 +331,51 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_bf16_kernel(ConvArgs a
             l_oh[j] -= hw ? a.OH : 0;
             l_off[j] += hw ? (a.H - a.OH) * a.W * a.C * 4 : 0;
         }
-        const int soff = chunk * BK * a.K * 4;
+        const int soff = l_chunk * BK * a.K * 4;
 #pragma unroll
         for (int p = 0; p < TransposedTile<BN>::PASSES; ++p)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tb.reg[p][j] = bload4s(rw, boff[p][j], soff);
+            for (int j = 0; j < 4; ++j) st.b[p][j] = bload4s(rw, boff[p][j], soff);
+        l_chunk = min(l_chunk + 1, nchunks_total);          // rows past the end of dy read as zeros
+    };
+    auto lstore = [&](const Stage& st, __bf16* An, __bf16* Bn) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            *reinterpret_cast<bf16x4*>(An + (4 * ta.nb + e) * LDH + 4 * ta.kb) = cvt4(st.a[0][e], st.a[1][e], st.a[2][e], st.a[3][e]);
+#pragma unroll
+        for (int p = 0; p < TransposedTile<BN>::PASSES; ++p) {
+            if (!tb.active(p)) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<bf16x4*>(Bn + (4 * (tb.nb + 32 * p) + e) * LDH + 4 * tb.kb) = cvt4(st.b[p][0][e], st.b[p][1][e], st.b[p][2][e], st.b[p][3][e]);
+        }
     };
 
     Acc<TM, TN> acc;
     acc.zero();
     if (nchunks > 0) {
-        gload(c_begin);
-        ta.store(lds);
-        tb.store(lds + 2 * ASZ);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) gload(ring[d]);
+        lstore(ring[0], lds, lds + 2 * ASZ);
         __syncthreads();
         FragH<TM, TN> f;
-        for (int c = 0; c < nchunks; ++c) {
-            const int cur = c & 1;
+        auto stage = [&](int j, Stage& fetch_into, const Stage& store_from, bool fetch) {
+            const int cur = j & 1;
             const __bf16* As = lds + cur * ASZ;
             const __bf16* Bs = lds + 2 * ASZ + cur * BSZ;
-            __bf16* An = lds + (cur ^ 1) * ASZ;
-            __bf16* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
-            // the prefetch past this split's last stage reads the next split's first stage (or past the end of dy = zeros) into the
-            // LDS buffer nobody reads
-            gload(c_begin + c + 1);
             f.load(As, Bs, wm0, wn0, lane);
+            if (fetch) gload(fetch_into);
             f.mma(acc);
-            ta.store(An);
-            tb.store(Bn);
+            lstore(store_from, lds + (cur ^ 1) * ASZ, lds + 2 * ASZ + (cur ^ 1) * BSZ);
             __syncthreads();
+        };
+        const int nmain = (nchunks / DEPTH) * DEPTH;
+        for (int j0 = 0; j0 < nmain; j0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) stage(j0 + d, ring[d], ring[(d + 1) % DEPTH], true);
         }
+        if (nchunks - nmain >= 1) stage(nmain, ring[0], ring[1], false);
+        if (nchunks - nmain >= 2) stage(nmain + 1, ring[1], ring[2], false);
     }
     epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, mm0, n0, wm0, wn0, lane, a.Kred, false);
 }

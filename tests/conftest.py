@@ -32,3 +32,45 @@ def dev(built):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+GUARD_BYTES = 4096
+
+
+@pytest.fixture(autouse=True)
+def workspace_canary(request):
+    """Out-of-bounds canary around every kernel workspace of a -m gpu test: kernels.workspace() hands the kernels a
+    view of EXACTLY the bytes the pnp_*_workspace_bytes query asked for (the documented contract), followed by a guard zone filled
+    with 0xA5; after the test every guard zone must be intact."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    K = pkg("kernels")
+    orig = K.workspace
+    last = {}           # base buffer -> guard zone of the most recent request (earlier zones may lie inside a later, larger request)
+
+    def check(g):
+        assert bool((g == 0xA5).all()), "a kernel wrote past the workspace it asked for"
+
+    def guarded(nbytes, device, slot="main"):
+        nbytes = int(nbytes)
+        buf = orig(nbytes + GUARD_BYTES, device, slot)
+        prev = last.get(buf.data_ptr())
+        if prev is not None:
+            check(prev)             # stream-ordered: every kernel that used the previous view has been queued before this read
+        g = buf[nbytes:nbytes + GUARD_BYTES]
+        g.fill_(0xA5)
+        last[buf.data_ptr()] = g
+        return buf[:max(nbytes, 1)]
+    K.workspace = guarded
+    try:
+        yield
+    finally:
+        K.workspace = orig
+    torch.cuda.synchronize()
+    for g in last.values():
+        check(g)
