@@ -132,6 +132,9 @@ int pnp_dropout(const float* x, float* y, size_t n, float keep_prob, uint64_t se
 size_t pnp_bn_workspace_bytes(int64_t P, int32_t C);
 int pnp_bn_stats(const float* x, float* mean, float* var, int64_t P, int32_t C,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* pnp_bn_stats + pnp_bn_update_moving in one pass (the per-replica training-mode forward: one launch less per BN layer) */
+int pnp_bn_stats_update(const float* x, float* mean, float* var, float* moving_mean, float* moving_var, int64_t P, int32_t C,
+                        float decay, void* workspace, size_t workspace_bytes, void* stream);
 /* moving_mean -= (1-decay)*(moving_mean-mean); moving_var likewise with var*P/(P-1) (Bessel) */
 int pnp_bn_update_moving(float* moving_mean, float* moving_var, const float* mean, const float* var,
                          int64_t P, int32_t C, float decay, void* stream);

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "pnp_dropout": (c_int, [_F, _F, c_size_t, c_float, c_uint64, c_uint32, c_void_p]),
     "pnp_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "pnp_bn_stats": (c_int, [_F, _F, _F, c_int64, c_int32, c_void_p, c_size_t, c_void_p]),
+    "pnp_bn_stats_update": (c_int, [_F, _F, _F, _F, _F, c_int64, c_int32, c_float, c_void_p, c_size_t, c_void_p]),
     "pnp_bn_update_moving": (c_int, [_F, _F, _F, _F, c_int64, c_int32, c_float, c_void_p]),
     "pnp_bn_apply": (c_int, [_F, _F, _F, _F, _F, _F, c_int32, _F, c_int64, c_int32, c_float, c_float, c_void_p]),
     "pnp_bn_bwd": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int32, c_float, c_float, c_int32,

@@ -142,7 +142,8 @@ __global__ void colreduce_scalar_kernel(ColArgs a) {
 // final combine over blocks in double. KIND 0 -> mean,var ; KIND 1 -> dbeta (o0), dgamma (o1)
 template <int KIND>
 __global__ void __launch_bounds__(1024) colreduce_final_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
-                                                               float* o0, float* o1, int nblk, int C, long long P) {
+                                                               float* o0, float* o1, int nblk, int C, long long P, float* mm, float* mv,
+                                                               float decay) {
     // 1024 threads = 32 channels x 32 slices of the block list; fixed summation order => deterministic
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -169,8 +170,15 @@ __global__ void __launch_bounds__(1024) colreduce_final_kernel(const float* __re
         const double md = s0 * inv;                 // mean of (x - shift)
         double var = s1 * inv - md * md;
         if (var < 0.0) var = 0.0;
-        o0[c] = (float)((double)x0[c] + md);
-        o1[c] = (float)var;
+        const float meanf = (float)((double)x0[c] + md), varf = (float)var;
+        o0[c] = meanf;
+        o1[c] = varf;
+        if (mm) {       // tf.contrib.layers.batch_norm(updates_collections=None): the moving averages move with every training-mode forward
+            const float one_minus = 1.0f - decay;
+            const float bessel = P > 1 ? (float)((double)P / (double)(P - 1)) : 1.0f;
+            mm[c] -= (mm[c] - meanf) * one_minus;
+            mv[c] -= (mv[c] - varf * bessel) * one_minus;
+        }
     } else {
         o0[c] = (float)s0;
         o1[c] = (float)s1;
@@ -192,7 +200,8 @@ int colreduce_plan(long long P, int C, int* nblk, int* rpb) {
 }
 
 template <int KIND>
-int run_colreduce(ColArgs a, float* o0, float* o1, void* ws, size_t ws_bytes, hipStream_t st, const char* who) {
+int run_colreduce(ColArgs a, float* o0, float* o1, void* ws, size_t ws_bytes, hipStream_t st, const char* who, float* mm = nullptr,
+                  float* mv = nullptr, float decay = 0.f) {
     int nblk, rpb;
     colreduce_plan(a.P, a.C, &nblk, &rpb);
     const size_t need = (size_t)nblk * 2 * a.C * sizeof(float);
@@ -209,7 +218,7 @@ int run_colreduce(ColArgs a, float* o0, float* o1, void* ws, size_t ws_bytes, hi
     }
     PNP_CHECK_LAUNCH(who);
     hipLaunchKernelGGL(colreduce_final_kernel<KIND>, dim3(pnp_cdiv(a.C, 32)), dim3(1024), 0, st, (const float*)ws, a.x, o0,
-                       o1, nblk, a.C, a.P);
+                       o1, nblk, a.C, a.P, mm, mv, decay);
     PNP_CHECK_LAUNCH(who);
     return PNP_OK;
 }
@@ -635,6 +644,14 @@ int pnp_bn_stats(const float* x, float* mean, float* var, int64_t P, int32_t C, 
     ColArgs a{};
     a.x = x; a.P = P; a.C = C;
     return run_colreduce<0>(a, mean, var, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_stats");
+}
+
+int pnp_bn_stats_update(const float* x, float* mean, float* var, float* moving_mean, float* moving_var, int64_t P, int32_t C, float decay,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    PNP_REQUIRE(x && mean && var && moving_mean && moving_var && P > 0 && C > 0, "pnp_bn_stats_update: bad argument");
+    ColArgs a{};
+    a.x = x; a.P = P; a.C = C;
+    return run_colreduce<0>(a, mean, var, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_stats_update", moving_mean, moving_var, decay);
 }
 
 int pnp_bn_update_moving(float* moving_mean, float* moving_var, const float* mean, const float* var, int64_t P, int32_t C,

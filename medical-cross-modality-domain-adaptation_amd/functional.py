@@ -115,11 +115,12 @@ class ConvBNActFn(Function):
         P = xc.numel() // xc.shape[-1]
         ctx.P_norm = P
         if is_train:
-            mean, var = K.bn_stats(xc)
             if sync:                  # opt-in SyncBN: statistics of the batch concatenated over the replicas
-                mean, var = par.sync_bn_stats(mean, var)
+                mean, var = par.sync_bn_stats(*K.bn_stats(xc))
                 ctx.P_norm = P * par.sync_world()
-            K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
+                K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
+            else:
+                mean, var = K.bn_stats_update(xc, moving_mean, moving_var, BN_DECAY)
             _bump_stat_version(moving_mean, moving_var)
         else:
             mean, var = _frozen_stats(ctx, moving_mean, moving_var)
@@ -154,11 +155,12 @@ class BNActFn(Function):
         P = xc.numel() // xc.shape[-1]
         ctx.P_norm = P
         if is_train:
-            mean, var = K.bn_stats(xc)
             if sync:                  # opt-in SyncBN: statistics of the batch concatenated over the replicas
-                mean, var = par.sync_bn_stats(mean, var)
+                mean, var = par.sync_bn_stats(*K.bn_stats(xc))
                 ctx.P_norm = P * par.sync_world()
-            K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
+                K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
+            else:
+                mean, var = K.bn_stats_update(xc, moving_mean, moving_var, BN_DECAY)
             _bump_stat_version(moving_mean, moving_var)
         else:
             mean, var = _frozen_stats(ctx, moving_mean, moving_var)

@@ -153,6 +153,19 @@ def bn_stats(x2d_like):
     return mean, var
 
 
+def bn_stats_update(x2d_like, mm, mv, decay=0.9):
+    """bn_stats + bn_update_moving in one pass (per-replica statistics)"""
+    lib = _lib.load()
+    C = x2d_like.shape[-1]
+    P = x2d_like.numel() // C
+    mean = torch.empty(C, dtype=torch.float32, device=x2d_like.device)
+    var = torch.empty(C, dtype=torch.float32, device=x2d_like.device)
+    ws = workspace(lib.pnp_bn_workspace_bytes(P, C), x2d_like.device)
+    check(lib.pnp_bn_stats_update(_p(x2d_like), _p(mean), _p(var), _p(mm), _p(mv), P, C, float(decay), ctypes.c_void_p(ws.data_ptr()),
+                                  ws.numel(), _stream()), "pnp_bn_stats_update")
+    return mean, var
+
+
 def bn_update_moving(mm, mv, mean, var, P, decay=0.9):
     lib = _lib.load()
     check(lib.pnp_bn_update_moving(_p(mm), _p(mv), _p(mean), _p(var), P, mm.numel(), float(decay), _stream()),

@@ -139,5 +139,6 @@ def test_segmenter_bf16_forward_within_budget_and_trains(dev):
     assert _rel(l32, lo32) < 1e-4
     assert 1e-4 < e_hip < 2.5 * e_cpu and e_hip < 0.1                           # tests/test_bf16_budget.py's bounds, and the oracle's size
     assert agree_hip > min(0.97, agree_cpu - 0.01) and dice_hip > min(0.95, dice_cpu - 0.02)
-    assert all(np.isfinite(v) for v in losses16) and abs(losses16[-1] - losses32[-1]) < 0.1 * abs(losses32[-1]) + 1e-3
-    assert losses16[-1] < losses16[0]
+    # the bf16 run tracks the fp32 run step by step (same data, same dropout masks, same Adam): within 2 % after four updates
+    assert all(np.isfinite(v) for v in losses16)
+    assert all(abs(a_ - b_) < 0.02 * abs(b_) + 1e-3 for a_, b_ in zip(losses16, losses32)), (losses16, losses32)
