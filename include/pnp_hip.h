@@ -94,6 +94,17 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
                       float keep_prob, uint64_t seed, uint32_t stream_id,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Training-mode conv -> dropout -> batch norm: the forward convolution leaves per-(pixel tile, wave row) partial sums of (y - shift[k])
+ * and (y - shift[k])^2 over its output rows, so that the batch statistics cost no second pass over the activation
+ * (pnp_bn_stats_finish combines them in double).  shift [K] (nullable = 0): any per-channel constant near the mean, e.g. the moving
+ * mean — it only conditions the variance.  pnp_conv2d_fwd_stats_parts(g) = number of partial rows, 0 when this geometry's forward
+ * cannot provide them (vector-ALU narrow-output kernels, reduction-split tiny layers): run pnp_bn_stats on the output instead.
+ * parts: [parts][2][K] floats. */
+int32_t pnp_conv2d_fwd_stats_parts(const pnp_conv_geom* g);
+int pnp_conv2d_fwd_stats(const float* x, const float* w, float* y, const pnp_conv_geom* g,
+                         float keep_prob, uint64_t seed, uint32_t stream_id,
+                         const float* shift /*nullable*/, float* parts, size_t parts_bytes, void* stream);
+
 /* Inference-mode conv -> dropout -> batch norm -> (+ shortcut) -> leaky-ReLU in ONE kernel (the monitoring forwards of
  * source_segmenter.py:525-570 / adversarial.py:948-991, every frozen-BN forward of the GAN steps, Trainer.test_eval):
  *   y = act( drop(conv(x,w)) * scale[k] + shift[k] + pad_channels(shortcut) ),  scale / shift from pnp_bn_fold.
@@ -135,6 +146,10 @@ int pnp_bn_stats(const float* x, float* mean, float* var, int64_t P, int32_t C,
 /* pnp_bn_stats + pnp_bn_update_moving in one pass (the per-replica training-mode forward: one launch less per BN layer) */
 int pnp_bn_stats_update(const float* x, float* mean, float* var, float* moving_mean, float* moving_var, int64_t P, int32_t C,
                         float decay, void* workspace, size_t workspace_bytes, void* stream);
+/* mean / biased variance from the partials of pnp_conv2d_fwd_stats (same shift), optionally followed by the moving-average update
+ * (moving_mean / moving_var nullable together; shift may alias moving_mean) */
+int pnp_bn_stats_finish(const float* parts, int32_t nparts, const float* shift, float* mean, float* var,
+                        float* moving_mean, float* moving_var, int64_t P, int32_t C, float decay, void* stream);
 /* moving_mean -= (1-decay)*(moving_mean-mean); moving_var likewise with var*P/(P-1) (Bessel) */
 int pnp_bn_update_moving(float* moving_mean, float* moving_var, const float* mean, const float* var,
                          int64_t P, int32_t C, float decay, void* stream);

@@ -64,6 +64,9 @@ PROTOTYPES = {
     "pnp_conv2d_wgrad": (c_int, [_F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
     "pnp_conv2d_fwd_workspace_bytes": (c_size_t, [_G]),
     "pnp_conv2d_fwd_ws": (c_int, [_F, _F, _F, _G, c_float, c_uint64, c_uint32, c_void_p, c_size_t, c_void_p]),
+    "pnp_conv2d_fwd_stats_parts": (c_int32, [_G]),
+    "pnp_conv2d_fwd_stats": (c_int, [_F, _F, _F, _G, c_float, c_uint64, c_uint32, _F, _F, c_size_t, c_void_p]),
+    "pnp_bn_stats_finish": (c_int, [_F, c_int32, _F, _F, _F, _F, _F, c_int64, c_int32, c_float, c_void_p]),
     "pnp_bn_fold": (c_int, [_F, _F, _F, _F, _F, _F, c_int32, c_float, c_void_p]),
     "pnp_conv2d_fwd_bn": (c_int, [_F, _F, _F, _G, c_float, c_uint64, c_uint32, _F, _F, _F, c_int32, c_float, c_void_p]),
     "pnp_conv2d_fwd_naive": (c_int, [_F, _F, _F, _G, c_void_p]),

@@ -78,11 +78,11 @@ struct TransposedTile {
     }
 };
 
+// filter-gradient tile -> dW rows (or a split partial)
 template <int TM, int TN>
-__device__ __forceinline__ void epilogue(const ConvArgs& a, const Acc<TM, TN>& acc, float* __restrict__ yout, int m0, int n0, int wm0, int wn0,
-                                         int lane, int Mrows, bool conv_out) {
+__device__ __forceinline__ void wgrad_epilogue(const ConvArgs& a, const Acc<TM, TN>& acc, float* __restrict__ out, int mm0, int n0, int wm0, int wn0,
+                                               int lane) {
     const int l31 = lane & 31, h = lane >> 5;
-    const bool scatter = conv_out && a.o_s != 0 && a.nsplit == 1;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -90,18 +90,8 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const Acc<TM, TN>& a
             const int n = n0 + wn0 + tn * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < Mrows && n < a.K) {
-                    float v = acc.v[tm][tn][r];
-                    if (conv_out) {
-                        const size_t idx = (size_t)m * a.K + n;
-                        if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-                        if (a.ep_scale) v = bn_epilogue(a, v, m, n);
-                        yout[out_row(a, m, scatter) + n] = v;
-                    } else {
-                        yout[(size_t)m * a.K + n] = v;
-                    }
-                }
+                const int m = mm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < a.Kred && n < a.K) out[(size_t)m * a.K + n] = acc.v[tm][tn][r];
             }
         }
 }
@@ -243,7 +233,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_bf16_kernel(ConvArgs a)
     static_assert(DEPTH == 3, "tail below is written for a ring of three");
     if (nst - nmain >= 1) stage(nmain, ring[0], ring[1], false);
     if (nst - nmain >= 2) stage(nmain + 1, ring[1], ring[2], false);
-    epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, a.M, true);
+    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN);
 }
 
 // ===================================== filter gradient ============================================
@@ -377,7 +367,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_bf16_kernel(ConvArgs a
         if (nchunks - nmain >= 1) stage(nmain, ring[0], ring[1], false);
         if (nchunks - nmain >= 2) stage(nmain + 1, ring[1], ring[2], false);
     }
-    epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, mm0, n0, wm0, wn0, lane, a.Kred, false);
+    wgrad_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, mm0, n0, wm0, wn0, lane);
 }
 
 template <int BM, int BN, int WM, int WN, int KIND>

@@ -42,6 +42,10 @@ struct ConvArgs {
     int ep_cs;                   // shortcut channels, zero-padded (K - ep_cs)/2 on each side
     float ep_alpha;
     int dtype;                   // PNP_DTYPE_F32 / PNP_DTYPE_BF16: arithmetic type of the MFMA operands (tensors in HBM are fp32 either way)
+    // batch-norm statistics from the epilogue (training-mode conv -> dropout -> BN): per (pixel tile, wave row) partial sums of
+    // (v - stat_shift[k]) and its square over the rows the wave owns, written to stat_ws[(part*2 + q)*K + k]; null: off
+    float* stat_ws;
+    const float* stat_shift;
 };
 
 __device__ __forceinline__ float bn_epilogue(const ConvArgs& a, float v, int m, int n) {
@@ -132,6 +136,59 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off) 
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
+
+// Epilogue of the forward / data-gradient kernels.  C/D layout of the 32x32 MFMAs: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// dropout (counter hash on the flat output index) -> optional BN statistics partials -> optional fused inference BN -> store
+// (plain rows, or scattered to a stride phase's pixels).  part = index of this wave's row block among all (pixel tile, wave row) pairs.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, TN>& acc, float* __restrict__ yout, int m0, int n0, int wm0,
+                                              int wn0, int lane, int part) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const bool scatter = a.o_s != 0 && a.nsplit == 1;                  // split partials stay row-major; the reduce kernel scatters them
+    const bool stats = a.stat_ws != nullptr;
+    float ssum[TN], ssq[TN], shift[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn0 + tn * 32 + l31;
+        ssum[tn] = 0.f;
+        ssq[tn] = 0.f;
+        shift[tn] = (stats && a.stat_shift && n < a.K) ? a.stat_shift[n] : 0.f;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn0 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < a.M && n < a.K) {
+                    float v = acc.v[tm][tn][r];
+                    const size_t idx = (size_t)m * a.K + n;
+                    if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                    if (stats) {
+                        const float d = v - shift[tn];
+                        ssum[tn] += d;
+                        ssq[tn] = fmaf(d, d, ssq[tn]);
+                    }
+                    if (a.ep_scale) v = bn_epilogue(a, v, m, n);
+                    yout[out_row(a, m, scatter) + n] = v;
+                }
+            }
+        }
+    if (stats) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const float s = ssum[tn] + __shfl_xor(ssum[tn], 32, 64);     // the two half-waves hold the same column, disjoint rows
+            const float q = ssq[tn] + __shfl_xor(ssq[tn], 32, 64);
+            const int n = n0 + wn0 + tn * 32 + l31;
+            if (h == 0 && n < a.K) {
+                a.stat_ws[((size_t)part * 2 + 0) * a.K + n] = s;
+                a.stat_ws[((size_t)part * 2 + 1) * a.K + n] = q;
+            }
+        }
+    }
+}
 
 constexpr unsigned OOB2 = 0x80000000u;     // host guarantees both tensors are < 2 GiB on this path
 

@@ -338,29 +338,49 @@ struct Frag {
     }
 };
 #define PNP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// Slices 1..3 of a stage: the fragment reads of the NEXT slice and the MFMAs of THIS slice are independent (two Frag sets).
-// PNP_CONV_ILV = 0: all reads are issued in front of the MFMAs (the matrix pipe drains while 6..16 ds_reads issue);
-// PNP_CONV_ILV = 1: NDS reads ride behind each MFMA (a 32x32x2 fp32 MFMA occupies the pipe for 64 cycles = 16 issue slots).
+// Schedule of slices 1..3 of a stage (two Frag sets: the fragment reads of the NEXT slice and the MFMAs of THIS slice are independent).
+// PNP_CONV_ILV selects where the next stage's LDS stores go (compile-time; measured A/B/A/B on the 512-channel layers at B=16):
+//   0  after the last slice's MFMAs (round 1)
+//   1  as 0, with the fragment reads of slices 2 / 3 interleaved behind single MFMAs instead of in front of them: no change
+//   2  behind the second half of the last slice's MFMAs: 512->512 forward +2.4 %, g10 forward +3.2 % / wgrad +4.6 %, segmenter step
+//      422 -> 434 slices/s, joint GAN step 147.4 -> 151.1 — the stores (and the vmcnt wait in front of them) left the exposed chain
+//      [last MFMA -> stores -> barrier -> first fragment reads -> first MFMA] that the co-resident workgroup has to cover
+//   3  behind the first half of the last slice;  4  behind the second half of slice 2 (loads are issued under slice 0)
 #ifndef PNP_CONV_ILV
-#define PNP_CONV_ILV 0
+#define PNP_CONV_ILV 2
 #endif
-// last slice + the next stage's LDS stores.  PNP_CONV_ILV = 2: the stores ride behind the second half of the slice's MFMAs instead of
-// after them (the global loads they wait for were issued three slices earlier)
+#define PNP_STORE_BEHIND(MMA, STORE, NMFMA, LEAD)                           \
+    MMA;                                                                    \
+    STORE;                                                                  \
+    if ((LEAD) > 0) __builtin_amdgcn_sched_group_barrier(0x008, (LEAD), 0); \
+    _Pragma("unroll") for (int i_ = 0; i_ < (NMFMA) / 2; ++i_) {            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                  \
+    }                                                                       \
+    PNP_SCHED_FENCE();
+// last slice (+ the next stage's LDS stores unless they already went behind slice 2)
 #define PNP_LAST_SLICE(MMA, STORE, NMFMA)                                   \
     if constexpr (PNP_CONV_ILV == 2) {                                      \
+        PNP_STORE_BEHIND(MMA, STORE, NMFMA, (NMFMA) / 2)                    \
+    } else if constexpr (PNP_CONV_ILV == 3) {                               \
+        PNP_STORE_BEHIND(MMA, STORE, NMFMA, 0)                              \
+    } else if constexpr (PNP_CONV_ILV == 4) {                               \
         MMA;                                                                \
-        STORE;                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x008, (NMFMA) / 2, 0);        \
-        _Pragma("unroll") for (int i_ = 0; i_ < (NMFMA) / 2; ++i_) {        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);              \
-        }                                                                   \
         PNP_SCHED_FENCE();                                                  \
     } else {                                                                \
         MMA;                                                                \
         PNP_SCHED_FENCE();                                                  \
         STORE;                                                              \
         PNP_SCHED_FENCE();                                                  \
+    }
+// slice 2 (variant 4 carries the stores here)
+#define PNP_SLICE2(LOAD, MMA, STORE, NMFMA, NDS)                            \
+    if constexpr (PNP_CONV_ILV == 4) {                                      \
+        LOAD;                                                               \
+        PNP_SCHED_FENCE();                                                  \
+        PNP_STORE_BEHIND(MMA, STORE, NMFMA, (NMFMA) / 2)                    \
+    } else {                                                                \
+        PNP_SLICE(LOAD, MMA, NMFMA, NDS)                                    \
     }
 #define PNP_SLICE(LOAD, MMA, NMFMA, NDS)                                   \
     if constexpr (PNP_CONV_ILV == 1) {                                      \
@@ -501,27 +521,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
         f0.load(An, Bn, 0, wm0, wn0, lane);
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int l31 = lane & 31, h = lane >> 5;
-    float* __restrict__ yout = a.y + (size_t)z * a.split_stride;     // split partials (z > 0 only for data gradients)
-    const bool scatter = a.o_s != 0 && a.nsplit == 1;                  // partials stay row-major; splitk_reduce scatters them
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn0 + tn * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < a.M && n < a.K) {
-                    float v = acc.v[tm][tn][r];
-                    const size_t idx = (size_t)m * a.K + n;
-                    if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-                    if (a.ep_scale) v = bn_epilogue(a, v, m, n);
-                    yout[out_row(a, m, scatter) + n] = v;
-                }
-            }
-        }
+    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN);
 }
 
 // ============ forward (any stride) / stride-1 data gradient, zero padding, C % 32 == 0, RxS filter: taps unrolled ============
@@ -651,33 +651,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
             }
             PNP_SCHED_FENCE();
             PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
-            PNP_SLICE(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
+            PNP_SLICE2(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), lstore(An, Bn), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
             PNP_LAST_SLICE(f1.mma(acc), lstore(An, Bn), 4 * TM * TN)
             __syncthreads();
             f0.load(An, Bn, 0, wm0, wn0, lane);
         }
     }
 
-    const int l31 = lane & 31, h = lane >> 5;
-    float* __restrict__ yout = a.y + (size_t)z * a.split_stride;
-    const bool scatter = a.o_s != 0 && a.nsplit == 1;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn0 + tn * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < a.M && n < a.K) {
-                    float v = acc.v[tm][tn][r];
-                    const size_t idx = (size_t)m * a.K + n;
-                    if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-                    if (a.ep_scale) v = bn_epilogue(a, v, m, n);
-                    yout[out_row(a, m, scatter) + n] = v;
-                }
-            }
-        }
+    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN);
 }
 
 // ===================================== wgrad kernel ============================================
@@ -753,7 +734,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
             }
             PNP_SCHED_FENCE();
             PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, (4 * TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
-            PNP_SLICE(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), 4 * TM * TN, (4 * TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
+            PNP_SLICE2(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), (la.store(An), lb.store(Bn)), 4 * TM * TN, (4 * TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
             // stores after the last MFMAs: gives the global loads a whole stage of latency cover (see conv_fwd_kernel)
             PNP_LAST_SLICE(f1.mma(acc), (la.store(An), lb.store(Bn)), 4 * TM * TN)
             __syncthreads();
@@ -1690,6 +1671,40 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
     float* split_ws = (workspace && workspace_bytes >= pnp_conv2d_fwd_workspace_bytes(g) && pnp_conv2d_fwd_workspace_bytes(g) > 0)
                           ? (float*)workspace : nullptr;
     return launch_fwd<0>(a, (hipStream_t)stream, split_ws);
+}
+
+// ---- forward convolution that also leaves the batch-norm statistics partials of its output (training-mode conv -> dropout -> BN) ----
+// Only on the MFMA kernels with an un-split reduction (the epilogue owns complete output rows there); 0 parts = not available for
+// this geometry (narrow-output vector-ALU kernels, reduction-split tiny layers): the caller runs pnp_bn_stats on the output instead.
+int32_t pnp_conv2d_fwd_stats_parts(const pnp_conv_geom* g) {
+    if (!g || check_geom(g, "pnp_conv2d_fwd_stats_parts") != PNP_OK) return 0;
+    if (narrow_fwd_ok(g, nullptr) || fwd_split(g) > 1) return 0;
+    const long long M = (long long)g->N * g->OH * g->OW;
+    const int tile = choose_tile(M, g->K);
+    return pnp_cdiv(M, 128) * ((tile == 0 || tile == 1) ? 2 : 4);        // pixel tiles x wave rows of the tile (WM)
+}
+
+int pnp_conv2d_fwd_stats(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
+                         uint32_t stream_id, const float* shift, float* parts, size_t parts_bytes, void* stream) {
+    if (int e = check_geom(g, "pnp_conv2d_fwd_stats")) return e;
+    PNP_REQUIRE(x && w && y && parts, "pnp_conv2d_fwd_stats: null pointer");
+    PNP_REQUIRE(keep_prob > 0.f, "pnp_conv2d_fwd_stats: keep_prob must be > 0");
+    const int nparts = pnp_conv2d_fwd_stats_parts(g);
+    PNP_REQUIRE(nparts > 0, "pnp_conv2d_fwd_stats: no epilogue statistics for this geometry (pnp_conv2d_fwd_stats_parts == 0)");
+    if (parts_bytes < (size_t)nparts * 2 * g->K * sizeof(float)) {
+        pnp_set_error("pnp_conv2d_fwd_stats: parts buffer too small (%zu < %zu)", parts_bytes, (size_t)nparts * 2 * g->K * sizeof(float));
+        return PNP_EWORKSPACE;
+    }
+    ConvArgs a = make_args(x, w, y, g);
+    if (keep_prob < 1.f) {
+        a.do_drop = 1;
+        a.drop_scale = 1.f / keep_prob;
+        a.drop_key = pnp_drop_key(seed, stream_id);
+        a.drop_thresh = pnp_drop_thresh(keep_prob);
+    }
+    a.stat_ws = parts;
+    a.stat_shift = shift;
+    return launch_fwd<0>(a, (hipStream_t)stream);
 }
 
 int pnp_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float* scale, float* shift, int32_t C,

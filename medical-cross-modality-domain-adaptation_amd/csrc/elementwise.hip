@@ -654,6 +654,16 @@ int pnp_bn_stats_update(const float* x, float* mean, float* var, float* moving_m
     return run_colreduce<0>(a, mean, var, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_stats_update", moving_mean, moving_var, decay);
 }
 
+int pnp_bn_stats_finish(const float* parts, int32_t nparts, const float* shift, float* mean, float* var, float* moving_mean,
+                        float* moving_var, int64_t P, int32_t C, float decay, void* stream) {
+    PNP_REQUIRE(parts && shift && mean && var && nparts > 0 && P > 0 && C > 0, "pnp_bn_stats_finish: bad argument");
+    PNP_REQUIRE((moving_mean != nullptr) == (moving_var != nullptr), "pnp_bn_stats_finish: moving_mean and moving_var go together");
+    hipLaunchKernelGGL(colreduce_final_kernel<0>, dim3(pnp_cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, parts, shift, mean, var, nparts, C,
+                       (long long)P, moving_mean, moving_var, decay);
+    PNP_CHECK_LAUNCH("pnp_bn_stats_finish");
+    return PNP_OK;
+}
+
 int pnp_bn_update_moving(float* moving_mean, float* moving_var, const float* mean, const float* var, int64_t P, int32_t C,
                          float decay, void* stream) {
     PNP_REQUIRE(moving_mean && moving_var && mean && var && P > 0 && C > 0, "pnp_bn_update_moving: bad argument");

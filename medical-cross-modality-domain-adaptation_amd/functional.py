@@ -21,6 +21,8 @@ LEAK = 0.2         # tf.nn.leaky_relu default alpha (layers.py:12,35,166,187)
 # inference-mode conv -> dropout -> BN -> shortcut -> activation in one kernel (pnp_conv2d_fwd_bn) whenever the BN parameters take no
 # gradient (monitoring forwards, frozen-BN forwards of the GAN steps, volume inference); False: separate kernels
 FUSE_BN_INFER = os.environ.get("PNP_FUSE_BN_INFER", "1") != "0"
+# training-mode BN statistics from the convolution's epilogue (pnp_conv2d_fwd_stats) instead of a reduction pass over its output
+FUSE_BN_STATS = os.environ.get("PNP_FUSE_BN_STATS", "1") != "0"
 
 
 def sync_now():
@@ -111,14 +113,22 @@ class ConvBNActFn(Function):
             ctx.P_norm = out.numel() // out.shape[-1]
             ctx.save_for_backward(x, w_, out, out, mean, var, gamma)     # the pre-BN tensor is never read in inference mode
             return out
-        xc = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
-        P = xc.numel() // xc.shape[-1]
+        P = geom.N * geom.OH * geom.OW
         ctx.P_norm = P
+        # training mode on the MFMA kernels: the convolution's epilogue leaves the statistics partials (no second pass over xc)
+        parts = None
+        if is_train and FUSE_BN_STATS and K.conv_stats_parts(geom) > 0:
+            xc, parts = K.conv2d_fwd_stats(x, w_, geom, moving_mean, keep_prob, seed, stream_id)
+        else:
+            xc = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
         if is_train:
             if sync:                  # opt-in SyncBN: statistics of the batch concatenated over the replicas
-                mean, var = par.sync_bn_stats(*K.bn_stats(xc))
+                local = K.bn_stats_finish(parts, moving_mean, P) if parts is not None else K.bn_stats(xc)
+                mean, var = par.sync_bn_stats(*local)
                 ctx.P_norm = P * par.sync_world()
                 K.bn_update_moving(moving_mean, moving_var, mean, var, ctx.P_norm, BN_DECAY)
+            elif parts is not None:
+                mean, var = K.bn_stats_finish(parts, moving_mean, P, moving_mean, moving_var, BN_DECAY)
             else:
                 mean, var = K.bn_stats_update(xc, moving_mean, moving_var, BN_DECAY)
             _bump_stat_version(moving_mean, moving_var)

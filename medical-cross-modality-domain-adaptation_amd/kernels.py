@@ -94,6 +94,33 @@ def conv2d_fwd(x, w, g, keep_prob=1.0, seed=0, stream_id=0, out=None, naive=Fals
     return y
 
 
+def conv_stats_parts(g):
+    """number of BN-statistics partial rows the forward of `g` can leave behind (0: not available, use bn_stats)"""
+    return int(_lib.load().pnp_conv2d_fwd_stats_parts(ctypes.byref(g)))
+
+
+def conv2d_fwd_stats(x, w, g, shift, keep_prob=1.0, seed=0, stream_id=0):
+    """forward conv (+dropout) that also writes the batch-norm statistics partials of its output -> (y, parts [nparts, 2, K])"""
+    lib = _lib.load()
+    nparts = conv_stats_parts(g)
+    y = torch.empty((g.N, g.OH, g.OW, g.K), dtype=torch.float32, device=x.device)
+    parts = workspace(nparts * 2 * g.K * 4, x.device, slot="stats")
+    check(lib.pnp_conv2d_fwd_stats(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _p(shift),
+                                   ctypes.c_void_p(parts.data_ptr()), parts.numel(), _stream()), "pnp_conv2d_fwd_stats")
+    return y, (parts, nparts)
+
+
+def bn_stats_finish(parts_n, shift, P, mm=None, mv=None, decay=0.9):
+    """(mean, biased var) from conv2d_fwd_stats' partials; with mm / mv also the moving-average update"""
+    parts, nparts = parts_n
+    C = shift.numel()
+    mean = torch.empty(C, dtype=torch.float32, device=shift.device)
+    var = torch.empty(C, dtype=torch.float32, device=shift.device)
+    check(_lib.load().pnp_bn_stats_finish(ctypes.c_void_p(parts.data_ptr()), int(nparts), _p(shift), _p(mean), _p(var), _p(mm), _p(mv), int(P), C,
+                                          float(decay), _stream()), "pnp_bn_stats_finish")
+    return mean, var
+
+
 def bn_fold(gamma, beta, mean, var, eps=1e-3):
     """inference-mode BN as per-channel (scale, shift)"""
     lib = _lib.load()

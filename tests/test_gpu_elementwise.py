@@ -176,3 +176,39 @@ def test_fused_conv_bn_inference_equals_separate_kernels(dev, case):
     out = F.ConvBNActFn.apply(x0, w0, gam, beta, mm.clone(), mv.clone(), None, g, 1.0, 0, 0, False, alpha)
     out.backward(dout)
     assert gam.grad is not None and float(gam.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("case", [(16, 32, 32, 256, 256, 3, 1, 1, 0.75), (2, 64, 64, 64, 64, 3, 1, 1, 1.0), (3, 37, 41, 96, 72, 3, 1, 1, 0.75),
+                                  (4, 128, 128, 64, 64, 3, 2, 1, 0.75), (2, 32, 32, 512, 512, 3, 1, 2, 0.75), (2, 256, 256, 32, 64, 3, 1, 1, 0.75)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_bn_statistics_from_the_conv_epilogue(dev, case):
+    """pnp_conv2d_fwd_stats + pnp_bn_stats_finish == pnp_conv2d_fwd + pnp_bn_stats (+ pnp_bn_update_moving): same output tensor bit
+    for bit, statistics to float32 round-off, with a non-trivial shift (the moving mean) and ragged tiles"""
+    K = pkg("kernels")
+    N, H, W, C, Kf, k, stride, dil, keep = case
+    rng = np.random.default_rng(sum(case[:6]))
+    x = torch.from_numpy(rng.standard_normal((N, H, W, C)).astype(np.float32) + 0.3).to(dev)
+    w = torch.from_numpy((rng.standard_normal((k, k, C, Kf)) * np.sqrt(2.0 / (k * k * C)) + 0.01).astype(np.float32)).to(dev)
+    g = K.conv_geom(tuple(x.shape), tuple(w.shape), stride, dil, "SAME")
+    assert K.conv_stats_parts(g) > 0
+    mm = torch.from_numpy((0.2 * rng.standard_normal(Kf)).astype(np.float32)).to(dev)
+    mv = torch.from_numpy((1.0 + 0.1 * rng.random(Kf)).astype(np.float32)).to(dev)
+    mm2, mv2 = mm.clone(), mv.clone()
+    y_ref = K.conv2d_fwd(x, w, g, keep, 5, 2)
+    mean_ref, var_ref = K.bn_stats_update(y_ref, mm2, mv2, 0.9)
+    y, parts = K.conv2d_fwd_stats(x, w, g, mm, keep, 5, 2)
+    P = y.numel() // Kf
+    mean, var = K.bn_stats_finish(parts, mm, P, mm, mv, 0.9)
+    assert torch.equal(y, y_ref)
+    y64 = y_ref.double().reshape(P, Kf)
+    m64, v64 = y64.mean(0), y64.var(0, unbiased=False)
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    print("epilogue stats %s: mean %.2e var %.2e (two-pass kernel: %.2e %.2e)" % (case, rel(mean, m64), rel(var, v64), rel(mean_ref, m64), rel(var_ref, v64)))
+    assert rel(mean, m64) < 2e-6 and rel(var, v64) < 1e-5
+    assert rel(mm, mm2.double()) < 1e-6 and rel(mv, mv2.double()) < 1e-5
+
+
+def test_no_epilogue_statistics_where_the_forward_is_not_on_the_mfma_tiles(dev):
+    K = pkg("kernels")
+    assert K.conv_stats_parts(K.conv_geom((16, 256, 256, 16), (3, 3, 16, 16), 1, 1, "SAME")) == 0       # narrow-output vector-ALU kernel
+    assert K.conv_stats_parts(K.conv_geom((16, 16, 16, 512), (5, 5, 512, 512), 4, 1, "SAME")) == 0      # reduction-split tiny layer
