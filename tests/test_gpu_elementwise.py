@@ -178,8 +178,8 @@ def test_fused_conv_bn_inference_equals_separate_kernels(dev, case):
     assert gam.grad is not None and float(gam.grad.abs().max()) > 0
 
 
-@pytest.mark.parametrize("case", [(16, 32, 32, 256, 256, 3, 1, 1, 0.75), (2, 64, 64, 64, 64, 3, 1, 1, 1.0), (3, 37, 41, 96, 72, 3, 1, 1, 0.75),
-                                  (4, 128, 128, 64, 64, 3, 2, 1, 0.75), (2, 32, 32, 512, 512, 3, 1, 2, 0.75), (2, 256, 256, 32, 64, 3, 1, 1, 0.75)],
+@pytest.mark.parametrize("case", [(16, 32, 32, 256, 256, 3, 1, 1, 0.75), (8, 64, 64, 64, 64, 3, 1, 1, 1.0), (13, 37, 41, 96, 72, 3, 1, 1, 0.75),
+                                  (8, 128, 128, 64, 64, 3, 2, 1, 0.75), (16, 32, 32, 512, 512, 3, 1, 2, 0.75), (2, 256, 256, 32, 64, 3, 1, 1, 0.75)],
                          ids=lambda c: "x".join(str(v) for v in c))
 def test_bn_statistics_from_the_conv_epilogue(dev, case):
     """pnp_conv2d_fwd_stats + pnp_bn_stats_finish == pnp_conv2d_fwd + pnp_bn_stats (+ pnp_bn_update_moving): same output tensor bit
@@ -212,3 +212,4 @@ def test_no_epilogue_statistics_where_the_forward_is_not_on_the_mfma_tiles(dev):
     K = pkg("kernels")
     assert K.conv_stats_parts(K.conv_geom((16, 256, 256, 16), (3, 3, 16, 16), 1, 1, "SAME")) == 0       # narrow-output vector-ALU kernel
     assert K.conv_stats_parts(K.conv_geom((16, 16, 16, 512), (5, 5, 512, 512), 4, 1, "SAME")) == 0      # reduction-split tiny layer
+    assert K.conv_stats_parts(K.conv_geom((2, 64, 64, 64), (3, 3, 64, 64), 1, 1, "SAME")) == 0          # few tiles at a small batch: split too
