@@ -18,7 +18,7 @@ import os
 import sys
 from collections import defaultdict
 
-NOTE = ("rocprofv3 PMC passes over `bench.py --steps 2 --warmup 1 --no-probe --no-cpu-baseline` (3 steps): pass 1 --pmc FETCH_SIZE, pass 2 --pmc "
+NOTE = ("rocprofv3 PMC passes over `bench.py --steps 2 --warmup 1 --no-probe --no-cpu-baseline --no-sub` (3 steps of the default workload: the joint segmenter+GAN step): pass 1 --pmc FETCH_SIZE, pass 2 --pmc "
         "WRITE_SIZE, pass 3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
         "SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES. KB units; gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by 2x "
         "(MI355X_MICROARCH.md, HBM section) -> read bytes = 2*FETCH_SIZE*1024 (calibrated on bn_bwd_apply / colreduce, whose traffic is known "
