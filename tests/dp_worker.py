@@ -30,12 +30,15 @@ for k in sd:
         s = sd[k].shape
         sd[k] = (sd[k] * (np.sqrt(2.0 / (s[0] * s[1] * s[2])) / 0.01)).astype(np.float32)
 net.store.load_state_dict(sd)
+sd0 = net.store.state_dict()      # incl. the BN moving averages: a training-mode forward moves them, and the epilogue statistics are
+                                  # accumulated around the moving mean, so "same gradients" means "from the same state"
 rng = np.random.default_rng(10 + rank)
 x = torch.from_numpy(rng.standard_normal((B, 256, 256, 3)).astype(np.float32)).to(dev)
 lab = rng.integers(0, 5, size=(B, 256, 256))
 y = torch.from_numpy(np.eye(5, dtype=np.float32)[lab]).to(dev)
 
 # reference: local gradients, then one plain all-reduce
+net.store.load_state_dict(sd0)
 net.loss_and_grads(x, y, 0.75, drop_seed=5 + rank)
 ref = net.store.grad_arena.clone()
 if NATIVE:
@@ -47,6 +50,7 @@ torch.cuda.synchronize()
 red = par.GradReducer(net.store, bucket_bytes=16 << 20, overlap=True)
 assert red.overlap and len(red.buckets) >= 5 and (red.native is not None) == NATIVE
 for it in range(2):                       # twice: the hook counters must re-arm
+    net.store.load_state_dict(sd0)
     net.loss_and_grads(x, y, 0.75, drop_seed=5 + rank)
     red.allreduce()
     torch.cuda.synchronize()

@@ -11,7 +11,7 @@ python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16_n1.json 2>/dev/nu
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub"
 rocprofv3 --kernel-trace --stats -d $O/prof_joint -o joint -- $B > $O/bench_prof_joint.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $O/prof_seg -o seg -- $B --workload segmenter > $O/bench_prof_seg.json 2>/dev/null
-rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o bf16 -- $B --dtype bf16 > $O/bench_prof_bf16.json 2>/dev/null
+[ -z "$FAST" ] && rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o bf16 -- $B --dtype bf16 > $O/bench_prof_bf16.json 2>/dev/null
 for w in joint seg bf16; do python tools/rocpd_summary.py $(find $O/prof_$w -name "*.db" | head -1) $O/${w}_kernel_stats.txt > /dev/null 2>&1; done
 head -12 $O/joint_kernel_stats.txt | cut -c1-170
 # PMC passes, each on its own (never together with other trace domains)
@@ -31,8 +31,10 @@ python tools/pmc_raw.py $O/pmc_seg_sq $O/pmc_seg_insts $O/pmc_seg_insts2 > $O/pm
 python tools/bench_conv.py > $O/conv_layers_f32.txt 2>/dev/null
 DTYPE=bf16 python tools/bench_conv.py > $O/conv_layers_bf16.txt 2>/dev/null
 # A/B: BN statistics from the conv epilogue vs the reduction pass
+if [ -z "$FAST" ]; then
 for i in 1 2; do for f in 1 0; do PNP_FUSE_BN_STATS=$f python bench.py --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FUSE_BN_STATS=$f', r['value'], r['ms_per_step'], r['segmenter_step']['value'])" >> $O/ab_bn_stats.txt; done; done; cat $O/ab_bn_stats.txt
 python tools/e2e_segmenter.py 2>&1 | grep "E2E" > $O/e2e.txt; cat $O/e2e.txt
+fi
 rm -rf $O/prof_joint $O/prof_seg $O/prof_bf16     # the sqlite traces are large; the summaries stay
 ls $O
