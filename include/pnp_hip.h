@@ -147,8 +147,9 @@ int pnp_bn_stats(const float* x, float* mean, float* var, int64_t P, int32_t C,
 int pnp_bn_stats_update(const float* x, float* mean, float* var, float* moving_mean, float* moving_var, int64_t P, int32_t C,
                         float decay, void* workspace, size_t workspace_bytes, void* stream);
 /* mean / biased variance from the partials of pnp_conv2d_fwd_stats (same shift), optionally followed by the moving-average update
- * (moving_mean / moving_var nullable together; shift may alias moving_mean) */
-int pnp_bn_stats_finish(const float* parts, int32_t nparts, const float* shift, float* mean, float* var,
+ * (moving_mean / moving_var nullable together; shift may alias moving_mean).  `parts` is CONSUMED: long lists (>= 512 partials) are
+ * first compacted in place by many workgroups (double sums written back as float high/low pairs), then combined. */
+int pnp_bn_stats_finish(float* parts, int32_t nparts, const float* shift, float* mean, float* var,
                         float* moving_mean, float* moving_var, int64_t P, int32_t C, float decay, void* stream);
 /* moving_mean -= (1-decay)*(moving_mean-mean); moving_var likewise with var*P/(P-1) (Bessel) */
 int pnp_bn_update_moving(float* moving_mean, float* moving_var, const float* mean, const float* var,

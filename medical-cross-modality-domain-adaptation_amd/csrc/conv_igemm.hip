@@ -757,6 +757,158 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
         }
 }
 
+// ---- filter gradient, linear pixel walk (MODE 3 geometry: stride 1, zero padding, OW >= 32, C % 4 == 0, K % 4 == 0), with a register
+// ring of DEPTH global-load stages.  Unlike the forward kernel (whose A rows are re-read for 9 taps and whose filters sit in L2), every
+// stage of the filter gradient fetches pixels nobody has touched before — all (tap, channel, filter) tiles of a pixel range walk it in
+// step, so the first toucher misses to HBM and the others wait on the same miss: the load latency of EVERY stage is an HBM round trip,
+// longer than the one stage (~64 MFMAs per wave) of cover conv_wgrad_kernel gives it.  Here stage j + DEPTH is requested while stage j
+// is contracted; the ring is indexed with compile-time constants only (loop unrolled by DEPTH), the tail is peeled.
+template <int BM, int BN, int WM, int WN, int DEPTH>
+__global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
+    constexpr int AC4 = BM / 4, ARP = NTHREADS / AC4, ANP = BK / ARP;
+    constexpr int BC4 = BN / 4, BRP = NTHREADS / BC4, BNP = BK / BRP;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nblk = a.nblk_m * a.nblk_n;
+    const int lid = a.xcd_swizzle ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int z = lid / nblk;
+    const int bid = lid - z * nblk;
+    int mt, nt;
+    tile_coords(bid, a.nblk_m, a.nblk_n, a.gn, mt, nt);
+    const int mm0 = mt * BM, n0 = nt * BN;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+    const int nchunks_total = (a.M + BK - 1) / BK;
+    const int c_begin = z * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    if (c_end > nchunks_total) c_end = nchunks_total;
+    const int nchunks = c_end - c_begin;
+
+    // A rows: output pixel p = stage*32 + arow + ARP*i, this thread's 4 consecutive m' (one tap, 4 channels), carried incrementally
+    const int acol = t % AC4, arow = t / AC4;
+    const int mm = mm0 + 4 * acol;
+    const bool mok = mm < a.Kred;
+    const int m_ = mok ? mm : 0;
+    const int rs_u = m_ / a.C, c_u = m_ - rs_u * a.C;
+    const int r_u = rs_u / a.S, s_u = rs_u - r_u * a.S;
+    const int l_dh = r_u * a.dil - a.pad_t, l_dw = s_u * a.dil - a.pad_l;
+    int l_ow[ANP], l_oh[ANP], l_off[ANP];
+#pragma unroll
+    for (int i = 0; i < ANP; ++i) {
+        const int p = c_begin * BK + arow + ARP * i;
+        const int n = p / a.OHW;
+        const int rem = p - n * a.OHW;
+        l_oh[i] = rem / a.OW;
+        l_ow[i] = rem - l_oh[i] * a.OW;
+        l_off[i] = (((n * a.H + l_oh[i] + l_dh) * a.W + l_ow[i] + l_dw) * a.C + c_u) * 4;
+    }
+    // B rows (dy): constant per-thread offset inside a stage, the stage is the scalar offset
+    const int bcol = t % BC4, brow = t / BC4;
+    unsigned boff[BNP];
+#pragma unroll
+    for (int i = 0; i < BNP; ++i) boff[i] = (n0 + 4 * bcol < a.K) ? (unsigned)(((brow + BRP * i) * a.K + n0 + 4 * bcol) * 4) : OOB2;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
+
+    // Fetches past this split's last stage (the ring runs DEPTH ahead) read the next split's rows, or zeros past the end of the tensors;
+    // those stages are never contracted.  Rows past the LAST pixel are zeros from the hardware (same argument as conv_wgrad_kernel MODE 3).
+    struct Stage {
+        f32x4 a[ANP];
+        f32x4 b[BNP];
+    };
+    Stage ring[DEPTH];
+    int l_chunk = c_begin;
+    auto gload = [&](Stage& st) {
+#pragma unroll
+        for (int i = 0; i < ANP; ++i) {
+            const bool ok = mok & ((unsigned)(l_oh[i] + l_dh) < (unsigned)a.H) & ((unsigned)(l_ow[i] + l_dw) < (unsigned)a.W);
+            st.a[i] = bload4(rx, ok ? (unsigned)l_off[i] : OOB);
+            l_ow[i] += BK;
+            l_off[i] += BK * a.C * 4;
+            const bool ww = l_ow[i] >= a.OW;                    // at most one wrap per step because OW >= 32
+            l_ow[i] -= ww ? a.OW : 0;
+            l_oh[i] += ww ? 1 : 0;
+            l_off[i] += ww ? (a.W - a.OW) * a.C * 4 : 0;
+            const bool hw = l_oh[i] >= a.OH;
+            l_oh[i] -= hw ? a.OH : 0;
+            l_off[i] += hw ? (a.H - a.OH) * a.W * a.C * 4 : 0;
+        }
+        const int soff = l_chunk * BK * a.K * 4;
+#pragma unroll
+        for (int i = 0; i < BNP; ++i) st.b[i] = bload4s(rw, boff[i], soff);
+        l_chunk = min(l_chunk + 1, nchunks_total);              // rows past the end of dy read as zeros
+    };
+    auto lstore = [&](const Stage& st, float* An, float* Bn) {
+#pragma unroll
+        for (int i = 0; i < ANP; ++i) *reinterpret_cast<f32x4*>(An + (arow + ARP * i) * LDA + 4 * acol) = st.a[i];
+#pragma unroll
+        for (int i = 0; i < BNP; ++i) *reinterpret_cast<f32x4*>(Bn + (brow + BRP * i) * LDB + 4 * bcol) = st.b[i];
+    };
+
+    Acc<TM, TN> acc;
+    acc.zero();
+    if (nchunks > 0) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) gload(ring[d]);
+        lstore(ring[0], lds, lds + 2 * ASZ);
+        __syncthreads();
+        Frag<TM, TN, false, LDA, LDB> f0, f1;
+        f0.load(lds, lds + 2 * ASZ, 0, wm0, wn0, lane);
+        constexpr int NDS = (4 * TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN);
+        auto stage = [&](int j, Stage& fetch_into, const Stage& store_from, bool fetch) {
+            const int cur = j & 1;
+            const float* As = lds + cur * ASZ;
+            const float* Bs = lds + 2 * ASZ + cur * BSZ;
+            float* An = lds + (cur ^ 1) * ASZ;
+            float* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
+            f1.load(As, Bs, 1, wm0, wn0, lane);
+            if (fetch) gload(fetch_into);
+            f0.mma(acc);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * TM + 4 * TN, 0);      // slice-1 fragment reads first
+#pragma unroll
+            for (int i = 0; i < 4 * TM * TN; ++i) {                                // then address arithmetic + loads under the MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            PNP_SCHED_FENCE();
+            PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, NDS)
+            PNP_SLICE2(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), lstore(store_from, An, Bn), 4 * TM * TN, NDS)
+            PNP_LAST_SLICE(f1.mma(acc), lstore(store_from, An, Bn), 4 * TM * TN)
+            __syncthreads();
+            f0.load(An, Bn, 0, wm0, wn0, lane);
+        };
+        const int nmain = (nchunks / DEPTH) * DEPTH;
+        for (int j0 = 0; j0 < nmain; j0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) stage(j0 + d, ring[d], ring[(d + 1) % DEPTH], true);
+        }
+        static_assert(DEPTH >= 1 && DEPTH <= 3, "tail below is written for rings of up to three");
+        if (DEPTH >= 2 && nchunks - nmain >= 1) stage(nmain, ring[0], ring[1 % DEPTH], false);
+        if (DEPTH >= 3 && nchunks - nmain >= 2) stage(nmain + 1, ring[1 % DEPTH], ring[2 % DEPTH], false);
+    }
+
+    float* out = a.y + (size_t)z * a.split_stride;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn0 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < a.Kred && n < a.K) out[(size_t)m * a.K + n] = acc.v[tm][tn][r];
+            }
+        }
+}
+
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nsplit,
                                      size_t stride) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1438,6 +1590,12 @@ int wgrad_plan_split(int nblk, int nchunks) {
     return best;
 }
 
+// global-load stages in flight in the linear filter-gradient kernel (conv_wgrad_ring_kernel); measured at B=16, see DESIGN.md §4.1
+int wgrad_ring_depth() {
+    static const int d = getenv("PNP_WGRAD_DEPTH") ? atoi(getenv("PNP_WGRAD_DEPTH")) : 2;
+    return d < 1 ? 1 : (d > 3 ? 3 : d);
+}
+
 template <int BM, int BN, int WM, int WN, bool VECB>
 int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStream_t st) {
     a.nblk_m = pnp_cdiv(a.Kred, BM);
@@ -1462,6 +1620,14 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     if (lin && VECB && a.dtype == PNP_DTYPE_BF16) {
         const bool launched = launch_wgrad_bf16(a, BN == 128 ? 0 : (BN == 64 ? 1 : 2), grid, st);
         PNP_REQUIRE(launched, "conv_wgrad_bf16_kernel: no instance for a %dx%d tile", BM, BN);
+    } else if (lin && VECB && wgrad_ring_depth() > 1) {
+        // linear pixel walk with DEPTH global-load stages in flight (PNP_WGRAD_DEPTH = 1: conv_wgrad_kernel MODE 3, one stage in flight)
+        const int depth = wgrad_ring_depth();
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "conv_wgrad_ring_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, depth);
+        if constexpr (VECB) {
+            if (depth == 2) hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 2>), grid, dim3(NTHREADS), 0, st, a);
+            else hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 3>), grid, dim3(NTHREADS), 0, st, a);
+        }
     } else {
         const int kmode = lin ? 3 : ((a.C % 4 == 0) ? 1 : 2);
         PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "conv_wgrad_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, WM, WN,

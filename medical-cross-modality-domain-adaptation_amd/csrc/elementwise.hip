@@ -139,11 +139,49 @@ __global__ void colreduce_scalar_kernel(ColArgs a) {
     a.ws[((size_t)blockIdx.x * 2 + 1) * a.C + c] = s1;
 }
 
+// Long partial lists (the convolution epilogue leaves one partial per 64 output rows: 16 384 of them for a 64-channel layer at 256^2,
+// which the C/32 = 2 workgroups of the final kernel walked alone: 240 us) are first compacted IN PLACE by (C/32) x nslab workgroups:
+// slab s = partials [s*SLAB, (s+1)*SLAB) (the last slab takes the remainder) is summed in double and written back over its own first two
+// partials as a (high, low) pair of floats, which together carry the double sum to 48 bits.  Only this workgroup ever reads those two
+// rows of its 32 channels, so there is no race; the summation order is fixed => deterministic.  The partial list is consumed.
+constexpr int COLRED_SLAB = 128;
+__global__ void __launch_bounds__(1024) colreduce_compact_kernel(float* __restrict__ ws, int nblk, int nslab, int C) {
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int s = blockIdx.y;
+    const int b0 = s * COLRED_SLAB;
+    const int b1 = (s == nslab - 1) ? nblk : b0 + COLRED_SLAB;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < C) {
+        for (int b = b0 + sl; b < b1; b += 32) {
+            s0 += (double)ws[((size_t)b * 2 + 0) * C + c];
+            s1 += (double)ws[((size_t)b * 2 + 1) * C + c];
+        }
+    }
+    red[0][sl][cl] = s0;
+    red[1][sl][cl] = s1;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    s0 = 0.0;
+    s1 = 0.0;
+    for (int j = 0; j < 32; ++j) {
+        s0 += red[0][j][cl];
+        s1 += red[1][j][cl];
+    }
+    const float h0 = (float)s0, h1 = (float)s1;
+    ws[((size_t)b0 * 2 + 0) * C + c] = h0;
+    ws[((size_t)b0 * 2 + 1) * C + c] = h1;
+    ws[((size_t)(b0 + 1) * 2 + 0) * C + c] = (float)(s0 - (double)h0);
+    ws[((size_t)(b0 + 1) * 2 + 1) * C + c] = (float)(s1 - (double)h1);
+}
+
 // final combine over blocks in double. KIND 0 -> mean,var ; KIND 1 -> dbeta (o0), dgamma (o1)
+// slab > 0: the list was compacted; entry b is partial (b >> 1) * slab + (b & 1)
 template <int KIND>
 __global__ void __launch_bounds__(1024) colreduce_final_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
                                                                float* o0, float* o1, int nblk, int C, long long P, float* mm, float* mv,
-                                                               float decay) {
+                                                               float decay, int slab) {
     // 1024 threads = 32 channels x 32 slices of the block list; fixed summation order => deterministic
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -151,8 +189,9 @@ __global__ void __launch_bounds__(1024) colreduce_final_kernel(const float* __re
     double s0 = 0.0, s1 = 0.0;
     if (c < C) {
         for (int b = sl; b < nblk; b += 32) {
-            s0 += (double)ws[((size_t)b * 2 + 0) * C + c];
-            s1 += (double)ws[((size_t)b * 2 + 1) * C + c];
+            const int row = slab > 0 ? (b >> 1) * slab + (b & 1) : b;
+            s0 += (double)ws[((size_t)row * 2 + 0) * C + c];
+            s1 += (double)ws[((size_t)row * 2 + 1) * C + c];
         }
     }
     red[0][sl][cl] = s0;
@@ -183,6 +222,25 @@ __global__ void __launch_bounds__(1024) colreduce_final_kernel(const float* __re
         o0[c] = (float)s0;
         o1[c] = (float)s1;
     }
+}
+
+// the final combine, in two launches when the list is long (>= 4 slabs)
+template <int KIND>
+int launch_colreduce_final(float* ws, const float* x0, float* o0, float* o1, int nblk, int C, long long P, float* mm, float* mv, float decay,
+                           hipStream_t st, const char* who) {
+    static const int two_stage = getenv("PNP_BN_FINAL_1STAGE") ? 0 : 1;
+    int slab = 0, n = nblk;
+    if (two_stage && nblk >= 4 * COLRED_SLAB) {
+        const int nslab = nblk / COLRED_SLAB;
+        hipLaunchKernelGGL(colreduce_compact_kernel, dim3(pnp_cdiv(C, 32), nslab), dim3(1024), 0, st, ws, nblk, nslab, C);
+        PNP_CHECK_LAUNCH(who);
+        slab = COLRED_SLAB;
+        n = 2 * nslab;
+    }
+    hipLaunchKernelGGL(colreduce_final_kernel<KIND>, dim3(pnp_cdiv(C, 32)), dim3(1024), 0, st, (const float*)ws, x0, o0, o1, n, C, P, mm, mv,
+                       decay, slab);
+    PNP_CHECK_LAUNCH(who);
+    return PNP_OK;
 }
 
 int colreduce_plan(long long P, int C, int* nblk, int* rpb) {
@@ -217,10 +275,7 @@ int run_colreduce(ColArgs a, float* o0, float* o1, void* ws, size_t ws_bytes, hi
         hipLaunchKernelGGL(colreduce_scalar_kernel<KIND>, dim3(nblk, pnp_cdiv(a.C, 64)), dim3(64), 0, st, a);
     }
     PNP_CHECK_LAUNCH(who);
-    hipLaunchKernelGGL(colreduce_final_kernel<KIND>, dim3(pnp_cdiv(a.C, 32)), dim3(1024), 0, st, (const float*)ws, a.x, o0,
-                       o1, nblk, a.C, a.P, mm, mv, decay);
-    PNP_CHECK_LAUNCH(who);
-    return PNP_OK;
+    return launch_colreduce_final<KIND>((float*)ws, a.x, o0, o1, nblk, a.C, a.P, mm, mv, decay, st, who);
 }
 
 __global__ void bn_update_moving_kernel(float* mm, float* mv, const float* mean, const float* var, long long P, int C,
@@ -654,14 +709,12 @@ int pnp_bn_stats_update(const float* x, float* mean, float* var, float* moving_m
     return run_colreduce<0>(a, mean, var, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_stats_update", moving_mean, moving_var, decay);
 }
 
-int pnp_bn_stats_finish(const float* parts, int32_t nparts, const float* shift, float* mean, float* var, float* moving_mean,
+int pnp_bn_stats_finish(float* parts, int32_t nparts, const float* shift, float* mean, float* var, float* moving_mean,
                         float* moving_var, int64_t P, int32_t C, float decay, void* stream) {
     PNP_REQUIRE(parts && shift && mean && var && nparts > 0 && P > 0 && C > 0, "pnp_bn_stats_finish: bad argument");
     PNP_REQUIRE((moving_mean != nullptr) == (moving_var != nullptr), "pnp_bn_stats_finish: moving_mean and moving_var go together");
-    hipLaunchKernelGGL(colreduce_final_kernel<0>, dim3(pnp_cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, parts, shift, mean, var, nparts, C,
-                       (long long)P, moving_mean, moving_var, decay);
-    PNP_CHECK_LAUNCH("pnp_bn_stats_finish");
-    return PNP_OK;
+    return launch_colreduce_final<0>(parts, shift, mean, var, nparts, C, (long long)P, moving_mean, moving_var, decay, (hipStream_t)stream,
+                                     "pnp_bn_stats_finish");
 }
 
 int pnp_bn_update_moving(float* moving_mean, float* moving_var, const float* mean, const float* var, int64_t P, int32_t C,
