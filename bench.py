@@ -58,14 +58,17 @@ def one_hot(lab, ncls=5):
 
 
 def he_state(sd, seed=7):
-    """He-scaled weights (the reference's stddev=.01 init gives vanishing activations after 30 layers; either is "random init")"""
+    """He-scaled weights (the reference's stddev=.01 / .1 inits give vanishing / exploding activations after 30 layers; either is
+    "random init").  Every filter is rescaled to std sqrt(2 / fan_in) from its OWN empirical std: the reference mixes
+    weight_variable(stddev=.01) and sharable_weight_variable(stddev=.1) (layers.py:47-55), and rescaling the latter as if it were the
+    former put 1e35 into the logits of the joint workload."""
     wr = np.random.default_rng(seed)
     for k in sd:
-        if "Variable" in k:
+        if "Variable" in k or np.ndim(sd[k]) == 4:
             s = sd[k].shape
-            if len(s) == 4 and "cls" not in k:      # segmenter conv filters: rescale the truncated-normal(0.01) init
-                sd[k] = (sd[k] * (np.sqrt(2.0 / (s[0] * s[1] * s[2])) / 0.01)).astype(np.float32)
-            else:                                   # critic convs / FC (stddev 0.1 shared variables): fresh He-normal draw
+            if len(s) == 4 and "cls" not in k:      # segmenter conv filters (truncated-normal draws of the store's own seed)
+                sd[k] = (sd[k] * (np.sqrt(2.0 / (s[0] * s[1] * s[2])) / max(float(np.std(sd[k])), 1e-12))).astype(np.float32)
+            else:                                   # critic convs / FC: fresh He-normal draw
                 sd[k] = (wr.standard_normal(s) * np.sqrt(2.0 / np.prod(s[:-1]))).astype(np.float32)
     return sd
 
@@ -252,6 +255,13 @@ def main():
                          train_config={"dis_sub_iter": 1, "gen_sub_iter": 1}, reducer=reducer)
         tr._get_optimizer()
         ct = torch.from_numpy((rng.standard_normal((B, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32)).to(dev)
+        # The phase starts from a trained segmenter whose BN moving statistics match its activations (train_gan.py restores the baseline
+        # checkpoint); the GAN steps run the segmenter's BN in inference mode.  Random filters with the initial (0, 1) statistics would
+        # leave those layers un-normalised (activations grow by sqrt(2) per residual block), so the statistics are calibrated first:
+        # training-mode forwards of both domains, untimed, until the moving averages (decay .9) have converged to the batch statistics.
+        with torch.no_grad():
+            for i in range(40):
+                net._graph(x, ct, 1.0, mr_front_bn=True, joint_bn=True, ct_front_bn=True, critics=False, drop_seed=1000 + i)
 
         def step(i):
             tr.dis_step(x, ct, 0.75, 2 * (i * world + rank) + 1)

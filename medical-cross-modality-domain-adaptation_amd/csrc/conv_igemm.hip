@@ -403,7 +403,7 @@ struct Frag {
 // zero-upsampled by `ups`).  0 and 1 run the same code; the distinct symbol lets rocprof separate forward from backward
 // launches.  Only KIND 2 carries the integer division of the upsampling test.
 template <int BM, int BN, int WM, int WN, int MODE, int KIND, bool VECB>
-__global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_fwd_body(ConvArgs a, const int blk) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BK + 4, LDB = BN + 4;
     constexpr int ASZ = BM * LDA, BSZ = BK * LDB;
@@ -414,15 +414,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
     // start with persists; dispatched together they stay aligned and the matrix pipe idles whenever both are in the non-MFMA part of
     // a stage (barrier, first fragment reads, LDS stores).  Starting every second dispatch wave late by about that part's length
     // de-phases them for the whole kernel.  (Speed only: nothing depends on which workgroups share a CU.)
-    if (a.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+    if (a.stagger > 0 && ((blk >> 8) & 1)) {
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     }
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nblk = a.nblk_m * a.nblk_n;
-    const int z = blockIdx.x / nblk;               // reduction split (data gradients only; a.nsplit == 1 otherwise)
-    int bid = blockIdx.x - z * nblk;
+    const int z = blk / nblk;                      // reduction split (data gradients only; a.nsplit == 1 otherwise)
+    int bid = blk - z * nblk;
     if (a.xcd_swizzle) bid = xcd_remap(bid, nblk);
     int mt, nt;
     tile_coords(bid, a.nblk_m, a.nblk_n, a.gn, mt, nt);
@@ -522,6 +522,46 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
     }
 
     conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN);
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int KIND, bool VECB>
+__global__ void __launch_bounds__(NTHREADS, 2) conv_fwd_kernel(ConvArgs a) {
+    conv_fwd_body<BM, BN, WM, WN, MODE, KIND, VECB>(a, (int)blockIdx.x);
+}
+
+// ---- all stride phases of a strided data gradient in ONE launch (small feature maps) -------------------------------------------------
+// A k5 s4 critic layer on a 16^2 -> 4^2 map has 16 phases of 256 GEMM rows each: one launch per phase (16 workgroups, reduction split
+// 32 ways, + a scatter-reduce) cost 16 x (17 + 4.5) us for 3.4 GFLOP.  Here the workgroups of all phases share one grid; a workgroup
+// looks up its phase (sub-filter extent / padding / output lattice / filter block) in the kernel arguments and runs the general
+// C % 32 == 0 stage loop, writing its rows straight to the phase's pixels (no reduction split, no second kernel).
+struct PhaseDesc {
+    int w_off;              // float offset of the phase's flipped sub-filter [T][U][K][C]
+    int R, S, OH, OW, pad_t, pad_l, o_h0, o_w0;
+    int first_blk, nblk_m;
+};
+struct GroupArgs {
+    ConvArgs base;          // everything the phases share (x = dy, y = dx, H/W = dy's extent, C, K, output lattice o_s/o_H/o_W, tiles in N)
+    PhaseDesc ph[16];
+    int nph;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(NTHREADS, 2) conv_dgrad_phases_kernel(GroupArgs g) {
+    int p = 0;
+    for (int i = 1; i < g.nph; ++i) p = ((int)blockIdx.x >= g.ph[i].first_blk) ? i : p;
+    const PhaseDesc d = g.ph[p];
+    ConvArgs a = g.base;
+    a.w = g.base.w + d.w_off;
+    a.R = d.R; a.S = d.S; a.OH = d.OH; a.OW = d.OW; a.pad_t = d.pad_t; a.pad_l = d.pad_l;
+    a.o_h0 = d.o_h0; a.o_w0 = d.o_w0;
+    a.OHW = d.OH * d.OW;
+    a.M = a.N * a.OHW;
+    a.Kred = d.R * d.S * a.C;
+    a.w_bytes = (unsigned)(a.Kred * a.K) * 4u;
+    a.nblk_m = d.nblk_m;
+    a.nsplit = 1;
+    a.chunks_per_split = (a.Kred + BK - 1) / BK;
+    conv_fwd_body<BM, BN, WM, WN, 0, 1, true>(a, (int)blockIdx.x - d.first_blk);
 }
 
 // ============ forward (any stride) / stride-1 data gradient, zero padding, C % 32 == 0, RxS filter: taps unrolled ============
@@ -757,7 +797,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
         }
 }
 
-// ---- filter gradient, linear pixel walk (MODE 3 geometry: stride 1, zero padding, OW >= 32, C % 4 == 0, K % 4 == 0), with a register
+// ---- filter gradient, linear pixel walk (any stride, zero padding, OW >= 32, C % 4 == 0, K % 4 == 0), with a register
 // ring of DEPTH global-load stages.  Unlike the forward kernel (whose A rows are re-read for 9 taps and whose filters sit in L2), every
 // stage of the filter gradient fetches pixels nobody has touched before — all (tap, channel, filter) tiles of a pixel range walk it in
 // step, so the first toucher misses to HBM and the others wait on the same miss: the load latency of EVERY stage is an HBM round trip,
@@ -797,16 +837,23 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a
     const int m_ = mok ? mm : 0;
     const int rs_u = m_ / a.C, c_u = m_ - rs_u * a.C;
     const int r_u = rs_u / a.S, s_u = rs_u - r_u * a.S;
+    // input coordinates of (output pixel, this thread's tap): ih = oh*stride + l_dh, iw = ow*stride + l_dw; the row / image wraps of the
+    // OUTPUT walk are the compares ih >= ih_lim / iw >= iw_lim
     const int l_dh = r_u * a.dil - a.pad_t, l_dw = s_u * a.dil - a.pad_l;
-    int l_ow[ANP], l_oh[ANP], l_off[ANP];
+    const int iw_lim = a.OW * a.stride + l_dw, ih_lim = a.OH * a.stride + l_dh;
+    const int step_w = BK * a.stride, step_off = BK * a.stride * a.C * 4;
+    const int wrap_w = a.OW * a.stride, wrap_w_off = a.stride * (a.W - a.OW) * a.C * 4;
+    const int wrap_h = a.OH * a.stride, wrap_h_off = (a.H - a.OH * a.stride) * a.W * a.C * 4;
+    int l_iw[ANP], l_ih[ANP], l_off[ANP];
 #pragma unroll
     for (int i = 0; i < ANP; ++i) {
         const int p = c_begin * BK + arow + ARP * i;
         const int n = p / a.OHW;
         const int rem = p - n * a.OHW;
-        l_oh[i] = rem / a.OW;
-        l_ow[i] = rem - l_oh[i] * a.OW;
-        l_off[i] = (((n * a.H + l_oh[i] + l_dh) * a.W + l_ow[i] + l_dw) * a.C + c_u) * 4;
+        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        l_ih[i] = oh * a.stride + l_dh;
+        l_iw[i] = ow * a.stride + l_dw;
+        l_off[i] = (((n * a.H + l_ih[i]) * a.W + l_iw[i]) * a.C + c_u) * 4;
     }
     // B rows (dy): constant per-thread offset inside a stage, the stage is the scalar offset
     const int bcol = t % BC4, brow = t / BC4;
@@ -827,17 +874,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a
     auto gload = [&](Stage& st) {
 #pragma unroll
         for (int i = 0; i < ANP; ++i) {
-            const bool ok = mok & ((unsigned)(l_oh[i] + l_dh) < (unsigned)a.H) & ((unsigned)(l_ow[i] + l_dw) < (unsigned)a.W);
+            const bool ok = mok & ((unsigned)l_ih[i] < (unsigned)a.H) & ((unsigned)l_iw[i] < (unsigned)a.W);
             st.a[i] = bload4(rx, ok ? (unsigned)l_off[i] : OOB);
-            l_ow[i] += BK;
-            l_off[i] += BK * a.C * 4;
-            const bool ww = l_ow[i] >= a.OW;                    // at most one wrap per step because OW >= 32
-            l_ow[i] -= ww ? a.OW : 0;
-            l_oh[i] += ww ? 1 : 0;
-            l_off[i] += ww ? (a.W - a.OW) * a.C * 4 : 0;
-            const bool hw = l_oh[i] >= a.OH;
-            l_oh[i] -= hw ? a.OH : 0;
-            l_off[i] += hw ? (a.H - a.OH) * a.W * a.C * 4 : 0;
+            l_iw[i] += step_w;
+            l_off[i] += step_off;
+            const bool ww = l_iw[i] >= iw_lim;                  // at most one wrap per step because OW >= 32
+            l_iw[i] -= ww ? wrap_w : 0;
+            l_ih[i] += ww ? a.stride : 0;
+            l_off[i] += ww ? wrap_w_off : 0;
+            const bool hw = l_ih[i] >= ih_lim;
+            l_ih[i] -= hw ? wrap_h : 0;
+            l_off[i] += hw ? wrap_h_off : 0;
         }
         const int soff = l_chunk * BK * a.K * 4;
 #pragma unroll
@@ -1615,12 +1662,13 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     a.y = (nsplit > 1) ? ws : dw;
     dim3 grid((unsigned)(nblk * nsplit));
     static const int env_nolin = getenv("PNP_CONV_NOLIN") ? 1 : 0;
-    const bool lin = !env_nolin && a.stride == 1 && a.pad_mode == PNP_PAD_ZERO && (a.C % 4) == 0 && a.OW >= BK &&
-                     a.x_bytes < 0x80000000u && a.w_bytes < 0x80000000u;
+    const bool lin_any = !env_nolin && a.pad_mode == PNP_PAD_ZERO && (a.C % 4) == 0 && a.OW >= BK && a.x_bytes < 0x80000000u &&
+                         a.w_bytes < 0x80000000u;                  // conv_wgrad_ring_kernel walks strided outputs too
+    const bool lin = lin_any && a.stride == 1;
     if (lin && VECB && a.dtype == PNP_DTYPE_BF16) {
         const bool launched = launch_wgrad_bf16(a, BN == 128 ? 0 : (BN == 64 ? 1 : 2), grid, st);
         PNP_REQUIRE(launched, "conv_wgrad_bf16_kernel: no instance for a %dx%d tile", BM, BN);
-    } else if (lin && VECB && wgrad_ring_depth() > 1) {
+    } else if (lin_any && VECB && wgrad_ring_depth() > 1) {
         // linear pixel walk with DEPTH global-load stages in flight (PNP_WGRAD_DEPTH = 1: conv_wgrad_kernel MODE 3, one stage in flight)
         const int depth = wgrad_ring_depth();
         PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "conv_wgrad_ring_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, depth);
@@ -1795,6 +1843,56 @@ pnp_conv_geom phase_geom(const pnp_conv_geom* g, const DgradPhase& p) {
     return d;
 }
 
+// All phases in one launch (conv_dgrad_phases_kernel) when no single phase fills the chip: the phases' pixel tiles x 64-wide channel
+// tiles together stay under one dispatch round (512 slots).  Needs the general kernel's fast mode (K % 32 == 0 channels of dy) and
+// float4 filter rows (C % 4 == 0).
+int phase_group_tiles(const pnp_conv_geom* g, const DgradPhase* ph, int nph, int bn) {
+    int tiles = 0;
+    for (int i = 0; i < nph; ++i)
+        if (ph[i].I > 0 && ph[i].J > 0) tiles += pnp_cdiv((long long)g->N * ph[i].I * ph[i].J, 128) * pnp_cdiv(g->C, bn);
+    return tiles;
+}
+bool phases_in_one_launch(const pnp_conv_geom* g, const DgradPhase* ph, int nph) {
+    static const int off = getenv("PNP_CONV_NOPHASEGROUP") ? 1 : 0;
+    if (off || nph < 2 || nph > 16 || (g->K % 32) != 0 || (g->C % 4) != 0 || g->C < 32) return false;
+    if ((size_t)g->N * g->OH * g->OW * g->K * sizeof(float) >= 0x80000000u) return false;
+    return phase_group_tiles(g, ph, nph, 64) <= 512;
+}
+
+int launch_phase_group(const float* dy, const float* wt, float* outp, const pnp_conv_geom* g, const DgradPhase* ph, int nph, int Ho, int Wo,
+                       hipStream_t st) {
+    GroupArgs ga{};
+    pnp_conv_geom d0 = phase_geom(g, ph[0]);
+    ga.base = make_args(dy, wt, outp, &d0);
+    ga.base.o_s = g->stride; ga.base.o_H = Ho; ga.base.o_W = Wo;
+    const bool narrow = phase_group_tiles(g, ph, nph, 64) < 256;          // more, narrower tiles when even 64-wide ones leave CUs idle
+    const int bn = narrow ? 32 : 64;
+    ga.base.nblk_n = pnp_cdiv(g->C, bn);
+    int blk = 0, n = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < nph; ++i) {
+        const DgradPhase& p = ph[i];
+        if (p.I == 0 || p.J == 0) continue;
+        PhaseDesc& q = ga.ph[n++];
+        q.w_off = (int)p.wt_off;
+        q.R = p.T; q.S = p.U; q.OH = p.I; q.OW = p.J; q.pad_t = p.pad_t; q.pad_l = p.pad_l; q.o_h0 = p.h0; q.o_w0 = p.w0;
+        q.first_blk = blk;
+        q.nblk_m = pnp_cdiv((long long)g->N * p.I * p.J, 128);
+        blk += q.nblk_m * ga.base.nblk_n;
+        const double rows = (double)g->N * p.I * p.J;
+        flops += 2.0 * rows * g->C * (double)(p.T * p.U * g->K);
+        bytes += 4.0 * (rows * g->C + (double)p.T * p.U * g->K * g->C);
+    }
+    ga.nph = n;
+    if (n == 0) return PNP_OK;
+    bytes += 4.0 * (double)g->N * g->OH * g->OW * g->K;
+    PnpProfScope ps(PNP_PROF_CONV_DGRAD, st, flops, bytes, "conv_dgrad_phases_kernel<128, %d, %d, %d>", bn, narrow ? 4 : 2, narrow ? 1 : 2);
+    if (narrow) hipLaunchKernelGGL((conv_dgrad_phases_kernel<128, 32, 4, 1>), dim3((unsigned)blk), dim3(NTHREADS), 0, st, ga);
+    else hipLaunchKernelGGL((conv_dgrad_phases_kernel<128, 64, 2, 2>), dim3((unsigned)blk), dim3(NTHREADS), 0, st, ga);
+    PNP_CHECK_LAUNCH("conv_dgrad_phases_kernel");
+    return PNP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1960,13 +2058,17 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
         dim3 tgp((unsigned)pnp_cdiv(g->K, 32), (unsigned)pnp_cdiv(g->C, 32), (unsigned)(g->R * g->S));
         hipLaunchKernelGGL(flip_transpose_phase_kernel, tgp, dim3(256), 0, st, w, wt, g->R, g->S, g->C, g->K, g->stride);
         PNP_CHECK_LAUNCH("flip_transpose_phase_kernel");
-        for (int i = 0; i < nph; ++i) {
-            const DgradPhase& p = ph[i];
-            if (p.I == 0 || p.J == 0) continue;
-            const pnp_conv_geom d = phase_geom(g, p);
-            ConvArgs a = make_args(dy, wt + p.wt_off, outp, &d);
-            a.o_s = g->stride; a.o_H = Ho; a.o_W = Wo; a.o_h0 = p.h0; a.o_w0 = p.w0;
-            if (int e = launch_fwd<1>(a, st, split_ws)) return e;
+        if (phases_in_one_launch(g, ph, nph)) {
+            if (int e = launch_phase_group(dy, wt, outp, g, ph, nph, Ho, Wo, st)) return e;
+        } else {
+            for (int i = 0; i < nph; ++i) {
+                const DgradPhase& p = ph[i];
+                if (p.I == 0 || p.J == 0) continue;
+                const pnp_conv_geom d = phase_geom(g, p);
+                ConvArgs a = make_args(dy, wt + p.wt_off, outp, &d);
+                a.o_s = g->stride; a.o_H = Ho; a.o_W = Wo; a.o_h0 = p.h0; a.o_w0 = p.w0;
+                if (int e = launch_fwd<1>(a, st, split_ws)) return e;
+            }
         }
         if (symp) {
             const size_t total = (size_t)g->N * g->H * g->W * g->C;

@@ -172,8 +172,9 @@ __global__ void __launch_bounds__(1024) colreduce_compact_kernel(float* __restri
     const float h0 = (float)s0, h1 = (float)s1;
     ws[((size_t)b0 * 2 + 0) * C + c] = h0;
     ws[((size_t)b0 * 2 + 1) * C + c] = h1;
-    ws[((size_t)(b0 + 1) * 2 + 0) * C + c] = (float)(s0 - (double)h0);
-    ws[((size_t)(b0 + 1) * 2 + 1) * C + c] = (float)(s1 - (double)h1);
+    // (an overflowed sum stays +-inf like in the single-launch combine: inf - inf would turn it into NaN)
+    ws[((size_t)(b0 + 1) * 2 + 0) * C + c] = (fabsf(h0) <= 3.4e38f) ? (float)(s0 - (double)h0) : 0.f;
+    ws[((size_t)(b0 + 1) * 2 + 1) * C + c] = (fabsf(h1) <= 3.4e38f) ? (float)(s1 - (double)h1) : 0.f;
 }
 
 // final combine over blocks in double. KIND 0 -> mean,var ; KIND 1 -> dbeta (o0), dgamma (o1)

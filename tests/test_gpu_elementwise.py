@@ -79,6 +79,39 @@ def test_bn_stats_large_mean_is_stable(dev):
     assert np.abs(var.cpu().numpy() - x64.var(0)).max() < 1e-2 * x64.var(0).max()
 
 
+@pytest.mark.parametrize("P,C", [(16384, 64), (65536, 64), (300000, 32), (262144, 5), (1048576, 16), (40000, 512)],
+                         ids=lambda v: str(v))
+def test_bn_reductions_with_long_partial_lists(dev, P, C):
+    """pnp_bn_stats / pnp_bn_bwd_reduce at the row counts of the 64^2 ... 256^2 layers: 512+ workgroup partials are compacted in
+    place (double sums as float high/low pairs) before the final combine; both against float64 sums of the same tensors"""
+    K = pkg("kernels")
+    rng = np.random.default_rng(P % 1000 + C)
+    x = torch.from_numpy((rng.standard_normal((P, C)) * 1.3 + 0.4).astype(np.float32)).to(dev)
+    dout = torch.from_numpy(rng.standard_normal((P, C)).astype(np.float32)).to(dev)
+    x4, d4 = x.view(1, 1, P, C), dout.view(1, 1, P, C)
+    mean, var = K.bn_stats(x4)
+    x64 = x.double()
+    m64, v64 = x64.mean(0), x64.var(0, unbiased=False)
+    assert float((mean.double() - m64).abs().max()) < 1e-6 and float((var.double() - v64).abs().max()) < 1e-5
+    gamma = torch.ones(C, device=dev)
+    out = K.bn_apply(x4, mean, var, gamma, torch.zeros(C, device=dev), None, 1e-3, 0.2)
+    dx, dg, db, _ = K.bn_bwd(d4, out, x4, mean, var, gamma, 0, 1e-3, 0.2, True, 1.0, 0, 0)
+    g = torch.where(out.view(P, C) > 0, dout, dout * 0.2).double()
+    xh = (x64 - mean.double()) / torch.sqrt(var.double() + 1e-3)
+    db64, dg64 = g.sum(0), (g * xh).sum(0)
+    assert float((db.double() - db64).abs().max() / db64.abs().max()) < 2e-6
+    assert float((dg.double() - dg64).abs().max() / dg64.abs().max()) < 2e-6
+    assert bool(torch.isfinite(dx).all())
+
+
+def test_bn_statistics_of_an_overflowing_tensor_stay_infinite_not_nan(dev):
+    """a partial sum beyond float range must come out as inf (like the single-launch combine), never as inf - inf = NaN"""
+    K = pkg("kernels")
+    x = torch.full((1, 1, 65536, 32), 3e37, device=dev)
+    mean, var = K.bn_stats(x)
+    assert not bool(torch.isnan(mean).any())
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 16), (2, 8, 12, 32), (1, 4, 4, 6)])
 def test_maxpool(dev, shape):
     K = pkg("kernels")
