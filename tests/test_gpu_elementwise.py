@@ -107,9 +107,11 @@ def test_bn_reductions_with_long_partial_lists(dev, P, C):
 def test_bn_statistics_of_an_overflowing_tensor_stay_infinite_not_nan(dev):
     """a partial sum beyond float range must come out as inf (like the single-launch combine), never as inf - inf = NaN"""
     K = pkg("kernels")
-    x = torch.full((1, 1, 65536, 32), 3e37, device=dev)
+    x = torch.full((1, 1, 65536, 32), 1e25, device=dev)
+    x[0, 0, 0, :] = 0.0                 # the shift (first row): every other row contributes d = 1e25, d*d = inf in float32
     mean, var = K.bn_stats(x)
-    assert not bool(torch.isnan(mean).any())
+    assert bool(torch.isfinite(mean).all()) and abs(float(mean[0]) / 1e25 - 1.0) < 1e-3
+    assert bool(torch.isinf(var).all()) and not bool(torch.isnan(var).any())
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 16, 16), (2, 8, 12, 32), (1, 4, 4, 6)])
