@@ -122,11 +122,20 @@ int pnp_conv2d_fwd_bn(const float* x, const float* w, float* y, const pnp_conv_g
 size_t pnp_conv2d_dgrad_workspace_bytes(const pnp_conv_geom* g);
 int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_geom* g,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* dx = data gradient + residual (residual [N,H,W,C], not aliasing dx): the gradient that reaches the conv input a second way — the
+ * shortcut of layers.residual_block / DR_block (layers.py:145-189), where TF's autodiff emits an AddN.  Added in the epilogue of the
+ * stride-1 MFMA kernels; other geometries add it with one more pass. */
+int pnp_conv2d_dgrad_add(const float* dy, const float* w, const float* residual, float* dx, const pnp_conv_geom* g,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* gradient w.r.t. the filter (Conv2DBackpropFilter). dw [R,S,C,K] is overwritten. */
 size_t pnp_conv2d_wgrad_workspace_bytes(const pnp_conv_geom* g);
 int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_geom* g,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* dw += filter gradient: written straight into a gradient buffer that may already hold a contribution (filters shared by two
+ * passes, adversarial.py:196,235; TF's AddN of the per-use gradients) — no separate accumulation kernel */
+int pnp_conv2d_wgrad_acc(const float* x, const float* dy, float* dw, const pnp_conv_geom* g,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Naive one-thread-per-output direct convolution (fp32 fmaf chain in r,s,c order). On-device
  * cross-check for the MFMA kernels at sizes the CPU oracle cannot reach; not used by the product path. */
@@ -169,6 +178,14 @@ int pnp_bn_bwd(const float* dout, const float* out, const float* x, const float*
                int64_t P, int32_t C, float eps, float alpha, int32_t training,
                float keep_prob, uint64_t seed, uint32_t stream_id,
                void* workspace, size_t workspace_bytes, void* stream);
+/* Same, and the sums are ALSO added into dgamma_acc / dbeta_acc [C] (both or neither; e.g. the parameters' slots of a flat gradient
+ * arena that may already hold another use's contribution) — no separate accumulation kernel per parameter.  dgamma / dbeta still
+ * receive this call's own sums (the apply half needs them). */
+int pnp_bn_bwd_acc(const float* dout, const float* out, const float* x, const float* mean, const float* var,
+                   const float* gamma, float* dx, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc,
+                   float* dshortcut, int32_t Cs, int64_t P, int32_t C, float eps, float alpha, int32_t training,
+                   float keep_prob, uint64_t seed, uint32_t stream_id,
+                   void* workspace, size_t workspace_bytes, void* stream);
 /* The two halves of pnp_bn_bwd, for synchronised batch statistics under data parallelism: reduce the local
  * sums, all-reduce dgamma / dbeta across ranks (caller, RCCL), then apply with P_norm = the GLOBAL row count behind them.
  * pnp_bn_bwd == reduce followed by apply with P_norm = P. */

@@ -60,8 +60,10 @@ PROTOTYPES = {
     "pnp_conv2d_fwd": (c_int, [_F, _F, _F, _G, c_float, c_uint64, c_uint32, c_void_p]),
     "pnp_conv2d_dgrad_workspace_bytes": (c_size_t, [_G]),
     "pnp_conv2d_dgrad": (c_int, [_F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
+    "pnp_conv2d_dgrad_add": (c_int, [_F, _F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
     "pnp_conv2d_wgrad_workspace_bytes": (c_size_t, [_G]),
     "pnp_conv2d_wgrad": (c_int, [_F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
+    "pnp_conv2d_wgrad_acc": (c_int, [_F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
     "pnp_conv2d_fwd_workspace_bytes": (c_size_t, [_G]),
     "pnp_conv2d_fwd_ws": (c_int, [_F, _F, _F, _G, c_float, c_uint64, c_uint32, c_void_p, c_size_t, c_void_p]),
     "pnp_conv2d_fwd_stats_parts": (c_int32, [_G]),
@@ -78,6 +80,8 @@ PROTOTYPES = {
     "pnp_bn_apply": (c_int, [_F, _F, _F, _F, _F, _F, c_int32, _F, c_int64, c_int32, c_float, c_float, c_void_p]),
     "pnp_bn_bwd": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int32, c_float, c_float, c_int32,
                            c_float, c_uint64, c_uint32, c_void_p, c_size_t, c_void_p]),
+    "pnp_bn_bwd_acc": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int32, c_float, c_float, c_int32,
+                               c_float, c_uint64, c_uint32, c_void_p, c_size_t, c_void_p]),
     "pnp_bn_bwd_reduce": (c_int, [_F, _F, _F, _F, _F, _F, _F, c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "pnp_bn_bwd_apply": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int64, c_int32, c_float, c_float, c_int32,
                                  c_float, c_uint64, c_uint32, c_void_p]),

@@ -79,23 +79,6 @@ struct TransposedTile {
 };
 
 // filter-gradient tile -> dW rows (or a split partial)
-template <int TM, int TN>
-__device__ __forceinline__ void wgrad_epilogue(const ConvArgs& a, const Acc<TM, TN>& acc, float* __restrict__ out, int mm0, int n0, int wm0, int wn0,
-                                               int lane) {
-    const int l31 = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn0 + tn * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < a.Kred && n < a.K) out[(size_t)m * a.K + n] = acc.v[tm][tn][r];
-            }
-        }
-}
-
 // ======================= forward / stride-1 data gradient / stride-phase sub-filters (taps unrolled) ============================
 constexpr int DEPTH = 3;      // global-load stages in flight per workgroup (register ring)
 
@@ -233,7 +216,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_bf16_kernel(ConvArgs a)
     static_assert(DEPTH == 3, "tail below is written for a ring of three");
     if (nst - nmain >= 1) stage(nmain, ring[0], ring[1], false);
     if (nst - nmain >= 2) stage(nmain + 1, ring[1], ring[2], false);
-    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN);
+    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
 }
 
 // ===================================== filter gradient ============================================

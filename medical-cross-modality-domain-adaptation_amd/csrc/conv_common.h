@@ -46,6 +46,11 @@ struct ConvArgs {
     // (v - stat_shift[k]) and its square over the rows the wave owns, written to stat_ws[(part*2 + q)*K + k]; null: off
     float* stat_ws;
     const float* stat_shift;
+    // data gradient: dx = conv + res_add ([M][K] rows like the output; the gradient that reaches the same tensor through a residual
+    // shortcut) — added by the workgroups of reduction split 0.  filter gradient: accumulate != 0 adds into dW instead of overwriting
+    // (un-split launches; split launches accumulate in the reduce kernel)
+    const float* res_add;
+    int accumulate;
 };
 
 __device__ __forceinline__ float bn_epilogue(const ConvArgs& a, float v, int m, int n) {
@@ -142,7 +147,8 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off) 
 // (plain rows, or scattered to a stride phase's pixels).  part = index of this wave's row block among all (pixel tile, wave row) pairs.
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, TN>& acc, float* __restrict__ yout, int m0, int n0, int wm0,
-                                              int wn0, int lane, int part) {
+                                              int wn0, int lane, int part, bool first_split = true) {
+    const float* __restrict__ res = first_split ? a.res_add : nullptr;
     const int l31 = lane & 31, h = lane >> 5;
     const bool scatter = a.o_s != 0 && a.nsplit == 1;                  // split partials stay row-major; the reduce kernel scatters them
     const bool stats = a.stat_ws != nullptr;
@@ -166,6 +172,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, T
                     float v = acc.v[tm][tn][r];
                     const size_t idx = (size_t)m * a.K + n;
                     if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                    if (res) v += res[idx];
                     if (stats) {
                         const float d = v - shift[tn];
                         ssum[tn] += d;
@@ -188,6 +195,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, T
             }
         }
     }
+}
+
+// Epilogue of the filter-gradient kernels: the wave's 32x32 accumulator tiles -> dW rows [m' = (tap, channel)][k] (or this split's
+// partial); a.accumulate adds to what is there (un-split launches writing straight into a gradient that already holds a contribution).
+template <int TM, int TN>
+__device__ __forceinline__ void wgrad_epilogue(const ConvArgs& a, const Acc<TM, TN>& acc, float* __restrict__ out, int mm0, int n0, int wm0, int wn0,
+                                               int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn0 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < a.Kred && n < a.K) {
+                    const size_t idx = (size_t)m * a.K + n;
+                    out[idx] = a.accumulate ? out[idx] + acc.v[tm][tn][r] : acc.v[tm][tn][r];
+                }
+            }
+        }
 }
 
 constexpr unsigned OOB2 = 0x80000000u;     // host guarantees both tensors are < 2 GiB on this path

@@ -521,7 +521,7 @@ __device__ __forceinline__ void conv_fwd_body(ConvArgs a, const int blk) {
         f0.load(An, Bn, 0, wm0, wn0, lane);
     }
 
-    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN);
+    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, int KIND, bool VECB>
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
         }
     }
 
-    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN);
+    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
 }
 
 // ===================================== wgrad kernel ============================================
@@ -782,19 +782,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
         }
     }
 
-    float* out = a.y + (size_t)z * a.split_stride;
-    const int l31 = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn0 + tn * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < a.Kred && n < a.K) out[(size_t)m * a.K + n] = acc.v[tm][tn][r];
-            }
-        }
+    wgrad_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, mm0, n0, wm0, wn0, lane);
 }
 
 // ---- filter gradient, linear pixel walk (any stride, zero padding, OW >= 32, C % 4 == 0, K % 4 == 0), with a register
@@ -941,29 +929,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a
         if (DEPTH >= 3 && nchunks - nmain >= 2) stage(nmain + 1, ring[1 % DEPTH], ring[2 % DEPTH], false);
     }
 
-    float* out = a.y + (size_t)z * a.split_stride;
-    const int l31 = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn0 + tn * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < a.Kred && n < a.K) out[(size_t)m * a.K + n] = acc.v[tm][tn][r];
-            }
-        }
+    wgrad_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, mm0, n0, wm0, wn0, lane);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nsplit,
-                                     size_t stride) {
+                                     size_t stride, int accumulate) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t gs = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += gs) {
         float s = 0.f;
         for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * stride + i];
-        out[i] = s;
+        out[i] = accumulate ? out[i] + s : s;
     }
 }
 
@@ -1277,7 +1253,7 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 
 // many partials (one per workgroup of wgrad_direct_kernel), few outputs: 64 outputs x 16 slices of the partial list per workgroup
 __global__ void __launch_bounds__(1024) splitk_reduce_many_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
-                                                                  int nsplit) {
+                                                                  int nsplit, int accumulate) {
     __shared__ float red[16][64];
     const int l = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + l;
@@ -1290,7 +1266,7 @@ __global__ void __launch_bounds__(1024) splitk_reduce_many_kernel(const float* _
         float tot = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) tot += red[j][l];
-        out[e] = tot;
+        out[e] = accumulate ? out[e] + tot : tot;
     }
 }
 
@@ -1600,7 +1576,7 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
             ar.y = final_out;
             hipLaunchKernelGGL(splitk_reduce_scatter_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, ar, nsplit, nout);
         } else {
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, final_out, nout, nsplit, nout);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, final_out, nout, nsplit, nout, 0);
         }
         PNP_CHECK_LAUNCH("splitk_reduce_kernel");
     }
@@ -1660,6 +1636,8 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     a.nsplit = nsplit;
     a.split_stride = (long long)nout;
     a.y = (nsplit > 1) ? ws : dw;
+    const int accumulate = a.accumulate;           // un-split: in the kernel's epilogue; split: in the reduce kernel
+    if (nsplit > 1) a.accumulate = 0;
     dim3 grid((unsigned)(nblk * nsplit));
     static const int env_nolin = getenv("PNP_CONV_NOLIN") ? 1 : 0;
     const bool lin_any = !env_nolin && a.pad_mode == PNP_PAD_ZERO && (a.C % 4) == 0 && a.OW >= BK && a.x_bytes < 0x80000000u &&
@@ -1688,7 +1666,7 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     if (nsplit > 1) {
         int nb = pnp_cdiv((long long)nout, 256);
         if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, dw, nout, nsplit, nout);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, dw, nout, nsplit, nout, accumulate);
         PNP_CHECK_LAUNCH("splitk_reduce_kernel");
     }
     return PNP_OK;
@@ -2037,8 +2015,24 @@ size_t pnp_conv2d_dgrad_workspace_bytes(const pnp_conv_geom* g) {
     return b;
 }
 
+static int dgrad_impl(const float* dy, const float* w, float* dx, const pnp_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream,
+                      const float* residual);
+
 int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_geom* g, void* workspace,
                      size_t workspace_bytes, void* stream) {
+    return dgrad_impl(dy, w, dx, g, workspace, workspace_bytes, stream, nullptr);
+}
+
+int pnp_conv2d_dgrad_add(const float* dy, const float* w, const float* residual, float* dx, const pnp_conv_geom* g, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    PNP_REQUIRE(residual && residual != dx, "pnp_conv2d_dgrad_add: residual must be a tensor of its own");
+    return dgrad_impl(dy, w, dx, g, workspace, workspace_bytes, stream, residual);
+}
+
+// residual != null: dx = data gradient + residual.  Fused into the epilogue on the stride-1 MFMA paths (the residual blocks); every
+// other geometry computes the gradient and adds the residual with one more pass (pnp_axpby).
+static int dgrad_impl(const float* dy, const float* w, float* dx, const pnp_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream,
+                      const float* residual) {
     if (int e = check_geom(g, "pnp_conv2d_dgrad")) return e;
     PNP_REQUIRE(dy && w && dx && workspace, "pnp_conv2d_dgrad: null pointer");
     PNP_REQUIRE(workspace_bytes >= pnp_conv2d_dgrad_workspace_bytes(g), "pnp_conv2d_dgrad: workspace too small");
@@ -2046,6 +2040,10 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
     hipStream_t st = (hipStream_t)stream;
     float* wt = (float*)workspace;
     size_t woff = ((size_t)g->R * g->S * g->C * g->K * sizeof(float) + 255) & ~(size_t)255;
+    const size_t dx_elems = (size_t)g->N * g->H * g->W * g->C;
+    auto add_residual = [&](float* out, const float* res) -> int {
+        return res ? pnp_axpby(res, out, dx_elems, 1.f, 1.f, stream) : PNP_OK;
+    };
     DgradPhase ph[16];
     const int nph = plan_phases(g, ph);
     if (nph > 0) {
@@ -2076,7 +2074,7 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
                                (const float*)outp, dx, g->N, g->H, g->W, g->C, g->pad_t);
             PNP_CHECK_LAUNCH("sympad_bwd_kernel");
         }
-        return PNP_OK;
+        return add_residual(dx, residual);
     }
     dim3 tg((unsigned)pnp_cdiv(g->K, 32), (unsigned)pnp_cdiv(g->C, 32), (unsigned)(g->R * g->S));
     hipLaunchKernelGGL(flip_transpose_kernel, tg, dim3(256), 0, st, w, wt, g->R, g->S, g->C, g->K);
@@ -2105,11 +2103,13 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
                                (const float*)out, dx, g->N, g->H, g->W, g->C, g->pad_t);
             PNP_CHECK_LAUNCH("sympad_bwd_kernel");
         }
-        return PNP_OK;
+        return add_residual(dx, residual);
     }
     size_t poff = woff;
     if (sym) poff += ((size_t)d.N * d.OH * d.OW * d.K * sizeof(float) + 255) & ~(size_t)255;
     float* split_ws = (workspace_bytes > poff) ? (float*)((char*)workspace + poff) : nullptr;
+    const bool fuse_res = residual && !sym && g->stride == 1;          // rows of the GEMM == pixels of dx, plain row-major output
+    if (fuse_res) a.res_add = residual;
     if (int e = (g->stride > 1 ? launch_fwd<2>(a, st, split_ws) : launch_fwd<1>(a, st, split_ws))) return e;
     if (sym) {
         const size_t total = (size_t)g->N * g->H * g->W * g->C;
@@ -2117,16 +2117,17 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
                            (const float*)out, dx, g->N, g->H, g->W, g->C, g->pad_t);
         PNP_CHECK_LAUNCH("sympad_bwd_kernel");
     }
-    return PNP_OK;
+    return fuse_res ? PNP_OK : add_residual(dx, residual);
 }
 
 size_t pnp_conv2d_wgrad_workspace_bytes(const pnp_conv_geom* g) { return g ? wgrad_ws(g) : 0; }
 
-int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_geom* g, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+static int wgrad_impl(const float* x, const float* dy, float* dw, const pnp_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream,
+                      int accumulate) {
     if (int e = check_geom(g, "pnp_conv2d_wgrad")) return e;
     PNP_REQUIRE(x && dy && dw, "pnp_conv2d_wgrad: null pointer");
     ConvArgs a = make_args(x, dy, dw, g);
+    a.accumulate = accumulate;
     a.w_bytes = (unsigned)((size_t)g->N * g->OH * g->OW * g->K * sizeof(float));   // a.w is dy [P][K] here
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
@@ -2147,7 +2148,7 @@ int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_
         if (e) return e;
         const size_t nout = (size_t)a.Kred * a.K;
         hipLaunchKernelGGL(splitk_reduce_many_kernel, dim3((unsigned)pnp_cdiv((long long)nout, 64)), dim3(1024), 0, st,
-                           (const float*)ws, dw, (int)nout, pl.nblk);
+                           (const float*)ws, dw, (int)nout, pl.nblk, accumulate);
         PNP_CHECK_LAUNCH("splitk_reduce_many_kernel");
         return PNP_OK;
     }
@@ -2155,6 +2156,16 @@ int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_
     if (a.K > 64) return launch_wgrad_tile<128, 128, 2, 2, true>(a, dw, ws, workspace_bytes, st);
     if (a.K > 32) return launch_wgrad_tile<128, 64, 2, 2, true>(a, dw, ws, workspace_bytes, st);
     return launch_wgrad_tile<128, 32, 4, 1, true>(a, dw, ws, workspace_bytes, st);
+}
+
+int pnp_conv2d_wgrad(const float* x, const float* dy, float* dw, const pnp_conv_geom* g, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    return wgrad_impl(x, dy, dw, g, workspace, workspace_bytes, stream, 0);
+}
+
+int pnp_conv2d_wgrad_acc(const float* x, const float* dy, float* dw, const pnp_conv_geom* g, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    return wgrad_impl(x, dy, dw, g, workspace, workspace_bytes, stream, 1);
 }
 
 int pnp_sympad_fwd(const float* x, float* xp, int32_t N, int32_t H, int32_t W, int32_t C, int32_t p, void* stream) {

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(1024) colreduce_compact_kernel(float* __restri
 template <int KIND>
 __global__ void __launch_bounds__(1024) colreduce_final_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
                                                                float* o0, float* o1, int nblk, int C, long long P, float* mm, float* mv,
-                                                               float decay, int slab) {
+                                                               float decay, int slab, float* acc0, float* acc1) {
     // 1024 threads = 32 channels x 32 slices of the block list; fixed summation order => deterministic
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -222,13 +222,17 @@ __global__ void __launch_bounds__(1024) colreduce_final_kernel(const float* __re
     } else {
         o0[c] = (float)s0;
         o1[c] = (float)s1;
+        if (acc0) {         // the parameter gradients straight into the gradient arena (which may already hold another use's share)
+            acc0[c] += (float)s0;
+            acc1[c] += (float)s1;
+        }
     }
 }
 
 // the final combine, in two launches when the list is long (>= 4 slabs)
 template <int KIND>
 int launch_colreduce_final(float* ws, const float* x0, float* o0, float* o1, int nblk, int C, long long P, float* mm, float* mv, float decay,
-                           hipStream_t st, const char* who) {
+                           hipStream_t st, const char* who, float* acc0 = nullptr, float* acc1 = nullptr) {
     static const int two_stage = getenv("PNP_BN_FINAL_1STAGE") ? 0 : 1;
     int slab = 0, n = nblk;
     if (two_stage && nblk >= 4 * COLRED_SLAB) {
@@ -239,7 +243,7 @@ int launch_colreduce_final(float* ws, const float* x0, float* o0, float* o1, int
         n = 2 * nslab;
     }
     hipLaunchKernelGGL(colreduce_final_kernel<KIND>, dim3(pnp_cdiv(C, 32)), dim3(1024), 0, st, (const float*)ws, x0, o0, o1, n, C, P, mm, mv,
-                       decay, slab);
+                       decay, slab, acc0, acc1);
     PNP_CHECK_LAUNCH(who);
     return PNP_OK;
 }
@@ -260,7 +264,7 @@ int colreduce_plan(long long P, int C, int* nblk, int* rpb) {
 
 template <int KIND>
 int run_colreduce(ColArgs a, float* o0, float* o1, void* ws, size_t ws_bytes, hipStream_t st, const char* who, float* mm = nullptr,
-                  float* mv = nullptr, float decay = 0.f) {
+                  float* mv = nullptr, float decay = 0.f, float* acc0 = nullptr, float* acc1 = nullptr) {
     int nblk, rpb;
     colreduce_plan(a.P, a.C, &nblk, &rpb);
     const size_t need = (size_t)nblk * 2 * a.C * sizeof(float);
@@ -276,7 +280,7 @@ int run_colreduce(ColArgs a, float* o0, float* o1, void* ws, size_t ws_bytes, hi
         hipLaunchKernelGGL(colreduce_scalar_kernel<KIND>, dim3(nblk, pnp_cdiv(a.C, 64)), dim3(64), 0, st, a);
     }
     PNP_CHECK_LAUNCH(who);
-    return launch_colreduce_final<KIND>((float*)ws, a.x, o0, o1, nblk, a.C, a.P, mm, mv, decay, st, who);
+    return launch_colreduce_final<KIND>((float*)ws, a.x, o0, o1, nblk, a.C, a.P, mm, mv, decay, st, who, acc0, acc1);
 }
 
 __global__ void bn_update_moving_kernel(float* mm, float* mv, const float* mean, const float* var, long long P, int C,
@@ -781,7 +785,23 @@ int pnp_bn_bwd(const float* dout, const float* out, const float* x, const float*
                const float* gamma, float* dx, float* dgamma, float* dbeta, float* dshortcut, int32_t Cs, int64_t P,
                int32_t C, float eps, float alpha, int32_t training, float keep_prob, uint64_t seed, uint32_t stream_id,
                void* workspace, size_t workspace_bytes, void* stream) {
-    if (int e = pnp_bn_bwd_reduce(dout, out, x, mean, var, dgamma, dbeta, P, C, eps, alpha, workspace, workspace_bytes, stream)) return e;
+    return pnp_bn_bwd_acc(dout, out, x, mean, var, gamma, dx, dgamma, dbeta, nullptr, nullptr, dshortcut, Cs, P, C, eps, alpha, training,
+                          keep_prob, seed, stream_id, workspace, workspace_bytes, stream);
+}
+
+int pnp_bn_bwd_acc(const float* dout, const float* out, const float* x, const float* mean, const float* var,
+                   const float* gamma, float* dx, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, float* dshortcut,
+                   int32_t Cs, int64_t P, int32_t C, float eps, float alpha, int32_t training, float keep_prob, uint64_t seed,
+                   uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream) {
+    PNP_REQUIRE(dout && x && mean && var && dgamma && dbeta && P > 0 && C > 0, "pnp_bn_bwd: bad argument");
+    PNP_REQUIRE(alpha < 0.f || out, "pnp_bn_bwd: `out` is required when an activation is fused");
+    PNP_REQUIRE((size_t)P * C < (1ull << 32), "pnp_bn_bwd: tensor exceeds 2^32 elements");
+    PNP_REQUIRE((dgamma_acc != nullptr) == (dbeta_acc != nullptr), "pnp_bn_bwd_acc: dgamma_acc and dbeta_acc go together");
+    ColArgs ca{};
+    ca.x = x; ca.dout = dout; ca.out = out; ca.mean = mean; ca.var = var; ca.P = P; ca.C = C; ca.eps = eps; ca.alpha = alpha;
+    if (int e = run_colreduce<1>(ca, dbeta, dgamma, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_bwd", nullptr, nullptr, 0.f,
+                                 dbeta_acc, dgamma_acc))
+        return e;
     return pnp_bn_bwd_apply(dout, out, x, mean, var, gamma, dgamma, dbeta, dx, dshortcut, Cs, P, P, C, eps, alpha, training, keep_prob,
                             seed, stream_id, stream);
 }

@@ -12,6 +12,7 @@ import os
 import torch
 from torch.autograd import Function
 
+from . import gradsink
 from . import kernels as K
 from . import parallel as par
 
@@ -63,15 +64,69 @@ def _contig(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# the gradient that reaches a block input through the shortcut is added by the data-gradient kernel of the block's first convolution
+# (pnp_conv2d_dgrad_add) instead of by the autograd engine's elementwise add
+RES_LINK = os.environ.get("PNP_RES_LINK", "1") != "0"
+
+
+class ResLink(object):
+    """Ties the two conv-BN units of a residual / DR block that consume the SAME block input x (layers.residual_block, DR_block):
+    the tail unit (x = its shortcut) parks the shortcut gradient here, the head unit (x = its conv input) adds it to its data
+    gradient.  The tail's backward always runs before the head's (the head's output feeds the tail)."""
+    __slots__ = ("dsc",)
+
+    def __init__(self):
+        self.dsc = None
+
+    def take(self):
+        d, self.dsc = self.dsc, None
+        return d
+
+
+def _wgrad(ctx, x, dy, sink):
+    """filter gradient of a conv call site: into the variable's arena slot when it has one (returns None to the engine)"""
+    if sink is not None and sink.grad() is not None:
+        K.conv2d_wgrad(x, dy, ctx.geom, into=sink.grad())
+        gradsink.done(sink)
+        return None
+    return K.conv2d_wgrad(x, dy, ctx.geom)
+
+
 def _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, keep, seed, sid):
     """backward of BN (+activation, +dropout mask of the conv in front).  With synchronised statistics the per-channel sums are
-    all-reduced between the reduction and the apply kernel; the PARAMETER gradients stay local (the GradReducer sums them)."""
+    all-reduced between the reduction and the apply kernel; the PARAMETER gradients stay local (the GradReducer sums them).
+    Returns (dxc, dgamma, dbeta, dsc); dgamma / dbeta are None when they went straight into the variables' gradient slots."""
+    sinks = getattr(ctx, "bn_sinks", None)
+    slots = (sinks[0].grad(), sinks[1].grad()) if sinks is not None else None
+    if slots is not None and (slots[0] is None or slots[1] is None):
+        slots = None
     if ctx.is_train and ctx.P_norm != xc.numel() // xc.shape[-1]:
         sums = K.bn_bwd_reduce(dout, out, xc, mean, var, BN_EPS, ctx.alpha)
         gsums = par.all_sum_(sums.clone())
         dxc, dsc = K.bn_bwd_apply(dout, out, xc, mean, var, gamma, gsums, ctx.P_norm, need_sc, BN_EPS, ctx.alpha, True, keep, seed, sid)
-        return dxc, sums[0], sums[1], dsc
-    return K.bn_bwd(dout, out, xc, mean, var, gamma, need_sc, BN_EPS, ctx.alpha, ctx.is_train, keep, seed, sid)
+        dgamma, dbeta = sums[0], sums[1]
+        if slots is not None:                   # (opt-in SyncBN path: two [C]-sized adds)
+            K.axpby(dgamma, slots[0], 1.0, 1.0)
+            K.axpby(dbeta, slots[1], 1.0, 1.0)
+    else:
+        dxc, dgamma, dbeta, dsc = K.bn_bwd(dout, out, xc, mean, var, gamma, need_sc, BN_EPS, ctx.alpha, ctx.is_train, keep, seed, sid,
+                                           into=slots)
+    if slots is not None:
+        gradsink.done(sinks[0])
+        gradsink.done(sinks[1])
+        return dxc, None, None, dsc
+    return dxc, dgamma, dbeta, dsc
+
+
+def _bn_sinks(ctx, gamma, beta, ig, ib):
+    """forward: record the uses of gamma / beta when both take a gradient and both have a slot"""
+    ctx.bn_sinks = None
+    if ctx.needs_input_grad[ig] and ctx.needs_input_grad[ib]:
+        sg, sb = gradsink.lookup(gamma), gradsink.lookup(beta)
+        if sg is not None and sb is not None:
+            sg.pending += 1
+            sb.pending += 1
+            ctx.bn_sinks = (sg, sb)
 
 
 class Conv2dDropFn(Function):
@@ -82,6 +137,7 @@ class Conv2dDropFn(Function):
         y = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
         ctx.save_for_backward(x, w_)
         ctx.geom, ctx.keep, ctx.seed, ctx.sid = geom, keep_prob, seed, stream_id
+        ctx.w_sink = gradsink.use(w_) if ctx.needs_input_grad[1] else None
         return y
 
     @staticmethod
@@ -91,7 +147,7 @@ class Conv2dDropFn(Function):
         if ctx.keep < 1.0:
             dy = K.dropout(dy, ctx.keep, ctx.seed, ctx.sid)
         dx = K.conv2d_dgrad(dy, w, ctx.geom) if ctx.needs_input_grad[0] else None
-        dw = K.conv2d_wgrad(x, dy, ctx.geom) if ctx.needs_input_grad[1] else None
+        dw = _wgrad(ctx, x, dy, ctx.w_sink) if ctx.needs_input_grad[1] else None
         return dx, dw, None, None, None, None
 
 
@@ -99,13 +155,17 @@ class ConvBNActFn(Function):
     """y = act( BN( dropout( conv(x,w) ) ) + pad_channels(shortcut) )"""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, shortcut, geom, keep_prob, seed, stream_id, is_train, alpha, sync=False):
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, shortcut, geom, keep_prob, seed, stream_id, is_train, alpha, sync=False,
+                link=None):
         x = _contig(x)
         w_ = _contig(w)
         sc = _contig(shortcut) if shortcut is not None else None
         ctx.geom, ctx.keep, ctx.seed, ctx.sid = geom, keep_prob, seed, stream_id
         ctx.is_train, ctx.alpha = is_train, alpha
         ctx.sc_channels = sc.shape[-1] if sc is not None else 0
+        ctx.link = link if RES_LINK else None
+        ctx.w_sink = gradsink.use(w_) if ctx.needs_input_grad[1] else None
+        _bn_sinks(ctx, gamma, beta, 2, 3)
         ctx.fused = (not is_train) and FUSE_BN_INFER and not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         if ctx.fused:
             mean, var = _frozen_stats(ctx, moving_mean, moving_var)
@@ -150,10 +210,19 @@ class ConvBNActFn(Function):
             dgamma = dbeta = None
         else:
             dxc, dgamma, dbeta, dsc = _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, ctx.keep, ctx.seed, ctx.sid)
-        dx = K.conv2d_dgrad(dxc, w, ctx.geom) if ctx.needs_input_grad[0] else None
-        dw = K.conv2d_wgrad(x, dxc, ctx.geom) if ctx.needs_input_grad[1] else None
+        res = None
+        if ctx.link is not None:
+            if ctx.sc_channels:             # tail of a block: the head's data-gradient kernel adds the shortcut gradient
+                ctx.link.dsc, dsc = dsc, None
+            else:                           # head of a block
+                res = ctx.link.take()
+        if ctx.needs_input_grad[0]:
+            dx = K.conv2d_dgrad(dxc, w, ctx.geom, residual=res)
+        else:
+            dx = None
+        dw = _wgrad(ctx, x, dxc, ctx.w_sink) if ctx.needs_input_grad[1] else None
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, None, None,
-                dsc, None, None, None, None, None, None, None)
+                dsc, None, None, None, None, None, None, None, None)
 
 
 class BNActFn(Function):
@@ -164,6 +233,7 @@ class BNActFn(Function):
         xc = _contig(xc)
         P = xc.numel() // xc.shape[-1]
         ctx.P_norm = P
+        _bn_sinks(ctx, gamma, beta, 1, 2)
         if is_train:
             if sync:                  # opt-in SyncBN: statistics of the batch concatenated over the replicas
                 mean, var = par.sync_bn_stats(*K.bn_stats(xc))

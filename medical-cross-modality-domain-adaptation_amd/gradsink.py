@@ -1,0 +1,84 @@
+"""Gradient sinks: parameter gradients written by the kernels straight into the flat gradient arena.
+
+TF-1.4's autodiff materialises one gradient tensor per use of a variable and sums them with AddN; torch's engine does the same with an
+`AccumulateGrad` node per parameter, i.e. one elementwise add kernel per variable per step into `.grad` (376 variables in the
+adaptation graph: ~250 launches of 4-6 us per joint step).  A parameter that lives in a `VariableStore` arena registers its gradient
+slot here instead; the backward passes in functional.py hand that slot to the kernel that produces the gradient
+(pnp_conv2d_wgrad_acc, pnp_bn_bwd_acc: "add into"), return None to the engine, and tell the sink when the last use of the step has
+been written (the data-parallel reducer launches a bucket's all-reduce from that callback).
+
+The arena is zeroed once per step (`VariableStore.zero_grad`), which also re-arms the use counters.
+"""
+import os
+import weakref
+
+ENABLED = os.environ.get("PNP_GRAD_SINKS", "1") != "0"
+
+
+class Sink(object):
+    __slots__ = ("param", "pending", "ready")
+
+    def __init__(self, param):
+        self.param = weakref.ref(param)     # the store's own tensor object: while it lives nothing else can sit at its address
+        self.pending = 0                    # uses recorded by forward passes whose backward has not run yet
+        self.ready = None                   # callable(): every use of this step has been written
+
+    def grad(self):
+        p = self.param()
+        return None if p is None else p.grad
+
+
+_SINKS = {}     # data_ptr of the parameter -> Sink
+
+
+def register(param):
+    """param: a leaf tensor whose .grad is (a view of) the buffer the kernels may add into"""
+    s = Sink(param)
+    _SINKS[param.data_ptr()] = s
+    return s
+
+
+def lookup(t):
+    if not ENABLED:
+        return None
+    s = _SINKS.get(t.data_ptr())
+    if s is None:
+        return None
+    p = s.param()
+    if p is None or p.grad is None or p.data_ptr() != t.data_ptr() or tuple(p.shape) != tuple(t.shape):
+        if p is None:
+            _SINKS.pop(t.data_ptr(), None)          # the store that owned this address is gone
+        return None
+    return s
+
+
+def use(t):
+    """forward pass: `t` will receive a gradient from this call site -> its sink (or None), with the use recorded"""
+    s = lookup(t)
+    if s is not None:
+        s.pending += 1
+    return s
+
+
+def done(s):
+    """backward pass: one use has been added into the slot"""
+    s.pending -= 1
+    if s.pending <= 0:
+        s.pending = 0
+        if s.ready is not None:
+            s.ready()
+
+
+def set_ready(param, fn):
+    s = _SINKS.get(param.data_ptr())
+    if s is not None and s.param() is param:
+        s.ready = fn
+        return True
+    return False
+
+
+def rearm(params):
+    for p in params:
+        s = _SINKS.get(p.data_ptr())
+        if s is not None:
+            s.pending = 0

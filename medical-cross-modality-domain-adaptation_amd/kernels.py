@@ -140,21 +140,36 @@ def conv2d_fwd_bn(x, w, g, scale_shift, shortcut=None, alpha=0.2, keep_prob=1.0,
     return y
 
 
-def conv2d_dgrad(dy, w, g):
+def conv2d_dgrad(dy, w, g, residual=None):
+    """gradient w.r.t. the conv input; with `residual` ([N,H,W,C]) dx = gradient + residual in the same launch (pnp_conv2d_dgrad_add)"""
     lib = _lib.load()
     dx = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dy.device)
     nbytes = lib.pnp_conv2d_dgrad_workspace_bytes(ctypes.byref(g))
     ws = workspace(nbytes, dy.device)
+    if residual is not None:
+        if tuple(residual.shape) != tuple(dx.shape):
+            raise ValueError("conv2d_dgrad: residual %s does not match dx %s" % (tuple(residual.shape), tuple(dx.shape)))
+        check(lib.pnp_conv2d_dgrad_add(_p(dy), _p(w), _p(residual), _p(dx), ctypes.byref(g), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                       _stream()), "pnp_conv2d_dgrad_add")
+        return dx
     check(lib.pnp_conv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(g), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
           "pnp_conv2d_dgrad")
     return dx
 
 
-def conv2d_wgrad(x, dy, g):
+def conv2d_wgrad(x, dy, g, into=None):
+    """filter gradient; `into` ([R,S,C,K], e.g. the variable's slot of the gradient arena): dw is ADDED to it (pnp_conv2d_wgrad_acc)
+    and `into` is returned"""
     lib = _lib.load()
-    dw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
     nbytes = lib.pnp_conv2d_wgrad_workspace_bytes(ctypes.byref(g))
     ws = workspace(nbytes, x.device)
+    if into is not None:
+        if tuple(into.shape) != (g.R, g.S, g.C, g.K):
+            raise ValueError("conv2d_wgrad: `into` %s is not the filter shape %s" % (tuple(into.shape), (g.R, g.S, g.C, g.K)))
+        check(lib.pnp_conv2d_wgrad_acc(_p(x), _p(dy), _p(into), ctypes.byref(g), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+              "pnp_conv2d_wgrad_acc")
+        return into
+    dw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
     check(lib.pnp_conv2d_wgrad(_p(x), _p(dy), _p(dw), ctypes.byref(g), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
           "pnp_conv2d_wgrad")
     return dw
@@ -211,7 +226,8 @@ def bn_apply(x, mean, var, gamma, beta, shortcut=None, eps=1e-3, alpha=0.2):
 
 
 def bn_bwd(dout, out, x, mean, var, gamma, shortcut_channels=0, eps=1e-3, alpha=0.2, training=True, keep_prob=1.0, seed=0,
-           stream_id=0):
+           stream_id=0, into=None):
+    """`into` = (dgamma_slot, dbeta_slot): the parameter gradients are also ADDED to these [C] buffers (pnp_bn_bwd_acc)"""
     lib = _lib.load()
     C = x.shape[-1]
     P = x.numel() // C
@@ -222,6 +238,12 @@ def bn_bwd(dout, out, x, mean, var, gamma, shortcut_channels=0, eps=1e-3, alpha=
     if shortcut_channels:
         dsc = torch.empty(x.shape[:-1] + (shortcut_channels,), dtype=torch.float32, device=x.device)
     ws = workspace(lib.pnp_bn_workspace_bytes(P, C), x.device)
+    if into is not None:
+        check(lib.pnp_bn_bwd_acc(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(into[0]),
+                                 _p(into[1]), _p(dsc), shortcut_channels, P, C, float(eps), float(alpha), 1 if training else 0,
+                                 float(keep_prob), int(seed), int(stream_id), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+              "pnp_bn_bwd_acc")
+        return dx, dgamma, dbeta, dsc
     check(lib.pnp_bn_bwd(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(dsc),
                          shortcut_channels, P, C, float(eps), float(alpha), 1 if training else 0, float(keep_prob), int(seed),
                          int(stream_id), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_bn_bwd")

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
-from .functional import BNActFn, Conv2dDropFn, ConvBNActFn, LEAK, MaxPool2Fn, SymPadFn, sync_now
+from .functional import BNActFn, Conv2dDropFn, ConvBNActFn, LEAK, MaxPool2Fn, ResLink, SymPadFn, sync_now
 from .variables import current_store, truncated_normal
 
 
@@ -73,14 +73,14 @@ def dilate_conv2d(x, W, keep_prob_, rate=2, padding='SAME'):
     return Conv2dDropFn.apply(x, W, g, keep, seed, sid)
 
 
-def _conv_bn(x, W, keep_prob, padding, stride, dil, is_train, scope, bn_trainable, alpha, shortcut=None):
+def _conv_bn(x, W, keep_prob, padding, stride, dil, is_train, scope, bn_trainable, alpha, shortcut=None, link=None):
     x, padding = _prepad(x, W, padding)
     g = K.conv_geom(tuple(x.shape), tuple(W.shape), stride, dil, padding)
     gamma, beta, mm, mv = _bn_vars(scope, g.K, bn_trainable)
     keep, seed, sid = _drop_ids(keep_prob)
     if x.is_meta:
         return _meta_out(g)
-    return ConvBNActFn.apply(x, W, gamma, beta, mm, mv, shortcut, g, keep, seed, sid, bool(is_train), float(alpha), sync_now())
+    return ConvBNActFn.apply(x, W, gamma, beta, mm, mv, shortcut, g, keep, seed, sid, bool(is_train), float(alpha), sync_now(), link)
 
 
 # ---- layers.py:16-27 ---------------------------------------------------------------------------------
@@ -191,7 +191,10 @@ def residual_block(x, w1, w2, keep_prob, inc_dim=False, is_train=True, scope=Non
     else:
         s1, s2 = scope + "_1", scope + "_2"
     alpha = LEAK if leak is True else 0.0
-    inner = _conv_bn(x, w1, keep_prob, padding, 1, 1, is_train, s1, bn_trainable, alpha)
+    # x feeds the first conv AND the shortcut: one fused gradient add (functional.ResLink).  Not with SYMMETRIC padding: the first conv
+    # then reads a mirror-padded copy of x, whose gradient has another shape.
+    link = ResLink() if (padding == 'SAME' and not x.is_meta) else None
+    inner = _conv_bn(x, w1, keep_prob, padding, 1, 1, is_train, s1, bn_trainable, alpha, link=link)
     C = x.shape[-1]
     Cout = w2.shape[-1]
     if inc_dim is True:
@@ -199,7 +202,7 @@ def residual_block(x, w1, w2, keep_prob, inc_dim=False, is_train=True, scope=Non
             raise ValueError("residual_block(inc_dim): shortcut %d + 2*%d != %d output channels" % (C, C // 2, Cout))
     elif Cout != C:
         raise ValueError("residual_block: shortcut has %d channels, block output %d" % (C, Cout))
-    return _conv_bn(inner, w2, keep_prob, padding, 1, 1, is_train, s2, bn_trainable, alpha, shortcut=x)
+    return _conv_bn(inner, w2, keep_prob, padding, 1, 1, is_train, s2, bn_trainable, alpha, shortcut=x, link=link)
 
 
 # ---- layers.py:168-189 -------------------------------------------------------------------------------
@@ -209,9 +212,10 @@ def DR_block(x, w1, w2, rate, keep_prob, inc_dim=False, is_train=True, bn_traina
     else:
         s1, s2 = scope + "_1", scope + "_2"
     alpha = LEAK if leak is True else 0.0
-    inner = _conv_bn(x, w1, keep_prob, 'SAME', 1, int(rate), is_train, s1, bn_trainable, alpha)
+    link = None if x.is_meta else ResLink()
+    inner = _conv_bn(x, w1, keep_prob, 'SAME', 1, int(rate), is_train, s1, bn_trainable, alpha, link=link)
     C = x.shape[-1]
     Cout = w2.shape[-1]
     if (inc_dim is True and Cout != C + 2 * (C // 2)) or (inc_dim is not True and Cout != C):
         raise ValueError("DR_block: shortcut/output channel mismatch (%d -> %d, inc_dim=%s)" % (C, Cout, inc_dim))
-    return _conv_bn(inner, w2, keep_prob, 'SAME', 1, int(rate), is_train, s2, bn_trainable, alpha, shortcut=x)
+    return _conv_bn(inner, w2, keep_prob, 'SAME', 1, int(rate), is_train, s2, bn_trainable, alpha, shortcut=x, link=link)

@@ -220,8 +220,11 @@ class GradReducer(object):
         self.native = _COMM if (group is None and store.arena.is_cuda) else None      # data path: pnp_comm_allreduce on OUR stream
         self.side = torch.cuda.Stream() if self.overlap else None
         if self.overlap:
+            from . import gradsink
             for v in tr:
-                v.tensor.register_post_accumulate_grad_hook(self._make_hook(v))
+                hook = self._make_hook(v)
+                v.tensor.register_post_accumulate_grad_hook(hook)          # gradients that come through the autograd engine
+                gradsink.set_ready(v.tensor, (lambda h=hook, t=v.tensor: h(t)))   # gradients the kernels add straight into the arena
         self.reset()
 
     def _close(self, start, end, members):
@@ -236,11 +239,19 @@ class GradReducer(object):
         self._count = list(self._remaining)
         self._pending = []
         self._launched = [False] * len(self.buckets)
+        self._seen = set()
 
     def _make_hook(self, v):
         b = self._var_bucket[v.name]
+        name = v.name
 
         def hook(_param):
+            # once per variable and step: a gradient the kernels added straight into the arena announces itself through its sink, and
+            # the engine's AccumulateGrad node still runs its post-accumulate hook for the (undefined) gradient it was handed — both
+            # come after the variable's last use of the step, the first one counts
+            if name in self._seen:
+                return
+            self._seen.add(name)
             self._count[b] -= 1
             if self._count[b] == 0:
                 self._launch(b)

@@ -13,6 +13,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+from . import gradsink
 from ._lib import OPT_CHUNK
 
 _current = None
@@ -170,6 +171,7 @@ class VariableStore(object):
             t.requires_grad_(True)
             t.grad = self.grad_arena[v.offset:v.offset + v.numel].view(v.shape)
             v.tensor = t
+            gradsink.register(t)        # kernels may add this variable's gradient straight into its slot
         self.finalized = True
 
     # ---- helpers for the optimisers ---------------------------------------------------------------
@@ -213,6 +215,7 @@ class VariableStore(object):
 
     def zero_grad(self):
         self.grad_arena.zero_()
+        gradsink.rearm(v.tensor for v in self.trainable())
 
     def state_dict(self):
         return OrderedDict((k, v.tensor.detach().cpu().numpy().copy()) for k, v in self.vars.items())

@@ -86,6 +86,16 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert errs["y"] < TOL, errs
     assert errs["dx"] < TOL, errs
     assert errs["dw"] < TOL, errs
+    # "add into" variants (gradient sinks / residual shortcut): dx = dgrad + residual, dw_slot += wgrad — against the plain results above
+    res = torch.from_numpy(np.random.default_rng(2).standard_normal(tuple(dx.shape)).astype(np.float32)).to(dev)
+    dx2 = K.conv2d_dgrad(dyd, wd, g, residual=res)
+    assert _rel(dx2, dx + res) < 2e-6, ("dgrad_add", case, _rel(dx2, dx + res))
+    slot0 = torch.from_numpy(np.random.default_rng(3).standard_normal(tuple(dw.shape)).astype(np.float32)).to(dev)
+    slot = slot0.clone()
+    assert K.conv2d_wgrad(xd, dyd, g, into=slot) is slot
+    assert _rel(slot, slot0 + dw) < 2e-6, ("wgrad_acc", case, _rel(slot, slot0 + dw))
+    K.conv2d_wgrad(xd, dyd, g, into=slot)            # a second use of the same filters (shared critic weights)
+    assert _rel(slot, slot0 + 2 * dw) < 4e-6
 
 
 def test_conv_transpose_detecting(dev):
@@ -174,3 +184,9 @@ def test_conv_full_size_adjoint_identities(dev, shape):
     a, b, c = dot(y, dy), dot(x, dx), dot(w, dw)
     scale = float(y.double().norm() * dy.double().norm())       # |<y,dy>| <= |y||dy|: the natural error scale
     assert abs(a - b) < 2e-6 * scale and abs(a - c) < 2e-6 * scale, (a, b, c, scale)
+    # the "add into" entry points at the same sizes (reduction splits accumulate in the summing kernel, un-split tiles in the epilogue)
+    slot = torch.ones_like(dw)
+    K.conv2d_wgrad(x, dy, g, into=slot)
+    assert _rel(slot, dw + 1.0) < 2e-6
+    res = torch.randn(tuple(dx.shape), generator=gen).to(dev)
+    assert _rel(K.conv2d_dgrad(dy, w, g, residual=res), dx + res) < 2e-6

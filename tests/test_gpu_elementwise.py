@@ -67,6 +67,13 @@ def test_bn_unit_fwd_bwd(dev, shape, Cs, alpha, training):
     assert _rel(dbeta, b_t.grad) < 1e-4
     if sc is not None:
         assert _rel(dsc, sc_t.grad) < 1e-5
+    # pnp_bn_bwd_acc: the same sums also added into caller-owned slots, twice (a BN layer shared by two passes)
+    sg, sb = torch.full((C,), 2.0, device=dev), torch.full((C,), -1.0, device=dev)
+    for rep in (1, 2):
+        dxa2, dg2, db2, _ = K.bn_bwd(torch.from_numpy(dout).to(dev), out, xcd, mean, var, gd, Cs, 1e-3, alpha, training, keep, seed, sid,
+                                     into=(sg, sb))
+        assert torch.equal(dxa2, dxa) and torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
+        assert _rel(sg, 2.0 + rep * dgamma) < 1e-6 and _rel(sb, -1.0 + rep * dbeta) < 1e-6
 
 
 def test_bn_stats_large_mean_is_stable(dev):

@@ -192,3 +192,33 @@ def test_segmenter_train_step_B16_vs_float32_oracle(dev):
     for k, v in V32.items():
         if k.endswith("moving_mean") or k.endswith("moving_variance"):
             assert _rel(after[k], v.detach()) < 1e-4, k
+
+
+def test_gradient_sinks_and_shortcut_links_equal_the_autograd_engine(dev):
+    """The parameter gradients the kernels add straight into the arena (gradsink) and the shortcut gradient the data-gradient kernel
+    adds (functional.ResLink) must equal what the autograd engine's own AccumulateGrad / AddN produce: same step, both ways, and no
+    `aten::add` launches left on the fast path."""
+    ss, F, gs = pkg("source_segmenter"), pkg("functional"), pkg("gradsink")
+    rng = np.random.default_rng(7)
+    B = 2
+    x = torch.from_numpy(rng.standard_normal((B, 256, 256, 3)).astype(np.float32)).to(dev)
+    y = torch.from_numpy(np.eye(5, dtype=np.float32)[_blob_labels(rng, B)]).to(dev)
+    net = ss.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, cost_kwargs=dict(COST), seed=3)
+    sd = he_scaled(net.store.state_dict())
+    arenas = {}
+    for mode in ("engine", "sinks"):
+        gs.ENABLED = F.RES_LINK = (mode == "sinks")
+        try:
+            net.store.load_state_dict(sd)
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+                net.loss_and_grads(x, y, 0.75, drop_seed=11)
+            adds = sum(e.count for e in prof.key_averages() if e.key in ("aten::add", "aten::add_"))
+            arenas[mode] = (net.store.grad_arena.clone(), adds)
+        finally:
+            gs.ENABLED = F.RES_LINK = True
+    (g0, adds0), (g1, adds1) = arenas["engine"], arenas["sinks"]
+    print("engine: %d aten::add launches, sinks: %d; max |diff| / max |g| = %.3e" % (adds0, adds1, _rel(g1, g0)))
+    assert adds0 > 100 and adds1 <= 2
+    assert _rel(g1, g0) < 2e-6
+    worst = max(_rel(g1[v.offset:v.offset + v.numel], g0[v.offset:v.offset + v.numel]) for v in net.store.trainable())
+    assert worst < 1e-4, worst
