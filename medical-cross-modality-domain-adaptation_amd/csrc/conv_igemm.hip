@@ -791,6 +791,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
 // step, so the first toucher misses to HBM and the others wait on the same miss: the load latency of EVERY stage is an HBM round trip,
 // longer than the one stage (~64 MFMAs per wave) of cover conv_wgrad_kernel gives it.  Here stage j + DEPTH is requested while stage j
 // is contracted; the ring is indexed with compile-time constants only (loop unrolled by DEPTH), the tail is peeled.
+// PNP_WGRAD_ABLATE (compile-time, timing experiments only — results are wrong when set): 1 = no global loads after the prologue,
+// 2 = x loads at a fixed address (no address arithmetic), 4 = no LDS stores, 8 = no barrier
+#ifndef PNP_WGRAD_ABLATE
+#define PNP_WGRAD_ABLATE 0
+#endif
 template <int BM, int BN, int WM, int WN, int DEPTH>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -862,6 +867,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a
     auto gload = [&](Stage& st) {
 #pragma unroll
         for (int i = 0; i < ANP; ++i) {
+            if constexpr (PNP_WGRAD_ABLATE & 2) {          // timing experiment: the loads without their address arithmetic
+                st.a[i] = bload4(rx, (unsigned)l_off[i] & 0xFFFFFu);
+                continue;
+            }
             const bool ok = mok & ((unsigned)l_ih[i] < (unsigned)a.H) & ((unsigned)l_iw[i] < (unsigned)a.W);
             st.a[i] = bload4(rx, ok ? (unsigned)l_off[i] : OOB);
             l_iw[i] += step_w;
@@ -874,10 +883,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a
             l_ih[i] -= hw ? wrap_h : 0;
             l_off[i] += hw ? wrap_h_off : 0;
         }
-        const int soff = l_chunk * BK * a.K * 4;
+        // (readfirstlane: the stage counter is uniform, but the compiler did not prove it and wrapped every one of these loads in a
+        // waterfall loop — 16 extra basic blocks per two stages, which also fenced the MFMA / load interleave)
+        const int soff = __builtin_amdgcn_readfirstlane(l_chunk * BK * a.K * 4);
 #pragma unroll
         for (int i = 0; i < BNP; ++i) st.b[i] = bload4s(rw, boff[i], soff);
-        l_chunk = min(l_chunk + 1, nchunks_total);              // rows past the end of dy read as zeros
+        l_chunk = (l_chunk + 1 < nchunks_total) ? l_chunk + 1 : nchunks_total;      // rows past the end of dy read as zeros
     };
     auto lstore = [&](const Stage& st, float* An, float* Bn) {
 #pragma unroll
@@ -903,7 +914,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a
             float* An = lds + (cur ^ 1) * ASZ;
             float* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
             f1.load(As, Bs, 1, wm0, wn0, lane);
-            if (fetch) gload(fetch_into);
+            if constexpr (!(PNP_WGRAD_ABLATE & 1)) {
+                if (fetch) gload(fetch_into);
+            }
             f0.mma(acc);
             __builtin_amdgcn_sched_group_barrier(0x100, 4 * TM + 4 * TN, 0);      // slice-1 fragment reads first
 #pragma unroll
@@ -915,8 +928,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a
             PNP_SCHED_FENCE();
             PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, NDS)
             PNP_SLICE2(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), lstore(store_from, An, Bn), 4 * TM * TN, NDS)
-            PNP_LAST_SLICE(f1.mma(acc), lstore(store_from, An, Bn), 4 * TM * TN)
-            __syncthreads();
+            if constexpr (PNP_WGRAD_ABLATE & 4) {
+                f1.mma(acc);
+            } else {
+                PNP_LAST_SLICE(f1.mma(acc), lstore(store_from, An, Bn), 4 * TM * TN)
+            }
+            if constexpr (!(PNP_WGRAD_ABLATE & 8)) __syncthreads();
             f0.load(An, Bn, 0, wm0, wn0, lane);
         };
         const int nmain = (nchunks / DEPTH) * DEPTH;
