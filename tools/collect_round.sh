@@ -12,7 +12,13 @@ B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub"
 rocprofv3 --kernel-trace --stats -d $O/prof_joint -o joint -- $B > $O/bench_prof_joint.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $O/prof_seg -o seg -- $B --workload segmenter > $O/bench_prof_seg.json 2>/dev/null
 [ -z "$FAST" ] && rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o bf16 -- $B --dtype bf16 > $O/bench_prof_bf16.json 2>/dev/null
-for w in joint seg bf16; do python tools/rocpd_summary.py $(find $O/prof_$w -name "*.db" | head -1) $O/${w}_kernel_stats.txt > /dev/null 2>&1; done
+# per-kernel tables of the TIMED region only (warm-up and the joint workload's BN calibration forwards come before it): the dispatches that
+# start within the last steps * ms_per_step milliseconds of the trace
+for w in joint seg bf16; do
+  [ -f $O/bench_prof_$w.json ] || continue
+  X=$(python -c "import json;r=json.loads(open('$O/bench_prof_$w.json').read().strip().splitlines()[-1]);print(r['steps']*r['ms_per_step'])" 2>/dev/null)
+  python tools/rocpd_summary.py $(find $O/prof_$w -name "*.db" | head -1) $O/${w}_kernel_stats.txt --last-ms $X > /dev/null 2>&1
+done
 head -12 $O/joint_kernel_stats.txt | cut -c1-170
 # PMC passes, each on its own (never together with other trace domains)
 P="python bench.py --steps 2 --warmup 1 --no-probe --no-cpu-baseline --no-sub"
