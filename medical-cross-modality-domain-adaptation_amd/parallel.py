@@ -104,12 +104,43 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         if want_native:
-            _COMM = NativeComm(rank, world)
+            _bring_up_native(rank, world)
     return rank, local, world
 
 
+_DATA_GROUP = None      # torch.distributed group that carries the data-path collectives when the native communicator is not up
+
+
+def _bring_up_native(rank, world):
+    """NativeComm on every rank, or — if ANY rank fails to bring it up (a librccl.so that cannot be bound, an init error) — on none:
+    the ranks agree over gloo, and the data path then runs on torch.distributed's own nccl (= RCCL) group instead, loudly."""
+    global _COMM, _DATA_GROUP
+    err = None
+    try:
+        _COMM = NativeComm(rank, world)
+    except Exception as e:          # noqa: BLE001 — whatever went wrong, the other ranks must learn of it before anyone proceeds
+        err = e
+        _COMM = None
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return
+    import logging
+    logging.getLogger(__name__).warning("native RCCL communicator (pnp_comm_*) unavailable on at least one rank (%s): "
+                                        "gradient all-reduce falls back to torch.distributed's nccl (RCCL) group", err)
+    if _COMM is not None:
+        _COMM.destroy()
+        _COMM = None
+    _DATA_GROUP = dist.new_group(backend="nccl")
+
+
+def data_group():
+    return _DATA_GROUP
+
+
 def shutdown():
-    global _COMM
+    global _COMM, _DATA_GROUP
+    _DATA_GROUP = None
     if _COMM is not None:
         _COMM.destroy()
         _COMM = None
@@ -152,7 +183,7 @@ def all_sum_(t):
         if _COMM is not None and _SYNC[0] is None and t.is_cuda:
             _COMM.allreduce_(t)
         else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_SYNC[0])
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_SYNC[0] if (_SYNC[0] is not None or not t.is_cuda) else _DATA_GROUP)
     return t
 
 
@@ -189,6 +220,8 @@ class GradReducer(object):
 
     def __init__(self, store, bucket_bytes=32 << 20, overlap=True, group=None):
         self.store = store
+        if group is None and _COMM is None and store.arena.is_cuda:
+            group = _DATA_GROUP          # native communicator not up: torch.distributed's nccl group (None: the default group)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.overlap = overlap and self.world > 1 and store.arena.is_cuda
