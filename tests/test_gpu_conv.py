@@ -51,6 +51,10 @@ CASES = [
     (2, 64, 64, 32, 12, 3, 1, 2, "SAME"),       # direct narrow-output forward, K = 12 on the 16-wide instance, dilation 2
     (2, 64, 64, 16, 32, 3, 1, 1, "SAME"),       # data gradient with 16 INPUT channels: narrow-output kernel over dy (32 channels)
     (2, 70, 66, 16, 16, 3, 1, 1, "SAME"),       # narrow kernels with ragged 8x32 output patches
+    (2, 33, 45, 64, 96, 3, 1, 1, "SAME"),       # ring filter gradient (rows >= 32 pixels), ragged rows / tiles, K not a tile multiple
+    (2, 67, 65, 32, 48, 3, 2, 1, "SAME"),       # ring filter gradient walking a STRIDED output with odd extents (OW = 33)
+    (1, 70, 70, 32, 64, 3, 2, 1, "VALID"),      # same, VALID: the last input row / column is never read (OW = 34)
+    (2, 40, 72, 64, 64, 5, 2, 1, "SAME"),       # 5x5 stride 2 on the ring kernel (OW = 36), phases of the data gradient in one launch
 ]
 
 
