@@ -230,6 +230,12 @@ __device__ __forceinline__ f32x4 bload4s(__amdgpu_buffer_rsrc_t r, unsigned voff
 // planned by the caller exactly as for the fp32 kernels.  tile: 0 = 128x128, 1 = 128x64, 2 = 128x32.  Return false: no instance.
 bool launch_taps_bf16(const ConvArgs& a, int tile, int kind, dim3 grid, hipStream_t st);
 bool launch_wgrad_bf16(const ConvArgs& a, int tile, dim3 grid, hipStream_t st);
+// 3x3 stride-1 convolutions with exactly 16 output channels and 16 / 32 input channels on the 16x16x4 MFMA (conv_small.hip): forward,
+// data gradient (kind 1; honours res_add) and filter gradient (per-workgroup partials [n16_wgrad_blocks][9*C][16] -> splitk_reduce_many)
+bool n16_geom_ok(const pnp_conv_geom* g);
+int launch_n16_fwd(const ConvArgs& a, int kind, hipStream_t st);
+int n16_wgrad_blocks(const pnp_conv_geom* g);
+int launch_n16_wgrad(const ConvArgs& a, float* part, hipStream_t st);
 inline double conv_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.K * a.Kred; }
 inline double conv_bytes(const ConvArgs& a) {
     return 4.0 * ((double)a.N * a.H * a.W * a.C + (double)a.M * a.K + (double)a.Kred * a.K);

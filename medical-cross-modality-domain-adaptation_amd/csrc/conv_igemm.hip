@@ -1776,6 +1776,7 @@ int launch_wgd(const WgdArgs& a, const WgdPlan& pl, hipStream_t st) {
 
 size_t wgrad_ws(const pnp_conv_geom* g) {
     const size_t nout = (size_t)g->R * g->S * g->C * g->K;
+    if (n16_geom_ok(g)) return (size_t)n16_wgrad_blocks(g) * nout * sizeof(float);
     const long long P = (long long)g->N * g->OH * g->OW;
     const int bn = ((g->K & 3) != 0 || g->K <= 32) ? 32 : (g->K > 64 ? 128 : 64);
     const int nblk = pnp_cdiv((long long)g->R * g->S * g->C, 128) * pnp_cdiv(g->K, bn);
@@ -1926,6 +1927,7 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
     }
+    if (n16_geom_ok(g)) return launch_n16_fwd(a, 0, (hipStream_t)stream);
     if (narrow_fwd_ok(g, nullptr)) return launch_narrow(x, w, y, g, a, (hipStream_t)stream);
     float* split_ws = (workspace && workspace_bytes >= pnp_conv2d_fwd_workspace_bytes(g) && pnp_conv2d_fwd_workspace_bytes(g) > 0)
                           ? (float*)workspace : nullptr;
@@ -1937,7 +1939,7 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
 // this geometry (narrow-output vector-ALU kernels, reduction-split tiny layers): the caller runs pnp_bn_stats on the output instead.
 int32_t pnp_conv2d_fwd_stats_parts(const pnp_conv_geom* g) {
     if (!g || check_geom(g, "pnp_conv2d_fwd_stats_parts") != PNP_OK) return 0;
-    if (narrow_fwd_ok(g, nullptr) || fwd_split(g) > 1) return 0;
+    if (n16_geom_ok(g) || narrow_fwd_ok(g, nullptr) || fwd_split(g) > 1) return 0;
     const long long M = (long long)g->N * g->OH * g->OW;
     const int tile = choose_tile(M, g->K);
     return pnp_cdiv(M, 128) * ((tile == 0 || tile == 1) ? 2 : 4);        // pixel tiles x wave rows of the tile (WM)
@@ -1990,6 +1992,7 @@ int pnp_conv2d_fwd_bn(const float* x, const float* w, float* y, const pnp_conv_g
         a.drop_thresh = pnp_drop_thresh(keep_prob);
     }
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = shortcut; a.ep_cs = shortcut ? Cs : g->K; a.ep_alpha = alpha;
+    if (n16_geom_ok(g)) return launch_n16_fwd(a, 0, (hipStream_t)stream);
     return launch_fwd<0>(a, (hipStream_t)stream);      // no workspace: the reduction is never split on this path
 }
 
@@ -2112,6 +2115,10 @@ static int dgrad_impl(const float* dy, const float* w, float* dx, const pnp_conv
     float* out = sym ? (float*)((char*)workspace + woff) : dx;
     ConvArgs a = make_args(dy, wt, out, &d);
     a.ups = g->stride;
+    if (!sym && n16_geom_ok(&d)) {                           // 16 INPUT channels: the data gradient is a 16-output conv of dy
+        a.res_add = residual;
+        return launch_n16_fwd(a, 1, st);
+    }
     if (g->stride == 1 && narrow_fwd_ok(&d, nullptr)) {       // few INPUT channels: the data gradient is a narrow-output conv of dy
         if (int e = launch_narrow(dy, wt, out, &d, a, st)) return e;
         if (sym) {
@@ -2149,6 +2156,14 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, const pnp_conv
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     if (!ws) workspace_bytes = 0;
+    if (n16_geom_ok(g) && workspace_bytes >= wgrad_ws(g)) {
+        if (int e = launch_n16_wgrad(a, ws, st)) return e;
+        const size_t nout = (size_t)a.Kred * a.K;
+        hipLaunchKernelGGL(splitk_reduce_many_kernel, dim3((unsigned)pnp_cdiv((long long)nout, 64)), dim3(1024), 0, st,
+                           (const float*)ws, dw, (int)nout, n16_wgrad_blocks(g), accumulate);
+        PNP_CHECK_LAUNCH("splitk_reduce_many_kernel");
+        return PNP_OK;
+    }
     const WgdPlan pl = wgd_plan(g);
     if (pl.use && workspace_bytes >= pl.ws_bytes) {
         WgdArgs d{};

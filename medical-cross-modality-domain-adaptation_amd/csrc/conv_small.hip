@@ -1,0 +1,229 @@
+// conv_small.hip — 3x3 stride-1 convolutions with exactly 16 output channels on the fp32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// The 16-channel layers at 256^2 (group_1 of the segmenter, source_segmenter.py:93-96, and the CT copy adapt_1; their data gradients;
+// the first conv of group_2 seen from its data gradient) do not fit the 32x32 MFMA tiles of conv_igemm.hip: N = 16 fills half a tile,
+// and the reduction (9 taps x 16 channels = 144) is 4.5 stages deep, so a workgroup spends its life in prologue and epilogue.  Round 1
+// moved them to the vector ALUs (conv_fwd_narrow_kernel, wgrad_direct_kernel: 37 / 21 TF/s, i.e. 1.0 / 0.6 TB/s effective).  The 16x16x4
+// MFMA has the right shape: N = 16 is one tile, the filters (144 x 16 floats) live in 36 VGPRs per lane for the whole kernel, and the
+// input patch of an 8x32-pixel output tile is staged ONCE in LDS and read by all 9 taps (im2col-free, no re-fetch per tap).
+//
+//   conv_n16_kernel<C>      forward / data gradient, C = 16 or 32 input channels: per 16-pixel tile and tap ONE ds_read_b128 feeds 4 MFMAs
+//                           (lane (pixel p, quarter g) reads channels 4g..4g+3; MFMA j contracts channels {4g+j}: a k-permutation, legal
+//                           because the filter registers use the same pairing).  Pixel stride C+4 floats: 16-byte slot 5p+g (C = 16) /
+//                           9p+g (C = 32) is a bijection over each 16-lane group -> conflict-free.  Epilogue = conv_igemm's (dropout,
+//                           fused inference BN + shortcut + leaky-ReLU, residual add).
+//   wgrad_n16_kernel<C>     filter gradient: dW[(tap, c)][k] = sum_p x[p + tap][c] * dy[p][k] with M = 16 channels of one tap, N = 16
+//                           filters, K = 4 pixels per MFMA; x from the same LDS patch, dy straight from memory (64 lanes = 4 pixels x 16
+//                           filters = 256 contiguous bytes); per-workgroup partials are summed by splitk_reduce_many_kernel (fixed order).
+#include "conv_common.h"
+
+using namespace pnpconv;
+
+namespace {
+
+constexpr int TH = 8, TW = 32;             // output tile of a workgroup; wave w owns rows 2w, 2w+1 = four 16-pixel MFMA tiles
+constexpr int PH = TH + 2, PW = TW + 2;    // input patch (3x3, dilation 1)
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// input patch of the tile at (n, oh0, ow0) -> LDS [PH*PW pixels][C + 4]; pixels outside the image are zeros (TF zero padding)
+template <int C, int LD>
+__device__ __forceinline__ void load_patch(const ConvArgs& a, __amdgpu_buffer_rsrc_t rx, float* __restrict__ lds, int n, int oh0, int ow0, int t) {
+    constexpr int CQ = C / 4;
+    for (int i = t; i < PH * PW * CQ; i += 256) {
+        const int pix = i / CQ, cq = i - pix * CQ;
+        const int py = pix / PW, px = pix - py * PW;
+        const int ih = oh0 - a.pad_t + py, iw = ow0 - a.pad_l + px;
+        const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+        const f32x4 v = bload4(rx, ok ? (unsigned)((((n * a.H + ih) * a.W + iw) * C + 4 * cq) * 4) : OOB);
+        *reinterpret_cast<f32x4*>(lds + pix * LD + 4 * cq) = v;
+    }
+}
+
+// ---- forward / data gradient: y[n, oh, ow, 0..15] -------------------------------------------------------------------------------------
+// grid = (column-tile groups, row tiles, images); a workgroup walks `tiles_per_wg` consecutive 32-pixel column tiles of its row band so that
+// the filter registers (and the launch) are paid once per several tiles.  KIND only names the launch for the profiler (0 fwd, 1 dgrad).
+template <int C, int KIND>
+__global__ void __launch_bounds__(256) conv_n16_kernel(ConvArgs a, int tiles_w, int tiles_per_wg) {
+    constexpr int LD = C + 4, NH = C / 16;
+    __shared__ __attribute__((aligned(16))) float lds[PH * PW * LD];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int p = lane & 15, g = lane >> 4;
+    const int n = blockIdx.z, oh0 = blockIdx.y * TH;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+
+    // filters: lane (g, k = p) holds w[tap][16h + 4g + j][k] for every (tap, h, j)
+    float wreg[9][NH][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wreg[tap][h][j] = a.w[(tap * C + 16 * h + 4 * g + j) * 16 + p];
+
+    const int jt0 = blockIdx.x * tiles_per_wg;
+    for (int jt = jt0; jt < jt0 + tiles_per_wg && jt < tiles_w; ++jt) {
+        const int ow0 = jt * TW;
+        __syncthreads();                                   // the previous tile's fragment reads are done
+        load_patch<C, LD>(a, rx, lds, n, oh0, ow0, t);
+        __syncthreads();
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int r = tap / 3, s = tap % 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                  // tile q: row 2*wave + q/2, columns 16*(q%2) .. +15
+                const int pix = (2 * wave + (q >> 1) + r) * PW + 16 * (q & 1) + p + s;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(lds + pix * LD + 16 * h + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[q] = mfma16(av[j], wreg[tap][h][j], acc[q]);
+                }
+            }
+        }
+        // epilogue: lane holds rows (pixels) 4g+i, column (filter) p of each tile
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oh = oh0 + 2 * wave + (q >> 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ow = ow0 + 16 * (q & 1) + 4 * g + i;
+                if (oh < a.OH && ow < a.OW) {
+                    const int m = (n * a.OH + oh) * a.OW + ow;
+                    const size_t idx = (size_t)m * 16 + p;
+                    float v = acc[q][i];
+                    if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                    if (a.res_add) v += a.res_add[idx];
+                    if (a.ep_scale) v = bn_epilogue(a, v, m, p);
+                    a.y[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- filter gradient ---------------------------------------------------------------------------------------------------------------------
+// a.x = x [N,H,W,C], a.w = dy [N,OH,OW,16], a.y = partials [gridDim.x][9*C][16].  A workgroup walks the tiles t = blockIdx.x, +gridDim.x, ...
+// of the linearised (image, row band, column tile) list; its four waves each own 2 rows of a tile and are summed through LDS at the end.
+template <int C>
+__global__ void __launch_bounds__(256) wgrad_n16_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles) {
+    // pixel stride of the patch: the A fragments are ds_read_b32 of 16 consecutive channels x 4 consecutive pixels: 16g + p (C = 16) and
+    // 48g + p (C = 32) hit 64 distinct banks
+    constexpr int LD = (C == 16) ? 16 : 48, NC = C / 16, NT = 9 * NC;      // NT accumulator tiles (tap, 16-channel group) of 16 x 16
+    constexpr int LDSF = PH * PW * LD > NT * 256 ? PH * PW * LD : NT * 256;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int p = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.w, a.w_bytes);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int jt = tile % tiles_w, rest = tile / tiles_w;
+        const int it = rest % tiles_h, n = rest / tiles_h;
+        const int oh0 = it * TH, ow0 = jt * TW;
+        __syncthreads();
+        load_patch<C, LD>(a, rx, lds, n, oh0, ow0, t);
+        __syncthreads();
+        // 16 groups of 4 consecutive pixels per wave: row 2*wave + q/8, columns 4*(q%8) .. +3; lane quarter g = pixel within the group
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int row = 2 * wave + (q >> 3), col = 4 * (q & 7) + g;
+            const int oh = oh0 + row, ow = ow0 + col;
+            // B operand: dy[pixel g of the group][filter p]; pixels outside the image contribute zeros
+            const bool ok = (oh < a.OH) & (ow < a.OW);
+            const float dyv = bload1(rdy, ok ? (unsigned)((((n * a.OH + oh) * a.OW + ow) * 16 + p) * 4) : OOB);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int pix = (row + tap / 3) * PW + col + tap % 3;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float xv = lds[pix * LD + 16 * c + p];      // A operand: x[pixel g + tap shift][channel 16c + p]
+                    acc[tap * NC + c] = mfma16(xv, dyv, acc[tap * NC + c]);
+                }
+            }
+        }
+    }
+    // the four waves' accumulators are summed through LDS one wave after the other (fixed order), then one partial per workgroup:
+    // lane (g, p) of tile (tap, c) holds rows m' = tap*C + 16c + 4g + k (k = 0..3), column p
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                f32x4* slot = reinterpret_cast<f32x4*>(lds + (i * 64 + lane) * 4);
+                if (w == 0) *slot = acc[i];
+                else {
+                    f32x4 v = *slot;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += acc[i][k];
+                    *slot = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* out = a.y + (size_t)blockIdx.x * (9 * C * 16);
+    for (int e = t; e < NT * 64; e += 256) {
+        const int i = e >> 6, l = e & 63;
+        const f32x4 s = *reinterpret_cast<const f32x4*>(lds + (i * 64 + l) * 4);
+        const int tap = i / NC, c = i - tap * NC, lp = l & 15, lg = l >> 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[(size_t)(tap * C + 16 * c + 4 * lg + k) * 16 + lp] = s[k];
+    }
+}
+
+}  // namespace
+
+namespace pnpconv {
+
+bool n16_geom_ok(const pnp_conv_geom* g) {
+    static const int off = getenv("PNP_CONV_NON16") ? 1 : 0;
+    if (off || g->K != 16 || (g->C != 16 && g->C != 32) || g->R != 3 || g->S != 3 || g->stride != 1 || g->dil != 1) return false;
+    if (g->pad_mode != PNP_PAD_ZERO || g->pad_t > 1 || g->pad_l > 1 || g->dtype != PNP_DTYPE_F32) return false;
+    if (g->OH != g->H + 2 * g->pad_t - 2 || g->OW != g->W + 2 * g->pad_l - 2) return false;
+    return (long long)g->N * g->OH * g->OW >= 8192 && g->N <= 65535;
+}
+
+int launch_n16_fwd(const ConvArgs& a, int kind, hipStream_t st) {
+    const int tiles_w = pnp_cdiv(a.OW, TW), tiles_h = pnp_cdiv(a.OH, TH);
+    // ~8 workgroup slots per CU x 256 CUs: walk several column tiles per workgroup once there are more tiles than that
+    int tpw = 1;
+    while (tpw < tiles_w && (long long)pnp_cdiv(tiles_w, tpw) * tiles_h * a.N > 4096) tpw *= 2;
+    dim3 grid((unsigned)pnp_cdiv(tiles_w, tpw), (unsigned)tiles_h, (unsigned)a.N);
+    PnpProfScope ps(kind == 0 ? PNP_PROF_CONV_FWD : PNP_PROF_CONV_DGRAD, st, conv_flops(a), conv_bytes(a), "conv_n16_kernel<%d, %d>", a.C, kind);
+    if (a.C == 16 && kind == 0) hipLaunchKernelGGL((conv_n16_kernel<16, 0>), grid, dim3(256), 0, st, a, tiles_w, tpw);
+    else if (a.C == 16) hipLaunchKernelGGL((conv_n16_kernel<16, 1>), grid, dim3(256), 0, st, a, tiles_w, tpw);
+    else if (kind == 0) hipLaunchKernelGGL((conv_n16_kernel<32, 0>), grid, dim3(256), 0, st, a, tiles_w, tpw);
+    else hipLaunchKernelGGL((conv_n16_kernel<32, 1>), grid, dim3(256), 0, st, a, tiles_w, tpw);
+    PNP_CHECK_LAUNCH("conv_n16_kernel");
+    return PNP_OK;
+}
+
+int n16_wgrad_blocks(const pnp_conv_geom* g) {
+    const long long ntiles = (long long)pnp_cdiv(g->OW, TW) * pnp_cdiv(g->OH, TH) * g->N;
+    return (int)(ntiles < 1024 ? ntiles : 1024);
+}
+
+// partials: [n16_wgrad_blocks][9*C][16] floats in `part`
+int launch_n16_wgrad(const ConvArgs& a, float* part, hipStream_t st) {
+    const int tiles_w = pnp_cdiv(a.OW, TW), tiles_h = pnp_cdiv(a.OH, TH);
+    const long long ntiles = (long long)tiles_w * tiles_h * a.N;
+    const int nblk = (int)(ntiles < 1024 ? ntiles : 1024);
+    ConvArgs b = a;
+    b.y = part;
+    PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "wgrad_n16_kernel<%d>", a.C);
+    if (a.C == 16) hipLaunchKernelGGL((wgrad_n16_kernel<16>), dim3((unsigned)nblk), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
+    else hipLaunchKernelGGL((wgrad_n16_kernel<32>), dim3((unsigned)nblk), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
+    PNP_CHECK_LAUNCH("wgrad_n16_kernel");
+    return PNP_OK;
+}
+
+}  // namespace pnpconv
