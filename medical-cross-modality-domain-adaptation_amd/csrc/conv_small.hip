@@ -180,13 +180,143 @@ __global__ void __launch_bounds__(256) wgrad_n16_kernel(ConvArgs a, int tiles_w,
     }
 }
 
+// ---- the first layer: 3 input channels (source_segmenter.py:93, adversarial.py:132) -----------------------------------------------------
+// Reduction 27 = 9 taps x 3 channels: 7 MFMA k-steps of 4 (the 28th product is a zero filter row).  The patch keeps 4 floats per pixel
+// (the image's 3 + a zero); k index kk = 4*step + g -> (tap, channel) = (kk / 3, kk % 3), i.e. each lane quarter reads its own tap: one
+// ds_read_b32 per MFMA at a per-lane offset fixed for the whole kernel.  28 MFMAs per 64 pixels: the kernel is a streaming pass (12.6 MB
+// in, 67 MB out at 256^2, B = 16), which is the point — the 32x32-tile kernel spent 0.13 ms on it (7 TF/s).
+__device__ __forceinline__ void load_patch3(const ConvArgs& a, __amdgpu_buffer_rsrc_t rx, float* __restrict__ lds, int n, int oh0, int ow0, int t) {
+    for (int i = t; i < PH * PW; i += 256) {
+        const int py = i / PW, px = i - py * PW;
+        const int ih = oh0 - a.pad_t + py, iw = ow0 - a.pad_l + px;
+        const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+        const unsigned off = ok ? (unsigned)((((n * a.H + ih) * a.W + iw) * 3) * 4) : OOB;
+        f32x4 v;
+        v[0] = bload1(rx, off);
+        v[1] = bload1(rx, ok ? off + 4u : OOB);
+        v[2] = bload1(rx, ok ? off + 8u : OOB);
+        v[3] = 0.f;
+        *reinterpret_cast<f32x4*>(lds + i * 4) = v;
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) conv_c3n16_kernel(ConvArgs a, int tiles_w, int tiles_per_wg) {
+    __shared__ __attribute__((aligned(16))) float lds[PH * PW * 4];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int p = lane & 15, g = lane >> 4;
+    const int n = blockIdx.z, oh0 = blockIdx.y * TH;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    float wreg[7];
+    int aoff[7];                       // LDS float offset of (tap, channel) of this lane's k index in step i
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int kk = 4 * i + g;
+        const int tap = kk < 27 ? kk / 3 : 0, c = kk < 27 ? kk - 3 * (kk / 3) : 3;      // kk = 27: the zero column of pixel 0, zero filter
+        wreg[i] = kk < 27 ? a.w[kk * 16 + p] : 0.f;
+        aoff[i] = ((tap / 3) * PW + tap % 3) * 4 + c;
+    }
+    const int jt0 = blockIdx.x * tiles_per_wg;
+    for (int jt = jt0; jt < jt0 + tiles_per_wg && jt < tiles_w; ++jt) {
+        const int ow0 = jt * TW;
+        __syncthreads();
+        load_patch3(a, rx, lds, n, oh0, ow0, t);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int base = ((2 * wave + (q >> 1)) * PW + 16 * (q & 1) + p) * 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 7; ++i) acc = mfma16(lds[base + aoff[i]], wreg[i], acc);
+            const int oh = oh0 + 2 * wave + (q >> 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ow = ow0 + 16 * (q & 1) + 4 * g + i;
+                if (oh < a.OH && ow < a.OW) {
+                    const int m = (n * a.OH + oh) * a.OW + ow;
+                    const size_t idx = (size_t)m * 16 + p;
+                    float v = acc[i];
+                    if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                    if (a.res_add) v += a.res_add[idx];
+                    if (a.ep_scale) v = bn_epilogue(a, v, m, p);
+                    a.y[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+// filter gradient of the first layer: dW[27][16]; rows m' = (tap, channel) = 16T + p for T = 0, 1 (rows 27..31 are padding, never written)
+__global__ void __launch_bounds__(256) wgrad_c3n16_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float lds[PH * PW * 4 > 2 * 256 ? PH * PW * 4 : 2 * 256];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int p = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.w, a.w_bytes);
+    int aoff[2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        const int mm = 16 * T + p;
+        const int tap = mm < 27 ? mm / 3 : 0, c = mm < 27 ? mm - 3 * (mm / 3) : 3;
+        aoff[T] = ((tap / 3) * PW + tap % 3) * 4 + c;
+    }
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int jt = tile % tiles_w, rest = tile / tiles_w;
+        const int it = rest % tiles_h, n = rest / tiles_h;
+        const int oh0 = it * TH, ow0 = jt * TW;
+        __syncthreads();
+        load_patch3(a, rx, lds, n, oh0, ow0, t);
+        __syncthreads();
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int row = 2 * wave + (q >> 3), col = 4 * (q & 7) + g;
+            const int oh = oh0 + row, ow = ow0 + col;
+            const bool ok = (oh < a.OH) & (ow < a.OW);
+            const float dyv = bload1(rdy, ok ? (unsigned)((((n * a.OH + oh) * a.OW + ow) * 16 + p) * 4) : OOB);
+            const int base = (row * PW + col) * 4;
+            acc[0] = mfma16(lds[base + aoff[0]], dyv, acc[0]);
+            acc[1] = mfma16(lds[base + aoff[1]], dyv, acc[1]);
+        }
+    }
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4* slot = reinterpret_cast<f32x4*>(lds + (i * 64 + lane) * 4);
+                if (w == 0) *slot = acc[i];
+                else {
+                    f32x4 v = *slot;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += acc[i][k];
+                    *slot = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* out = a.y + (size_t)blockIdx.x * (27 * 16);
+    if (t < 128) {
+        const int i = t >> 6, l = t & 63;
+        const f32x4 s = *reinterpret_cast<const f32x4*>(lds + (i * 64 + l) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int mm = 16 * i + 4 * (l >> 4) + k;
+            if (mm < 27) out[mm * 16 + (l & 15)] = s[k];
+        }
+    }
+}
+
 }  // namespace
 
 namespace pnpconv {
 
 bool n16_geom_ok(const pnp_conv_geom* g) {
     static const int off = getenv("PNP_CONV_NON16") ? 1 : 0;
-    if (off || g->K != 16 || (g->C != 16 && g->C != 32) || g->R != 3 || g->S != 3 || g->stride != 1 || g->dil != 1) return false;
+    if (off || g->K != 16 || (g->C != 16 && g->C != 32 && g->C != 3) || g->R != 3 || g->S != 3 || g->stride != 1 || g->dil != 1) return false;
     if (g->pad_mode != PNP_PAD_ZERO || g->pad_t > 1 || g->pad_l > 1 || g->dtype != PNP_DTYPE_F32) return false;
     if (g->OH != g->H + 2 * g->pad_t - 2 || g->OW != g->W + 2 * g->pad_l - 2) return false;
     return (long long)g->N * g->OH * g->OW >= 8192 && g->N <= 65535;
@@ -198,8 +328,11 @@ int launch_n16_fwd(const ConvArgs& a, int kind, hipStream_t st) {
     int tpw = 1;
     while (tpw < tiles_w && (long long)pnp_cdiv(tiles_w, tpw) * tiles_h * a.N > 4096) tpw *= 2;
     dim3 grid((unsigned)pnp_cdiv(tiles_w, tpw), (unsigned)tiles_h, (unsigned)a.N);
-    PnpProfScope ps(kind == 0 ? PNP_PROF_CONV_FWD : PNP_PROF_CONV_DGRAD, st, conv_flops(a), conv_bytes(a), "conv_n16_kernel<%d, %d>", a.C, kind);
-    if (a.C == 16 && kind == 0) hipLaunchKernelGGL((conv_n16_kernel<16, 0>), grid, dim3(256), 0, st, a, tiles_w, tpw);
+    PnpProfScope ps(kind == 0 ? PNP_PROF_CONV_FWD : PNP_PROF_CONV_DGRAD, st, conv_flops(a), conv_bytes(a), "%s<%d, %d>",
+                    a.C == 3 ? "conv_c3n16_kernel" : "conv_n16_kernel", a.C, kind);
+    if (a.C == 3 && kind == 0) hipLaunchKernelGGL((conv_c3n16_kernel<0>), grid, dim3(256), 0, st, a, tiles_w, tpw);
+    else if (a.C == 3) hipLaunchKernelGGL((conv_c3n16_kernel<1>), grid, dim3(256), 0, st, a, tiles_w, tpw);
+    else if (a.C == 16 && kind == 0) hipLaunchKernelGGL((conv_n16_kernel<16, 0>), grid, dim3(256), 0, st, a, tiles_w, tpw);
     else if (a.C == 16) hipLaunchKernelGGL((conv_n16_kernel<16, 1>), grid, dim3(256), 0, st, a, tiles_w, tpw);
     else if (kind == 0) hipLaunchKernelGGL((conv_n16_kernel<32, 0>), grid, dim3(256), 0, st, a, tiles_w, tpw);
     else hipLaunchKernelGGL((conv_n16_kernel<32, 1>), grid, dim3(256), 0, st, a, tiles_w, tpw);
@@ -219,8 +352,9 @@ int launch_n16_wgrad(const ConvArgs& a, float* part, hipStream_t st) {
     const int nblk = (int)(ntiles < 1024 ? ntiles : 1024);
     ConvArgs b = a;
     b.y = part;
-    PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "wgrad_n16_kernel<%d>", a.C);
-    if (a.C == 16) hipLaunchKernelGGL((wgrad_n16_kernel<16>), dim3((unsigned)nblk), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
+    PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "%s<%d>", a.C == 3 ? "wgrad_c3n16_kernel" : "wgrad_n16_kernel", a.C);
+    if (a.C == 3) hipLaunchKernelGGL(wgrad_c3n16_kernel, dim3((unsigned)nblk), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
+    else if (a.C == 16) hipLaunchKernelGGL((wgrad_n16_kernel<16>), dim3((unsigned)nblk), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
     else hipLaunchKernelGGL((wgrad_n16_kernel<32>), dim3((unsigned)nblk), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
     PNP_CHECK_LAUNCH("wgrad_n16_kernel");
     return PNP_OK;

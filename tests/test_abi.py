@@ -105,9 +105,9 @@ def test_host_planners_through_the_workspace_queries(built):
     # 16 -> 16 channels at 256^2: the 16x16x4-MFMA filter gradient (conv_small.hip), one partial per workgroup, 1024 workgroups
     g1 = geo(16, 256, 16, 16, 3)
     assert wgr(g1) == 1024 * 3 * 3 * 16 * 16 * 4
-    # direct (vector-ALU) filter gradient for the other K <= 16 layers: one partial per workgroup (2048 slabs)
-    g1a = geo(16, 256, 3, 16, 3)
-    assert wgr(g1a) == 2048 * 3 * 3 * 3 * 16 * 4
+    g1a = geo(16, 256, 3, 16, 3)          # the first layer (3 input channels) likewise
+    assert wgr(g1a) == 1024 * 3 * 3 * 3 * 16 * 4
+    # (the direct vector-ALU filter gradient keeps the other K <= 16 layers: one partial per workgroup, 2048 slabs — `logits` below)
     logits = K.conv_geom((16, 260, 260, 40), (5, 5, 40, 5), 1, 1, "VALID")
     assert wgr(logits) == 2048 * 5 * 5 * 40 * 5 * 4
     assert lib.pnp_conv2d_dgrad_workspace_bytes(None) == 0 and lib.pnp_conv2d_fwd_workspace_bytes(None) == 0
