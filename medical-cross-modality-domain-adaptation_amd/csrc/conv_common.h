@@ -233,6 +233,7 @@ bool launch_wgrad_bf16(const ConvArgs& a, int tile, dim3 grid, hipStream_t st);
 // 3x3 stride-1 convolutions with exactly 16 output channels and 16 / 32 input channels on the 16x16x4 MFMA (conv_small.hip): forward,
 // data gradient (kind 1; honours res_add) and filter gradient (per-workgroup partials [n16_wgrad_blocks][9*C][16] -> splitk_reduce_many)
 bool n16_geom_ok(const pnp_conv_geom* g);
+bool n16_wgrad_ok(const pnp_conv_geom* g);       // superset: filter gradients of 16/32 -> 32/64 channel layers too
 int launch_n16_fwd(const ConvArgs& a, int kind, hipStream_t st);
 int n16_wgrad_blocks(const pnp_conv_geom* g);
 int launch_n16_wgrad(const ConvArgs& a, float* part, hipStream_t st);

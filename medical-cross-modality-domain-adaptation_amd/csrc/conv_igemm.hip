@@ -1776,7 +1776,7 @@ int launch_wgd(const WgdArgs& a, const WgdPlan& pl, hipStream_t st) {
 
 size_t wgrad_ws(const pnp_conv_geom* g) {
     const size_t nout = (size_t)g->R * g->S * g->C * g->K;
-    if (n16_geom_ok(g)) return (size_t)n16_wgrad_blocks(g) * nout * sizeof(float);
+    if (n16_wgrad_ok(g)) return (size_t)n16_wgrad_blocks(g) * nout * sizeof(float);
     const long long P = (long long)g->N * g->OH * g->OW;
     const int bn = ((g->K & 3) != 0 || g->K <= 32) ? 32 : (g->K > 64 ? 128 : 64);
     const int nblk = pnp_cdiv((long long)g->R * g->S * g->C, 128) * pnp_cdiv(g->K, bn);
@@ -2156,7 +2156,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, const pnp_conv
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     if (!ws) workspace_bytes = 0;
-    if (n16_geom_ok(g) && workspace_bytes >= wgrad_ws(g)) {
+    if (n16_wgrad_ok(g) && workspace_bytes >= wgrad_ws(g)) {
         if (int e = launch_n16_wgrad(a, ws, st)) return e;
         const size_t nout = (size_t)a.Kred * a.K;
         hipLaunchKernelGGL(splitk_reduce_many_kernel, dim3((unsigned)pnp_cdiv((long long)nout, 64)), dim3(1024), 0, st,

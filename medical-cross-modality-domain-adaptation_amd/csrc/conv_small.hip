@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) conv_n16_kernel(ConvArgs a, int tiles_w, 
 }
 
 // ---- filter gradient ---------------------------------------------------------------------------------------------------------------------
-// a.x = x [N,H,W,C], a.w = dy [N,OH,OW,16], a.y = partials [gridDim.x][9*C][16].  A workgroup walks the tiles t = blockIdx.x, +gridDim.x, ...
+// a.x = x [N,H,W,C], a.w = dy [N,OH,OW,K], a.y = partials [gridDim.x][9*C][K]; blockIdx.y = 16-filter group.  A workgroup walks the tiles t = blockIdx.x, +gridDim.x, ...
 // of the linearised (image, row band, column tile) list; its four waves each own 2 rows of a tile and are summed through LDS at the end.
 template <int C>
 __global__ void __launch_bounds__(256) wgrad_n16_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles) {
@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(256) wgrad_n16_kernel(ConvArgs a, int tiles_w,
     const int p = lane & 15, g = lane >> 4;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.w, a.w_bytes);
+    const int kg0 = blockIdx.y * 16;         // this workgroup's 16 filters (K = 16, 32, 64: the input patch is re-staged per filter group)
     f32x4 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(256) wgrad_n16_kernel(ConvArgs a, int tiles_w,
             const int oh = oh0 + row, ow = ow0 + col;
             // B operand: dy[pixel g of the group][filter p]; pixels outside the image contribute zeros
             const bool ok = (oh < a.OH) & (ow < a.OW);
-            const float dyv = bload1(rdy, ok ? (unsigned)((((n * a.OH + oh) * a.OW + ow) * 16 + p) * 4) : OOB);
+            const float dyv = bload1(rdy, ok ? (unsigned)((((n * a.OH + oh) * a.OW + ow) * a.K + kg0 + p) * 4) : OOB);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int pix = (row + tap / 3) * PW + col + tap % 3;
@@ -170,13 +171,13 @@ __global__ void __launch_bounds__(256) wgrad_n16_kernel(ConvArgs a, int tiles_w,
         }
     }
     __syncthreads();
-    float* out = a.y + (size_t)blockIdx.x * (9 * C * 16);
+    float* out = a.y + (size_t)blockIdx.x * (9 * C * a.K) + kg0;
     for (int e = t; e < NT * 64; e += 256) {
         const int i = e >> 6, l = e & 63;
         const f32x4 s = *reinterpret_cast<const f32x4*>(lds + (i * 64 + l) * 4);
         const int tap = i / NC, c = i - tap * NC, lp = l & 15, lg = l >> 4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) out[(size_t)(tap * C + 16 * c + 4 * lg + k) * 16 + lp] = s[k];
+        for (int k = 0; k < 4; ++k) out[(size_t)(tap * C + 16 * c + 4 * lg + k) * a.K + lp] = s[k];
     }
 }
 
@@ -340,22 +341,39 @@ int launch_n16_fwd(const ConvArgs& a, int kind, hipStream_t st) {
     return PNP_OK;
 }
 
+// filter gradient: also 32 / 64 filters (one workgroup column per 16 of them) when the input has 16 or 32 channels — group_2's and
+// group_3's first convolutions, whose 9*C-row gradients are too small for the 128-row tiles of conv_wgrad_kernel (20-30 TF/s there)
+bool n16_wgrad_ok(const pnp_conv_geom* g) {
+    if (n16_geom_ok(g)) return true;
+    static const int off = getenv("PNP_CONV_NON16") ? 1 : 0;
+    if (off || (g->K != 32 && g->K != 64) || (g->C != 16 && g->C != 32) || g->R != 3 || g->S != 3 || g->stride != 1 || g->dil != 1) return false;
+    if (g->pad_mode != PNP_PAD_ZERO || g->pad_t > 1 || g->pad_l > 1 || g->dtype != PNP_DTYPE_F32) return false;
+    if (g->OH != g->H + 2 * g->pad_t - 2 || g->OW != g->W + 2 * g->pad_l - 2) return false;
+    return (long long)g->N * g->OH * g->OW >= 8192;
+}
+
 int n16_wgrad_blocks(const pnp_conv_geom* g) {
     const long long ntiles = (long long)pnp_cdiv(g->OW, TW) * pnp_cdiv(g->OH, TH) * g->N;
-    return (int)(ntiles < 1024 ? ntiles : 1024);
+    long long nb = ntiles < 1024 ? ntiles : 1024;
+    const long long cap = (8ll << 20) / ((long long)9 * g->C * g->K);          // partials of at most 32 MB
+    if (nb > cap) nb = cap;
+    return (int)(nb < 1 ? 1 : nb);
 }
 
 // partials: [n16_wgrad_blocks][9*C][16] floats in `part`
 int launch_n16_wgrad(const ConvArgs& a, float* part, hipStream_t st) {
     const int tiles_w = pnp_cdiv(a.OW, TW), tiles_h = pnp_cdiv(a.OH, TH);
     const long long ntiles = (long long)tiles_w * tiles_h * a.N;
-    const int nblk = (int)(ntiles < 1024 ? ntiles : 1024);
+    long long nb = ntiles < 1024 ? ntiles : 1024;
+    const long long cap = (8ll << 20) / ((long long)9 * a.C * a.K);
+    if (nb > cap) nb = cap;
+    const int nblk = (int)(nb < 1 ? 1 : nb);
     ConvArgs b = a;
     b.y = part;
     PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "%s<%d>", a.C == 3 ? "wgrad_c3n16_kernel" : "wgrad_n16_kernel", a.C);
     if (a.C == 3) hipLaunchKernelGGL(wgrad_c3n16_kernel, dim3((unsigned)nblk), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
-    else if (a.C == 16) hipLaunchKernelGGL((wgrad_n16_kernel<16>), dim3((unsigned)nblk), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
-    else hipLaunchKernelGGL((wgrad_n16_kernel<32>), dim3((unsigned)nblk), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
+    else if (a.C == 16) hipLaunchKernelGGL((wgrad_n16_kernel<16>), dim3((unsigned)nblk, (unsigned)(a.K / 16)), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
+    else hipLaunchKernelGGL((wgrad_n16_kernel<32>), dim3((unsigned)nblk, (unsigned)(a.K / 16)), dim3(256), 0, st, b, tiles_w, tiles_h, (int)ntiles);
     PNP_CHECK_LAUNCH("wgrad_n16_kernel");
     return PNP_OK;
 }

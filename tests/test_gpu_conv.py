@@ -55,6 +55,10 @@ CASES = [
     (2, 67, 65, 32, 48, 3, 2, 1, "SAME"),       # ring filter gradient walking a STRIDED output with odd extents (OW = 33)
     (1, 70, 70, 32, 64, 3, 2, 1, "VALID"),      # same, VALID: the last input row / column is never read (OW = 34)
     (2, 40, 72, 64, 64, 5, 2, 1, "SAME"),       # 5x5 stride 2 on the ring kernel (OW = 36), phases of the data gradient in one launch
+    (2, 64, 64, 32, 64, 3, 1, 1, "SAME"),       # 16x16x4-MFMA filter gradient with 4 filter groups (group_3's first conv)
+    (1, 96, 100, 32, 32, 3, 1, 1, "SAME"),      # same, ragged tiles (100 = 3 x 32 + 4), 2 filter groups; data gradient on conv_n16? no: K = 32
+    (2, 70, 66, 3, 16, 3, 1, 1, "SAME"),        # the first layer's MFMA kernels with ragged tiles
+    (2, 66, 70, 32, 16, 3, 1, 1, "VALID"),      # 32 -> 16 channels, VALID (the data gradient of a 16 -> 32 layer has this shape)
 ]
 
 
@@ -163,6 +167,7 @@ def test_conv_full_size_vs_naive_kernel(dev, shape):
 @pytest.mark.parametrize("shape", [
     (16, 32, 32, 512, 512, 3, 1, 1, "SAME"), (16, 32, 32, 512, 512, 3, 1, 2, "SAME"), (4, 32, 32, 512, 2560, 3, 1, 1, "SYMMETRIC"),
     (16, 256, 256, 3, 16, 3, 1, 1, "SAME"), (16, 256, 256, 16, 16, 3, 1, 1, "SAME"), (16, 260, 260, 40, 5, 5, 1, 1, "VALID"),
+    (16, 128, 128, 16, 32, 3, 1, 1, "SAME"), (16, 128, 128, 32, 32, 3, 1, 1, "SAME"), (16, 64, 64, 32, 64, 3, 1, 1, "SAME"),
     (16, 256, 256, 40, 5, 5, 1, 1, "SYMMETRIC"), (16, 256, 256, 64, 64, 3, 2, 1, "SAME"),
     (16, 128, 128, 128, 128, 5, 2, 1, "SAME"), (16, 64, 64, 256, 256, 3, 2, 1, "SAME"), (16, 16, 16, 512, 512, 5, 4, 1, "SAME"),
     (16, 4, 4, 512, 512, 3, 2, 1, "SYMMETRIC")])
