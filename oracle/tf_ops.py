@@ -322,3 +322,76 @@ def momentum_update(w, g, acc, lr, momentum):
     """tf.train.MomentumOptimizer: acc = momentum*acc + g; w -= lr*acc"""
     acc.mul_(momentum).add_(g)
     w -= lr * acc
+
+
+# ---- restatement of the lane arithmetic of csrc/conv_small.hip (16x16x4 fp32 MFMA tiles) ---------------------------------------------
+# Not a reference-side algorithm: the reference has no kernels.  It restates, in numpy, WHICH products each lane of a 64-wide wavefront
+# feeds to v_mfma_f32_16x16x4_f32 in conv_n16_kernel / wgrad_n16_kernel (operand layouts as the CDNA ISA defines them), so that the index
+# maps — the k-permutation of the channel quarters, the 8x32 output tile, the patch offsets — are pinned against the plain convolution on
+# the CPU (tests/test_host.py) and not only through the GPU parity tests.
+def _mfma_16x16x4(a_lane, b_lane, acc):
+    """a_lane[l] = A[m = l % 16][k = l // 16], b_lane[l] = B[k = l // 16][n = l % 16]; acc[4g + i][n] accumulates D (lane (g, n), register i)"""
+    A = a_lane.reshape(4, 16).T          # [m][k]
+    B = b_lane.reshape(4, 16)            # [k][n]
+    return acc + A @ B
+
+
+def conv3x3_n16_by_mfma_tiles(x, w, pad=1):
+    """x [N,H,W,C] (C = 16 or 32), w [3,3,C,16] float64 numpy -> y [N,OH,OW,16] computed tile by tile exactly like conv_n16_kernel:
+    workgroup tile 8 x 32 pixels, wave = 2 rows = four 16-pixel MFMA tiles, per tap and 16-channel half ONE 4-float read per lane
+    (lane (p, g): pixel p, channels 16h + 4g .. +3) feeding MFMAs j = 0..3 which contract the channels {16h + 4g + j : g = 0..3}."""
+    N, H, W, C = x.shape
+    OH, OW = H + 2 * pad - 2, W + 2 * pad - 2
+    xp = np.zeros((N, H + 2 * pad + 8, W + 2 * pad + 32, C))
+    xp[:, pad:pad + H, pad:pad + W] = x
+    y = np.zeros((N, OH, OW, 16))
+    lane = np.arange(64)
+    p, g = lane % 16, lane // 16
+    for n in range(N):
+        for oh0 in range(0, OH, 8):
+            for ow0 in range(0, OW, 32):
+                for wave in range(4):
+                    for q in range(4):
+                        row, col0 = 2 * wave + (q >> 1), 16 * (q & 1)
+                        acc = np.zeros((16, 16))
+                        for tap in range(9):
+                            r, s = tap // 3, tap % 3
+                            for h in range(C // 16):
+                                av = xp[n, oh0 + row + r, ow0 + col0 + p + s]          # [64 lanes][C]: the lane's patch pixel
+                                for j in range(4):
+                                    a_lane = av[lane, 16 * h + 4 * g + j]
+                                    b_lane = w[r, s, 16 * h + 4 * g + j, p]
+                                    acc = _mfma_16x16x4(a_lane, b_lane, acc)
+                        for gi in range(4):
+                            for i in range(4):
+                                oh, ow = oh0 + row, ow0 + col0 + 4 * gi + i
+                                if oh < OH and ow < OW:
+                                    y[n, oh, ow] = acc[4 * gi + i]
+    return y
+
+
+def wgrad3x3_n16_by_mfma_tiles(x, dy, pad=1):
+    """x [N,H,W,C] (C multiple of 16), dy [N,OH,OW,K] (K multiple of 16) -> dW [3,3,C,K] like wgrad_n16_kernel: M = 16 channels of a tap,
+    N = 16 filters, K-dimension of the MFMA = 4 consecutive pixels of a row (lane quarter g), accumulated over all pixel groups."""
+    N, H, W, C = x.shape
+    _, OH, OW, K = dy.shape
+    xp = np.zeros((N, H + 2 * pad + 8, W + 2 * pad + 32, C))
+    xp[:, pad:pad + H, pad:pad + W] = x
+    dyp = np.zeros((N, OH + 8, OW + 32, K))
+    dyp[:, :OH, :OW] = dy
+    dw = np.zeros((3, 3, C, K))
+    lane = np.arange(64)
+    p, g = lane % 16, lane // 16
+    for kg in range(K // 16):
+        for tap in range(9):
+            r, s = tap // 3, tap % 3
+            for c in range(C // 16):
+                acc = np.zeros((16, 16))
+                for n in range(N):
+                    for oh in range(0, OH):
+                        for ow0 in range(0, OW, 4):
+                            a_lane = xp[n, oh + r, ow0 + g + s, 16 * c + p]
+                            b_lane = dyp[n, oh, ow0 + g, 16 * kg + p]
+                            acc = _mfma_16x16x4(a_lane, b_lane, acc)
+                dw[r, s, 16 * c:16 * c + 16, 16 * kg:16 * kg + 16] = acc        # D[m = channel][n = filter]
+    return dw

@@ -445,3 +445,25 @@ def test_optimizer_state_travels_with_checkpoints(tmp_path):
     for k in before:
         moved = not np.array_equal(after[k], before[k])
         assert moved == (("group" in k or "output" in k) and "adapt" not in k and "cls" not in k), k
+
+
+def test_mfma_16x16x4_tile_restatement_of_the_small_convolutions():
+    """the lane / tile index maps of csrc/conv_small.hip (k-permuted channel quarters, 8x32 output tiles, 4-pixel reduction groups of
+    the filter gradient) restated in numpy equal the plain convolution and autograd's filter gradient, ragged extents included"""
+    rng = np.random.default_rng(3)
+    for (N, H, W, C, K, pad) in ((1, 9, 35, 16, 16, 1), (2, 8, 33, 32, 16, 1), (1, 12, 40, 16, 16, 0)):
+        x = rng.standard_normal((N, H, W, C))
+        w = rng.standard_normal((3, 3, C, K))
+        xt = torch.from_numpy(x)
+        wt = torch.from_numpy(w).requires_grad_(True)
+        ref = T.conv2d(xt, wt, 1, 1, "SAME" if pad else "VALID")
+        got = T.conv3x3_n16_by_mfma_tiles(x, w, pad)
+        assert got.shape == tuple(ref.shape) and np.allclose(got, ref.detach().numpy(), rtol=1e-11, atol=1e-11), (N, H, W, C, K, pad)
+        dy = rng.standard_normal(tuple(ref.shape))
+        ref.backward(torch.from_numpy(dy))
+        assert np.allclose(T.wgrad3x3_n16_by_mfma_tiles(x, dy, pad), wt.grad.numpy(), rtol=1e-11, atol=1e-10)
+    # 32 filters = two 16-filter workgroup columns of the filter gradient
+    x, dy = rng.standard_normal((1, 8, 34, 16)), rng.standard_normal((1, 8, 34, 32))
+    wt = torch.zeros((3, 3, 16, 32), dtype=torch.float64, requires_grad=True)
+    T.conv2d(torch.from_numpy(x), wt, 1, 1, "SAME").backward(torch.from_numpy(dy))
+    assert np.allclose(T.wgrad3x3_n16_by_mfma_tiles(x, dy, 1), wt.grad.numpy(), rtol=1e-11, atol=1e-10)
