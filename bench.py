@@ -14,7 +14,10 @@ all-reduced (RCCL).  Rank 0 prints ONE JSON line carrying
   * `roofline_kernels`  the same for every MFMA convolution symbol of the step (forward, data gradient, filter gradient);
   * `segmenter_step`    BASELINE configs[1] (source segmenter fwd + bwd + Adam, source_segmenter.py:484-489) timed the same way;
   * `cpu_baseline`      the CPU oracle's joint step (oracle/nets_adv.py, torch-CPU fp32) on this host's cores, bounded sample.
-`--workload segmenter` makes configs[1] the headline line instead (same contract).
+`--workload segmenter` makes configs[1] the headline line instead (same contract); `--dtype bf16` runs configs[4]'s arithmetic (a
+separate line, never the headline).  The joint workload starts from BN moving statistics calibrated on the synthetic batches (40
+untimed training-mode forwards) — the phase itself starts from a trained baseline checkpoint; with un-calibrated statistics the
+frozen-BN segmenter of the GAN steps is un-normalised and its random-filter activations overflow (see make_joint).
 """
 import argparse
 import glob

@@ -6,6 +6,10 @@ Fused units (what TF-1.4 lowers layers.py's chains to, restated as one forward +
   ConvBNActFn     : conv -> dropout -> batch_norm [-> + shortcut] [-> leaky_relu]
                     (layers.py:9-45 and the tails of residual_block / DR_block, 145-189)
   MaxPool2Fn, PSFn, SegLossFn, CriticInputFn
+
+Sums that TF's autodiff emits as AddN are done by the kernels, not by the engine: parameter gradients go straight into the
+variable's slot of the gradient arena (gradsink.py -> pnp_conv2d_wgrad_acc / pnp_bn_bwd_acc), the gradient arriving at a block input
+over the residual shortcut is added by the block's first data-gradient kernel (ResLink -> pnp_conv2d_dgrad_add).
 """
 import os
 
