@@ -395,3 +395,34 @@ def wgrad3x3_n16_by_mfma_tiles(x, dy, pad=1):
                             acc = _mfma_16x16x4(a_lane, b_lane, acc)
                 dw[r, s, 16 * c:16 * c + 16, 16 * kg:16 * kg + 16] = acc        # D[m = channel][n = filter]
     return dw
+
+
+def wgrad_ring_walk(N, H, W, C, OH, OW, stride, dil, pad_t, pad_l, r, s, c, p_first, nstages):
+    """The incremental input-coordinate walk of csrc/conv_igemm.hip::conv_wgrad_ring_kernel, restated: a loader row starts at output
+    pixel p_first and advances 32 output pixels per stage; (ih, iw, byte offset) of its filter tap (r, s) and channel c are carried with
+    one row wrap and one image wrap per step (needs OW >= 32).  Returns [(ok, offset)] per stage; `ok` False = the tap reads padding."""
+    BK = 32
+    OHW = OH * OW
+    l_dh, l_dw = r * dil - pad_t, s * dil - pad_l
+    iw_lim, ih_lim = OW * stride + l_dw, OH * stride + l_dh
+    step_w, step_off = BK * stride, BK * stride * C * 4
+    wrap_w, wrap_w_off = OW * stride, stride * (W - OW) * C * 4
+    wrap_h, wrap_h_off = OH * stride, (H - OH * stride) * W * C * 4
+    n = p_first // OHW
+    rem = p_first - n * OHW
+    oh, ow = rem // OW, rem % OW
+    ih, iw = oh * stride + l_dh, ow * stride + l_dw
+    off = (((n * H + ih) * W + iw) * C + c) * 4
+    out = []
+    for _ in range(nstages):
+        out.append((0 <= ih < H and 0 <= iw < W, off))
+        iw += step_w
+        off += step_off
+        if iw >= iw_lim:
+            iw -= wrap_w
+            ih += stride
+            off += wrap_w_off
+        if ih >= ih_lim:
+            ih -= wrap_h
+            off += wrap_h_off
+    return out

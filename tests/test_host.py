@@ -467,3 +467,42 @@ def test_mfma_16x16x4_tile_restatement_of_the_small_convolutions():
     wt = torch.zeros((3, 3, 16, 32), dtype=torch.float64, requires_grad=True)
     T.conv2d(torch.from_numpy(x), wt, 1, 1, "SAME").backward(torch.from_numpy(dy))
     assert np.allclose(T.wgrad3x3_n16_by_mfma_tiles(x, dy, 1), wt.grad.numpy(), rtol=1e-11, atol=1e-10)
+
+
+def test_ring_filter_gradient_coordinate_walk():
+    """conv_wgrad_ring_kernel carries (ih, iw, offset) of a loader row incrementally over the strided output walk; restated in
+    oracle.tf_ops.wgrad_ring_walk and held to the closed form for every stride / dilation / padding / tap / start pixel swept here
+    (the -m gpu tests can only afford a handful of geometries)"""
+    checked = 0
+    for stride in (1, 2, 3):
+        for dil in (1, 2):
+            for R in (1, 3, 5):
+                for (H, W) in ((40, 70), (33, 97), (64, 64), (35, 140)):
+                    for padding in ("SAME", "VALID"):
+                        eff = (R - 1) * dil + 1
+                        if padding == "SAME":
+                            OH, pt, _ = T.same_pad(H, R, stride, dil)
+                            OW, pl, _ = T.same_pad(W, R, stride, dil)
+                        else:
+                            if H < eff or W < eff:
+                                continue
+                            OH, OW, pt, pl = (H - eff) // stride + 1, (W - eff) // stride + 1, 0, 0
+                        if OW < 32:
+                            continue                      # the kernel's precondition (one row wrap per 32-pixel step)
+                        N, C = 3, 8
+                        P = N * OH * OW
+                        for (r, s, c) in ((0, 0, 0), (R - 1, R // 2, 4), (R // 2, R - 1, 4)):
+                            for p_first in (0, 7, 32 * 5 + 3, OH * OW - 1, OH * OW + 9):
+                                nst = (P - p_first + 31) // 32 + 2          # runs past the last pixel like the kernel's ring does
+                                walk = T.wgrad_ring_walk(N, H, W, C, OH, OW, stride, dil, pt, pl, r, s, c, p_first, nst)
+                                for k, (ok, off) in enumerate(walk):
+                                    p = p_first + 32 * k
+                                    n, rem = divmod(p, OH * OW)
+                                    oh, ow = divmod(rem, OW)
+                                    ih, iw = oh * stride - pt + r * dil, ow * stride - pl + s * dil
+                                    assert off == (((n * H + ih) * W + iw) * C + c) * 4, (stride, dil, R, H, W, padding, r, s, p_first, k)
+                                    assert ok == (0 <= ih < H and 0 <= iw < W)
+                                    if p >= P and ok:
+                                        assert off >= N * H * W * C * 4     # rows past the last pixel lie beyond x: hardware zero
+                                    checked += 1
+    assert checked > 50000
