@@ -796,8 +796,18 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
 #ifndef PNP_WGRAD_ABLATE
 #define PNP_WGRAD_ABLATE 0
 #endif
-template <int BM, int BN, int WM, int WN, int DEPTH>
+// UNI (opt-in, see launch_wgrad_tile): C % BM == 0, so a 128-row tile of the filter gradient holds ONE filter tap and the coordinates /
+// validity / offset of a loader row depend on the pixel only — they are wave-uniform and are carried in SGPRs by the scalar unit (a wave's
+// two half-waves load two consecutive pixels: two scalar rows per load, selected per lane).  The per-lane walk costs 1.45 VALU
+// instructions per MFMA (PMC), this form about 0.15.
+#ifndef PNP_WGRAD_UNIFORM_ROWS
+#define PNP_WGRAD_UNIFORM_ROWS 0
+#endif
+// (UNI is folded into the depth parameter — DEPTH_ = 10 + depth — so that the measured kernels keep their symbol names.)
+template <int BM, int BN, int WM, int WN, int DEPTH_>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a) {
+    constexpr bool UNI = DEPTH_ >= 10;
+    constexpr int DEPTH = UNI ? DEPTH_ - 10 : DEPTH_;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
@@ -848,6 +858,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a
         l_iw[i] = ow * a.stride + l_dw;
         l_off[i] = (((n * a.H + l_ih[i]) * a.W + l_iw[i]) * a.C + c_u) * 4;
     }
+    // UNI: the same walk per (pass i, half-wave h) in wave-uniform registers; the tile's tap and first channel are uniform too
+    static_assert(!UNI || (AC4 == 32 && ARP == 8), "UNI: a half-wave = one pixel row of 128 channels");
+    const int t_rs = mm0 / a.C, t_c0 = mm0 - t_rs * a.C;
+    const int t_r = t_rs / a.S, t_s = t_rs - t_r * a.S;
+    const int u_dh = t_r * a.dil - a.pad_t, u_dw = t_s * a.dil - a.pad_l;
+    const int u_iw_lim = a.OW * a.stride + u_dw, u_ih_lim = a.OH * a.stride + u_dh;
+    const unsigned lane_c = (unsigned)((t_c0 + 4 * acol) * 4);
+    int u_iw[ANP][2], u_ih[ANP][2], u_off[ANP][2];
+    if constexpr (UNI) {
+#pragma unroll
+        for (int i = 0; i < ANP; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p = c_begin * BK + 2 * wave + h + ARP * i;
+                const int n = p / a.OHW;
+                const int rem = p - n * a.OHW;
+                const int oh = rem / a.OW, ow = rem - oh * a.OW;
+                u_ih[i][h] = oh * a.stride + u_dh;
+                u_iw[i][h] = ow * a.stride + u_dw;
+                u_off[i][h] = (((n * a.H + u_ih[i][h]) * a.W + u_iw[i][h]) * a.C) * 4;
+            }
+    }
     // B rows (dy): constant per-thread offset inside a stage, the stage is the scalar offset
     const int bcol = t % BC4, brow = t / BC4;
     unsigned boff[BNP];
@@ -867,6 +899,25 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a
     auto gload = [&](Stage& st) {
 #pragma unroll
         for (int i = 0; i < ANP; ++i) {
+            if constexpr (UNI) {
+                unsigned so[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool ok = ((unsigned)u_ih[i][h] < (unsigned)a.H) & ((unsigned)u_iw[i][h] < (unsigned)a.W);
+                    so[h] = ok ? (unsigned)u_off[i][h] : OOB2;          // + lane_c (< 2 KiB) stays out of range: x < 2 GiB on this path
+                    u_iw[i][h] += step_w;
+                    u_off[i][h] += step_off;
+                    const bool ww = u_iw[i][h] >= u_iw_lim;
+                    u_iw[i][h] -= ww ? wrap_w : 0;
+                    u_ih[i][h] += ww ? a.stride : 0;
+                    u_off[i][h] += ww ? wrap_w_off : 0;
+                    const bool hw = u_ih[i][h] >= u_ih_lim;
+                    u_ih[i][h] -= hw ? wrap_h : 0;
+                    u_off[i][h] += hw ? wrap_h_off : 0;
+                }
+                st.a[i] = bload4(rx, ((lane & 32) ? so[1] : so[0]) + lane_c);
+                continue;
+            }
             if constexpr (PNP_WGRAD_ABLATE & 2) {          // timing experiment: the loads without their address arithmetic
                 st.a[i] = bload4(rx, (unsigned)l_off[i] & 0xFFFFFu);
                 continue;
@@ -1668,7 +1719,15 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
         const int depth = wgrad_ring_depth();
         PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "conv_wgrad_ring_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, depth);
         if constexpr (VECB) {
-            if (depth == 2) hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 2>), grid, dim3(NTHREADS), 0, st, a);
+            bool done = false;
+            if constexpr (PNP_WGRAD_UNIFORM_ROWS != 0 && BM == 128) {          // opt-in build: scalar loader rows where a tile holds one tap
+                if (depth == 2 && (a.C % BM) == 0) {
+                    hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 12>), grid, dim3(NTHREADS), 0, st, a);
+                    done = true;
+                }
+            }
+            if (done) {
+            } else if (depth == 2) hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 2>), grid, dim3(NTHREADS), 0, st, a);
             else hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 3>), grid, dim3(NTHREADS), 0, st, a);
         }
     } else {
