@@ -1,0 +1,132 @@
+"""-m gpu: teacher-forced per-kernel parity of the ADAPTATION graph (adversarial.py:127-443, 839-882).
+
+tests/test_gpu_teacher_forced.py pins every kernel of the source segmenter.  The units that exist only in the adaptation graph were held
+by adjoint identities and whole-step bands until now: the critics' strided k3 s2 / k5 s2 / k5 s4 convolutions with the stride-phase data
+gradient (one launch per phase, or `conv_dgrad_phases_kernel`), critic BN on batch statistics with filters used twice per step (CT and
+MR pass), `cls_6` / `m_cls_4` (SYMMETRIC, stride 2 / 4), the final matmuls, the critic-input assembly and its backward, PS at four
+channel counts, and — in the discriminator / generator steps — the segmenter with FROZEN BN through the fused `pnp_conv2d_fwd_bn`
+epilogue and its inference-mode backward (`pnp_bn_bwd_apply`), plus adapt_* in BN-training mode.
+
+The oracle runs the discriminator step graph and the generator step graph once each with the `units=` recorder; tests/teacher_forced.py
+then feeds every product kernel the oracle's own inputs and upstream gradient: 1e-4 of max|ref| per kernel.
+  * B=2 against the float64 oracle;
+  * B=16 (BASELINE batch: other tiles, reduction splits, phase groupings) — discriminator step against float32, generator step against
+    FLOAT64, whose gradients also adjudicate the whole-step generator comparison (HIP vs float64 next to CPU-float32 vs float64).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import nets_adv
+from teacher_forced import Checker, rel
+from test_gpu_adversarial import COST, NETCFG, _cos, he_state, make_vars
+
+pytestmark = pytest.mark.gpu
+KEEP = 0.75
+
+
+def _inputs(B, seed):
+    rng = np.random.default_rng(seed)
+    mr = rng.standard_normal((B, 256, 256, 3)).astype(np.float32)
+    ct = (rng.standard_normal((B, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32)
+    return mr, ct
+
+
+def _net(dev, B, seed):
+    adv = pkg("adversarial")
+    net = adv.Full_DRN(channels=3, n_class=5, batch_size=B, cost_kwargs=dict(COST), network_config=dict(NETCFG), device=dev, seed=seed)
+    sd = he_state(net, seed + 6)
+    net.store.load_state_dict(sd)
+    return net, sd
+
+
+def _dis_units(sd, mr, ct, dtype, seed):
+    V = make_vars(sd, dtype, lambda k: "cls" in k)
+    units = []
+    o = nets_adv.adv_forward(V, torch.from_numpy(mr).to(dtype), torch.from_numpy(ct).to(dtype), KEEP, seed=seed, segmenter_no_grad=True,
+                             units=units)
+    dis, _ = nets_adv.wgan_losses(o)
+    dis.backward()
+    return V, units, o, dis.detach()
+
+
+def _gen_units(sd, ct, dtype, seed, units=True):
+    V = make_vars(sd, dtype, lambda k: k.startswith("adapt_"))
+    rec = [] if units else None
+    o = nets_adv.adv_forward(V, None, torch.from_numpy(ct).to(dtype), KEEP, ct_front_bn=True, seed=seed, units=rec)
+    _, gen = nets_adv.wgan_losses(o)
+    gen.backward()
+    return V, rec, o, gen.detach()
+
+
+def _expect(units, dis):
+    kinds = [u["kind"] for u in units]
+    npass = 2 if dis else 1
+    assert kinds.count("conv") == npass * (21 + 12 + 16 + 8)       # front + shared half + feature critic + mask critic
+    assert kinds.count("fc") == npass * 2 and kinds.count("critic_input") == npass
+    assert kinds.count("ps") == npass * 5 and kinds.count("pool") == npass * 3
+
+
+DIS_FAMILIES = {"conv_fwd_bn_fused", "bn_bwd_train", "wgrad_s2_k3", "wgrad_s2_k5", "wgrad_s4_k5", "dgrad_s2_k3", "dgrad_s2_k5",
+                "dgrad_s4_k5", "fc", "critic_input_fwd", "ps", "maxpool"}
+GEN_FAMILIES = DIS_FAMILIES | {"bn_bwd_frozen", "critic_input_bwd", "wgrad_s1_k3", "dgrad_s1_k3", "dgrad_s1_k5"}
+
+
+def _check(dev, V, sd, units, seed, tag, families):
+    ck = Checker(dev, V, sd, seed, tag).run(units)
+    ck.report()
+    ck.assert_ok()
+    missing = families - ck.kernels
+    assert not missing, "kernel families never exercised: %s" % sorted(missing)
+    return ck
+
+
+def test_every_kernel_of_every_adaptation_unit_teacher_forced(dev):
+    """B=2 vs the float64 oracle: discriminator step graph (both domains, critics trained) and generator step graph"""
+    B = 2
+    mr, ct = _inputs(B, 0)
+    _, sd = _net(dev, B, 1)
+    V, units, _, _ = _dis_units(sd, mr, ct, torch.float64, 11)
+    _expect(units, True)
+    _check(dev, V, sd, units, 11, "dis B=2 vs float64", DIS_FAMILIES)
+    del V, units
+    V, units, _, _ = _gen_units(sd, ct, torch.float64, 12)
+    _expect(units, False)
+    _check(dev, V, sd, units, 12, "gen B=2 vs float64", GEN_FAMILIES)
+
+
+@pytest.mark.slow
+def test_every_kernel_of_every_adaptation_unit_teacher_forced_B16(dev):
+    """BASELINE batch.  Discriminator graph vs the float32 oracle; generator graph vs the FLOAT64 oracle, whose gradients then adjudicate
+    the whole generator step of the product (the B=16 band of test_joint_step_B16_vs_float32_oracle is float32 against float32)."""
+    B = 16
+    mr, ct = _inputs(B, 50)
+    net, sd = _net(dev, B, 2)
+    V, units, _, _ = _dis_units(sd, mr, ct, torch.float32, 21)
+    _check(dev, V, sd, units, 21, "dis B=16 vs float32", DIS_FAMILIES)
+    del V, units
+    V64, units, o64, gen64 = _gen_units(sd, ct, torch.float64, 22)
+    _check(dev, V64, sd, units, 22, "gen B=16 vs float64", GEN_FAMILIES)
+    g64 = {k: v.grad.clone() for k, v in V64.items() if v.requires_grad}
+    logits64 = o64["ct_logits"].detach()
+    del units, o64
+    # ---- whole generator step of the product and of the float32 CPU oracle, both against float64
+    V32, _, o32, gen32 = _gen_units(sd, ct, torch.float32, 22, units=False)
+    g32 = {k: v.grad.clone() for k, v in V32.items() if v.requires_grad}
+    net.store.load_state_dict(sd)
+    loss = net.gen_loss_and_grads(torch.from_numpy(ct).to(dev), KEEP, drop_seed=22)
+    g_hip = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if v.name.startswith("adapt_")}
+    rows = [(k, rel(g_hip[k], g64[k]), rel(g32[k], g64[k]), _cos(g_hip[k], g64[k]), _cos(g32[k], g64[k])) for k in g64]
+    eh, ec = np.array([r[1] for r in rows]), np.array([r[2] for r in rows])
+    print("gen B=16 whole step vs float64 over %d variables: hip median %.3e max %.3e min cosine %.8f | cpu-fp32 median %.3e max %.3e min cosine "
+          "%.8f | loss hip %.9f cpu32 %.9f fp64 %.9f | logits hip %.2e cpu32 %.2e" % (
+              len(rows), np.median(eh), eh.max(), min(r[3] for r in rows), np.median(ec), ec.max(), min(r[4] for r in rows), float(loss),
+              float(gen32), float(gen64), rel(net.ct_logits, logits64), rel(o32["ct_logits"], logits64)))
+    assert rel(net.ct_logits, logits64) < 1e-4
+    assert abs(float(loss) - float(gen64)) < 1e-4 * abs(float(gen64)) + 1e-8
+    # "same error class as another float32 evaluation of the graph": the product may not be further from float64 than a small multiple of
+    # what the float32 CPU oracle is (its own distance is pure evaluation-order noise amplified by leaky-ReLU / max-pool / dropout kinks)
+    assert np.median(eh) < 5.0 * np.median(ec) + 1e-4
+    assert eh.max() < max(3.0 * ec.max(), 1e-3)
+    assert min(r[3] for r in rows) > min(0.9999, 1.0 - 3.0 * (1.0 - min(r[4] for r in rows)))
