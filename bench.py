@@ -98,14 +98,16 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(workload, timed_steps=3):
-    """The CPU oracle (a port: TF-1.4 cannot run here) on this host's cores, same step definition as the GPU line, on a BOUNDED
-    sample: B=2 slices per domain, 1 warm-up step + `timed_steps` timed steps, median reported."""
+def cpu_baseline(workload, Bc=2, timed_steps=5, warm=2):
+    """The CPU oracle (a port: TF-1.4 cannot run here) on this host's cores, same step definition as the GPU line, timed as SURVEY.md
+    §8(d) prescribes — `warm` = 2 warm-up steps, median of `timed_steps` = 5 timed steps.  The default run BOUNDS the sample through the
+    batch: Bc = 2 slices per domain instead of 16 (the smallest batch the reference's PS accepts, ops.py:7), ~2 minutes of host time;
+    seven B = 16 steps would take ~6.  `--cpu-batch 16` runs the CPU path at the GPU line's own batch (the CPU path is more efficient
+    per slice there: oneDNN GEMMs are larger; DESIGN.md §5 quotes that measurement next to this one)."""
     # torch's default intra-op thread count honours the cgroup / affinity mask of the box (os.cpu_count() does not:
     # forcing 256 threads onto a restricted mask made this sample 50x slower)
     ncores = torch.get_num_threads()
     rng = np.random.default_rng(0)
-    Bc = 2
     times = []
     if workload == "segmenter":
         from oracle import nets
@@ -121,7 +123,7 @@ def cpu_baseline(workload, timed_steps=3):
                 state[k] = np.zeros(s, np.float32)
         V = nets.make_variables(state)
         opt = {}
-        for i in range(1 + timed_steps):
+        for i in range(warm + timed_steps):
             t0 = time.time()
             nets.segmenter_train_step(V, opt, x, y, 0.75, seed=1 + i, lr=1e-3, t=1 + i)
             times.append(time.time() - t0)
@@ -137,15 +139,15 @@ def cpu_baseline(workload, timed_steps=3):
         mr = torch.from_numpy(rng.standard_normal((Bc, 256, 256, 3)).astype(np.float32))
         ct = torch.from_numpy((rng.standard_normal((Bc, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32))
         ms_d, ms_g = {}, {}
-        for i in range(1 + timed_steps):
+        for i in range(warm + timed_steps):
             t0 = time.time()
             nets_adv.joint_train_step(V, ms_d, ms_g, mr, ct, 0.75, seed=1 + 2 * i)
             times.append(time.time() - t0)
         what = "oracle.nets_adv.joint_train_step (torch-CPU fp32 restatement of adversarial.py:839-882: 1 dis update + clip + 1 gen update)"
-    med = float(np.median(times[1:]))
+    med = float(np.median(times[warm:]))
     return {"value": Bc / med, "unit": "slices/s", "cores": ncores, "cpu_model": cpu_model(), "kind": "port",
-            "sample": "%s, B=%d per domain, 1 warm-up + %d timed steps, median %.2f s/step (all: %s)" % (
-                what, Bc, timed_steps, med, ", ".join("%.2f" % t for t in times))}
+            "sample": "%s, B=%d per domain (the GPU line runs B=16; default B=2 bounds the sample, DESIGN.md §5), %d warm-up + %d timed steps, "
+                      "median %.2f s/step (all: %s)" % (what, Bc, warm, timed_steps, med, ", ".join("%.2f" % t for t in times))}
 
 
 PROBE_STEPS = 2      # timed steps whose convolution launches carry HIP events (see timed_loop)
@@ -208,6 +210,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="slices per GPU (of each domain for the joint step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2, help="slices per domain of the cpu_baseline sample (default 2: bounded sample)")
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-warmup", type=int, default=2)
     ap.add_argument("--no-probe", action="store_true", help="no per-kernel HIP events (no roofline objects)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="skip the secondary workload's sub-record")
@@ -238,11 +243,14 @@ def main():
     x = torch.from_numpy(rng.standard_normal((B, 256, 256, 3)).astype(np.float32)).to(dev)
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
 
+    reducers = {}
+
     def make_segmenter():
         ss = importlib.import_module(PKG + ".source_segmenter")
         net = ss.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, cost_kwargs=dict(COST), seed=0, world_size=world)
         net.store.load_state_dict(he_state(net.store.state_dict()))
         reducer = par.GradReducer(net.store, overlap=not args.no_overlap) if world > 1 else None
+        reducers["segmenter"] = reducer
         tr = ss.Trainer(net, None, None, num_cls=5, batch_size=B, optimizer="adam", opt_kwargs={"learning_rate": 1e-3}, reducer=reducer)
         tr.opt = tr._get_optimizer(10)
         y = torch.from_numpy(one_hot(blob_labels(rng, B))).to(dev)
@@ -254,6 +262,7 @@ def main():
                            network_config=dict(GAN_NETCFG))
         net.store.load_state_dict(he_state(net.store.state_dict()))
         reducer = par.GradReducer(net.store, overlap=not args.no_overlap) if world > 1 else None
+        reducers["joint"] = reducer
         tr = adv.Trainer(net, None, None, None, None, num_cls=5, batch_size=B, opt_kwargs={"learning_rate": 3e-4},
                          train_config={"dis_sub_iter": 1, "gen_sub_iter": 1}, reducer=reducer)
         tr._get_optimizer()
@@ -268,6 +277,8 @@ def main():
 
         def step(i):
             tr.dis_step(x, ct, 0.75, 2 * (i * world + rank) + 1)
+            if reducer is not None:
+                step.comm_dis = (reducer.bytes_step, list(reducer.launch_log), reducer.exposed_time_ms() if reducer.measure_exposed else None)
             return tr.gen_step(ct, 0.75, 2 * (i * world + rank) + 2)
         return step
 
@@ -287,6 +298,28 @@ def main():
     step_fn = makers[args.workload]()
     el, lossv = timed_loop(step_fn, args.warmup, args.steps, world, dev, prof)
     rows = [] if args.no_probe else L.prof_summary()
+    comm = None
+    if world > 1:
+        # what the all-reduce moved and how much of it the step had to wait for: ONE extra, untimed step with an event pair around the
+        # compute stream's wait on the side stream (GradReducer.measure_exposed)
+        red = reducers[args.workload]
+        red.measure_exposed = True
+        step_fn(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        nc = par.native_comm()
+        comm = {"transport": par.transport(), "rccl_version": nc.version if nc is not None else None, "overlap": bool(red.overlap),
+                "buckets": len(red.buckets), "bucket_MB": [round((e - s_) * 4 / 1e6, 1) for s_, e in red.buckets],
+                "distinct_bucket_sets": len(red.sets_seen)}
+        if args.workload == "joint":
+            db, dlog, dexp = getattr(step_fn, "comm_dis", (None, None, None))
+            comm.update({"dis_step": {"allreduce_MB": db / 1e6 if db is not None else None, "launch_order": dlog, "exposed_ms": dexp},
+                         "gen_step": {"allreduce_MB": red.bytes_step / 1e6, "launch_order": list(red.launch_log),
+                                      "exposed_ms": red.exposed_time_ms()}})
+            comm["allreduce_MB_per_step"] = ((db or 0) + red.bytes_step) / 1e6
+        else:
+            comm.update({"allreduce_MB_per_step": red.bytes_step / 1e6, "launch_order": list(red.launch_log),
+                         "exposed_ms": red.exposed_time_ms()})
+        red.measure_exposed = False
     del step_fn
     sub = None
     if not args.no_sub:
@@ -302,7 +335,7 @@ def main():
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": names[args.workload][1], "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "final_loss": lossv, "comm": par.transport() if world > 1 else None},
+                       "final_loss": lossv, "comm": comm},
         }
         if rows:
             recs = roofline_records(rows, peak)
@@ -322,7 +355,7 @@ def main():
         if sub is not None:
             res["segmenter_step" if other == "segmenter" else "joint_step"] = sub
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.workload)
+            res["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps, args.cpu_warmup)
         print(json.dumps(res))
     if world > 1:
         par.shutdown()

@@ -81,7 +81,7 @@ class Full_DRN(object):
         if x.is_meta:
             return torch.empty((B, 1), device="meta")
         g = K.conv_geom((B, 1, 1, D), (1, 1, D, 1), 1, 1, "VALID")
-        y = Conv2dDropFn.apply(x.reshape(B, 1, 1, D), w.view(1, 1, D, 1), g, 1.0, 0, 0)
+        y = Conv2dDropFn.apply(x.reshape(B, 1, 1, D), w.view(1, 1, D, 1), g, 1.0, 0, 0, torch.is_grad_enabled())
         return y.reshape(B, 1)
 
     # ---- adversarial.py:127-271 ------------------------------------------------------------------------------------------

@@ -573,8 +573,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_dgrad_phases_kernel(GroupArg
 //   B:  voffset = constant per thread, soffset = (tap*C + channel-group*32) * K * 4   (scalar)
 // i.e. ~16 VALU per stage instead of ~130 (the general kernel re-derives tap, mirror/zero test and pixel offset per row per stage).
 
+// Waves per SIMD the register allocation must leave room for.  The 128x64 / 128x32 tiles take 54 / 46 KB of LDS — three workgroups fit a
+// CU's 160 KB — but at 175 VGPRs only two waves fit a SIMD; asking for three (<= 168 VGPRs) gives every SIMD a third wave to issue MFMAs
+// while the other two sit in the per-stage barrier / LDS-store part (a 128x64 stage carries half the MFMAs of a 128x128 one for the same
+// fixed part).  PNP_TAPS_NARROW_WAVES = 2 restores the round-2 allocation (A/B: tools/experiments/).
+#ifndef PNP_TAPS_NARROW_WAVES
+#define PNP_TAPS_NARROW_WAVES 2
+#endif
 template <int BM, int BN, int WM, int WN, int KIND, int R, int S>
-__global__ void __launch_bounds__(NTHREADS, 2) conv_taps_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS_NARROW_WAVES : 2)) conv_taps_kernel(ConvArgs a) {
     constexpr int NTAP = R * S;
     static_assert(NTAP <= 32, "one validity bit per tap");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -804,8 +811,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
 #define PNP_WGRAD_UNIFORM_ROWS 0
 #endif
 // (UNI is folded into the depth parameter — DEPTH_ = 10 + depth — so that the measured kernels keep their symbol names.)
+#ifndef PNP_WGRAD_NARROW_WAVES
+#define PNP_WGRAD_NARROW_WAVES 2
+#endif
 template <int BM, int BN, int WM, int WN, int DEPTH_>
-__global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_ring_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(NTHREADS, (BN <= 64 ? PNP_WGRAD_NARROW_WAVES : 2)) conv_wgrad_ring_kernel(ConvArgs a) {
     constexpr bool UNI = DEPTH_ >= 10;
     constexpr int DEPTH = UNI ? DEPTH_ - 10 : DEPTH_;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;

@@ -29,33 +29,38 @@ int g_prof_mask = 0;
 constexpr size_t kProfCap = 1u << 18;
 }  // namespace
 
-PnpProfScope::PnpProfScope(int cls, hipStream_t st, double flops, double bytes, const char* fmt, ...) : idx_(-1), st_(st) {
-    if (!(g_prof_mask & cls)) return;
-    char name[128];
+PnpProfScope::PnpProfScope(int cls, hipStream_t st, double flops, double bytes, const char* fmt, ...)
+    : on_(false), st_(st), e0_(nullptr), e1_(nullptr), flops_(flops), bytes_(bytes) {
+    int mask;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        mask = g_prof_mask;
+    }
+    if (!(mask & cls)) return;
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(name, sizeof(name), fmt, ap);
+    vsnprintf(name_, sizeof(name_), fmt, ap);
     va_end(ap);
-    ProfRec r{name, flops, bytes, nullptr, nullptr};
     // timing only: no system-scope fence when the event completes (hipEventDisableSystemFence exists for exactly this)
-    if (hipEventCreateWithFlags(&r.e0, hipEventDisableSystemFence) != hipSuccess ||
-        hipEventCreateWithFlags(&r.e1, hipEventDisableSystemFence) != hipSuccess)
-        return;
-    (void)hipEventRecord(r.e0, st);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (g_prof_recs.size() >= kProfCap) {
-        (void)hipEventDestroy(r.e0);
-        (void)hipEventDestroy(r.e1);
+    if (hipEventCreateWithFlags(&e0_, hipEventDisableSystemFence) != hipSuccess) return;
+    if (hipEventCreateWithFlags(&e1_, hipEventDisableSystemFence) != hipSuccess) {
+        (void)hipEventDestroy(e0_);
         return;
     }
-    idx_ = (int)g_prof_recs.size();
-    g_prof_recs.push_back(r);
+    (void)hipEventRecord(e0_, st);
+    on_ = true;
 }
 
 PnpProfScope::~PnpProfScope() {
-    if (idx_ < 0) return;
+    if (!on_) return;
+    (void)hipEventRecord(e1_, st_);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if ((size_t)idx_ < g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx_].e1, st_);
+    if (g_prof_recs.size() >= kProfCap) {
+        (void)hipEventDestroy(e0_);
+        (void)hipEventDestroy(e1_);
+        return;
+    }
+    g_prof_recs.push_back(ProfRec{name_, flops_, bytes_, e0_, e1_});
 }
 
 extern "C" {

@@ -64,8 +64,13 @@ struct PnpProfScope {
     PnpProfScope(int cls, hipStream_t st, double flops, double bytes, const char* fmt, ...) __attribute__((format(printf, 6, 7)));
     ~PnpProfScope();
     PnpProfScope(const PnpProfScope&) = delete;
-    int idx_;
+    // the scope owns its event pair and hands the FINISHED record over in the destructor: a pnp_prof_summary() between the constructor
+    // and the destructor can neither drop the end event nor have it recorded on another scope's record
+    bool on_;
     hipStream_t st_;
+    hipEvent_t e0_, e1_;
+    double flops_, bytes_;
+    char name_[128];
 };
 
 static inline int pnp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

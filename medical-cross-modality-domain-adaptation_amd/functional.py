@@ -122,10 +122,10 @@ def _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, keep, seed, sid):
     return dxc, dgamma, dbeta, dsc
 
 
-def _bn_sinks(ctx, gamma, beta, ig, ib):
-    """forward: record the uses of gamma / beta when both take a gradient and both have a slot"""
+def _bn_sinks(ctx, gamma, beta, ig, ib, taped=True):
+    """forward: record the uses of gamma / beta when both take a gradient and both have a slot (and a tape is being recorded)"""
     ctx.bn_sinks = None
-    if ctx.needs_input_grad[ig] and ctx.needs_input_grad[ib]:
+    if taped and ctx.needs_input_grad[ig] and ctx.needs_input_grad[ib]:
         sg, sb = gradsink.lookup(gamma), gradsink.lookup(beta)
         if sg is not None and sb is not None:
             sg.pending += 1
@@ -135,13 +135,14 @@ def _bn_sinks(ctx, gamma, beta, ig, ib):
 
 class Conv2dDropFn(Function):
     @staticmethod
-    def forward(ctx, x, w, geom, keep_prob, seed, stream_id):
+    def forward(ctx, x, w, geom, keep_prob, seed, stream_id, taped=True):
+        """taped: torch.is_grad_enabled() AT THE CALL SITE (gradsink.py: inside forward it is always off)"""
         x = _contig(x)
         w_ = _contig(w)
         y = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
         ctx.save_for_backward(x, w_)
         ctx.geom, ctx.keep, ctx.seed, ctx.sid = geom, keep_prob, seed, stream_id
-        ctx.w_sink = gradsink.use(w_) if ctx.needs_input_grad[1] else None
+        ctx.w_sink = gradsink.use(w_, taped) if ctx.needs_input_grad[1] else None
         return y
 
     @staticmethod
@@ -152,7 +153,7 @@ class Conv2dDropFn(Function):
             dy = K.dropout(dy, ctx.keep, ctx.seed, ctx.sid)
         dx = K.conv2d_dgrad(dy, w, ctx.geom) if ctx.needs_input_grad[0] else None
         dw = _wgrad(ctx, x, dy, ctx.w_sink) if ctx.needs_input_grad[1] else None
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 class ConvBNActFn(Function):
@@ -160,7 +161,7 @@ class ConvBNActFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, shortcut, geom, keep_prob, seed, stream_id, is_train, alpha, sync=False,
-                link=None):
+                link=None, taped=True):
         x = _contig(x)
         w_ = _contig(w)
         sc = _contig(shortcut) if shortcut is not None else None
@@ -168,9 +169,10 @@ class ConvBNActFn(Function):
         ctx.is_train, ctx.alpha = is_train, alpha
         ctx.sc_channels = sc.shape[-1] if sc is not None else 0
         ctx.link = link if RES_LINK else None
-        ctx.w_sink = gradsink.use(w_) if ctx.needs_input_grad[1] else None
-        _bn_sinks(ctx, gamma, beta, 2, 3)
-        ctx.fused = (not is_train) and FUSE_BN_INFER and not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        ctx.w_sink = gradsink.use(w_, taped) if ctx.needs_input_grad[1] else None
+        _bn_sinks(ctx, gamma, beta, 2, 3, taped)
+        # (no tape: no backward pass can follow, whatever the BN parameters' requires_grad says — monitoring forwards of a TRAINABLE net)
+        ctx.fused = (not is_train) and FUSE_BN_INFER and (not taped or not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]))
         if ctx.fused:
             mean, var = _frozen_stats(ctx, moving_mean, moving_var)
             out = K.conv2d_fwd_bn(x, w_, geom, K.bn_fold(gamma, beta, mean, var, BN_EPS), sc, alpha, keep_prob, seed, stream_id)
@@ -226,18 +228,18 @@ class ConvBNActFn(Function):
             dx = None
         dw = _wgrad(ctx, x, dxc, ctx.w_sink) if ctx.needs_input_grad[1] else None
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, None, None,
-                dsc, None, None, None, None, None, None, None, None)
+                dsc, None, None, None, None, None, None, None, None, None)
 
 
 class BNActFn(Function):
     """batch_norm alone (layers.batch_norm, layers.py:95-100), optional activation; no conv in front."""
 
     @staticmethod
-    def forward(ctx, xc, gamma, beta, moving_mean, moving_var, is_train, alpha, sync=False):
+    def forward(ctx, xc, gamma, beta, moving_mean, moving_var, is_train, alpha, sync=False, taped=True):
         xc = _contig(xc)
         P = xc.numel() // xc.shape[-1]
         ctx.P_norm = P
-        _bn_sinks(ctx, gamma, beta, 1, 2)
+        _bn_sinks(ctx, gamma, beta, 1, 2, taped)
         if is_train:
             if sync:                  # opt-in SyncBN: statistics of the batch concatenated over the replicas
                 mean, var = par.sync_bn_stats(*K.bn_stats(xc))
@@ -258,7 +260,7 @@ class BNActFn(Function):
         xc, out, mean, var, gamma = ctx.saved_tensors
         _check_frozen_stats(ctx, mean, var)
         dxc, dgamma, dbeta, _ = _bn_bwd(ctx, _contig(dout), out, xc, mean, var, gamma, 0, 1.0, 0, 0)
-        return dxc, dgamma, dbeta, None, None, None, None, None
+        return dxc, dgamma, dbeta, None, None, None, None, None, None
 
 
 class MaxPool2Fn(Function):

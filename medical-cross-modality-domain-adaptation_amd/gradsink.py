@@ -8,11 +8,34 @@ slot here instead; the backward passes in functional.py hand that slot to the ke
 been written (the data-parallel reducer launches a bucket's all-reduce from that callback).
 
 The arena is zeroed once per step (`VariableStore.zero_grad`), which also re-arms the use counters.
+
+Contract (the step functions of source_segmenter.py / adversarial.py follow it):
+  * `zero_grad()` comes BEFORE the forward pass of the step.  The usual torch order forward -> zero_grad -> backward would wipe the
+    uses the forward recorded; `done()` then RAISES (a count below zero) instead of announcing a bucket early.
+  * a use is recorded only when the CALLER of `Function.apply` is recording a tape (`taped = torch.is_grad_enabled()` evaluated at the
+    call site — inside `Function.forward` grad mode is always off and `ctx.needs_input_grad` is true under `no_grad` too), so
+    monitoring / evaluation forwards leave the counters alone.
+  * anything that asks the ENGINE for parameter gradients — `torch.autograd.grad(loss, params)`, tensor hooks on a weight,
+    `retain_graph` + a second backward — gets None for every store variable and adds into the arena as a side effect.  Wrap such code
+    in `with gradsink.disabled():` (the kernels then return the gradients to the engine, which accumulates into `.grad` itself).
 """
+import contextlib
 import os
 import weakref
 
 ENABLED = os.environ.get("PNP_GRAD_SINKS", "1") != "0"
+
+
+@contextlib.contextmanager
+def disabled():
+    """parameter gradients through the autograd engine (AccumulateGrad) for the forward passes recorded inside this block"""
+    global ENABLED
+    prev = ENABLED
+    ENABLED = False
+    try:
+        yield
+    finally:
+        ENABLED = prev
 
 
 class Sink(object):
@@ -52,8 +75,11 @@ def lookup(t):
     return s
 
 
-def use(t):
-    """forward pass: `t` will receive a gradient from this call site -> its sink (or None), with the use recorded"""
+def use(t, taped=True):
+    """forward pass: `t` will receive a gradient from this call site -> its sink (or None), with the use recorded.
+    taped: the caller of Function.apply is recording a tape (a backward pass can follow); False -> no sink, nothing recorded"""
+    if not taped:
+        return None
     s = lookup(t)
     if s is not None:
         s.pending += 1
@@ -63,10 +89,13 @@ def use(t):
 def done(s):
     """backward pass: one use has been added into the slot"""
     s.pending -= 1
-    if s.pending <= 0:
+    if s.pending < 0:
         s.pending = 0
-        if s.ready is not None:
-            s.ready()
+        raise RuntimeError("gradient sink: a backward pass wrote a parameter gradient whose forward use is not on record — "
+                           "zero_grad() (which re-arms the use counters) must run BEFORE the forward pass of the step, not between "
+                           "forward and backward")
+    if s.pending == 0 and s.ready is not None:
+        s.ready()
 
 
 def set_ready(param, fn):

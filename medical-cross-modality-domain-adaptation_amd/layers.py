@@ -60,7 +60,7 @@ def conv2d(x, W, keep_prob_, strides=[1, 1, 1, 1], padding='SAME'):
     keep, seed, sid = _drop_ids(keep_prob_)
     if x.is_meta:           # symbolic build pass (graph construction): shapes and variables only
         return _meta_out(g)
-    return Conv2dDropFn.apply(x, W, g, keep, seed, sid)
+    return Conv2dDropFn.apply(x, W, g, keep, seed, sid, torch.is_grad_enabled())
 
 
 # ---- layers.py:84-93 ---------------------------------------------------------------------------------
@@ -70,7 +70,7 @@ def dilate_conv2d(x, W, keep_prob_, rate=2, padding='SAME'):
     keep, seed, sid = _drop_ids(keep_prob_)
     if x.is_meta:
         return _meta_out(g)
-    return Conv2dDropFn.apply(x, W, g, keep, seed, sid)
+    return Conv2dDropFn.apply(x, W, g, keep, seed, sid, torch.is_grad_enabled())
 
 
 def _conv_bn(x, W, keep_prob, padding, stride, dil, is_train, scope, bn_trainable, alpha, shortcut=None, link=None):
@@ -80,7 +80,8 @@ def _conv_bn(x, W, keep_prob, padding, stride, dil, is_train, scope, bn_trainabl
     keep, seed, sid = _drop_ids(keep_prob)
     if x.is_meta:
         return _meta_out(g)
-    return ConvBNActFn.apply(x, W, gamma, beta, mm, mv, shortcut, g, keep, seed, sid, bool(is_train), float(alpha), sync_now(), link)
+    return ConvBNActFn.apply(x, W, gamma, beta, mm, mv, shortcut, g, keep, seed, sid, bool(is_train), float(alpha), sync_now(), link,
+                             torch.is_grad_enabled())
 
 
 # ---- layers.py:16-27 ---------------------------------------------------------------------------------
@@ -114,7 +115,7 @@ def batch_norm(x, is_training=True, scope=None, trainable=True):
     gamma, beta, mm, mv = _bn_vars(scope, x.shape[-1], trainable)
     if x.is_meta:
         return torch.empty(tuple(x.shape), device="meta")
-    return BNActFn.apply(x, gamma, beta, mm, mv, bool(is_training), -1.0, sync_now())
+    return BNActFn.apply(x, gamma, beta, mm, mv, bool(is_training), -1.0, sync_now(), torch.is_grad_enabled())
 
 
 # ---- layers.py:102-103 -------------------------------------------------------------------------------

@@ -25,24 +25,38 @@ from . import _lib
 class NativeComm(object):
     """One RCCL communicator per process behind the C-ABI (pnp_comm_*, csrc/comm.hip): the gradient / statistics all-reduces are
     enqueued by libpnp_hip.so directly on the HIP stream the caller names — no torch.distributed on the data path.  The 128-byte
-    RCCL unique id travels from rank 0 over the torchrun rendezvous (a gloo broadcast of a CPU tensor: control plane only)."""
+    RCCL unique id travels from rank 0 over the torchrun rendezvous (a gloo broadcast of a CPU tensor: control plane only).
+
+    Bring-up is in STAGES so that the ranks can agree after each one (_bring_up_native): `prepare()` is purely local (dlopen of
+    librccl.so, rank 0 draws the unique id), `connect()` holds the two collectives (the id broadcast and ncclCommInitRank)."""
 
     def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.handle = ctypes.c_void_p()
+        self.ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        self.version = 0
+        self.bytes_reduced = 0          # payload handed to pnp_comm_allreduce since the last take_bytes() (bench.py's comm record)
+
+    def prepare(self):
+        """local part: bind librccl.so, rank 0 draws the unique id.  May raise; no other rank is involved."""
         lib = _lib.load()
         # bind the librccl.so that ships inside the PyTorch wheel: it links the HIP runtime this process already uses (see _lib.py)
         cand = os.environ.get("PNP_RCCL_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         _lib.check(lib.pnp_comm_load(cand.encode() if os.path.exists(cand) else None), "pnp_comm_load")
-        ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
-        if rank == 0:
-            _lib.check(lib.pnp_comm_unique_id(ctypes.c_void_p(ident.data_ptr())), "pnp_comm_unique_id")
-        if world > 1:
-            dist.broadcast(ident, src=0, group=group)
-        self.handle = ctypes.c_void_p()
-        _lib.check(lib.pnp_comm_init(rank, world, ctypes.c_void_p(ident.data_ptr()), ctypes.byref(self.handle)), "pnp_comm_init")
-        self.rank, self.world = rank, world
+        if self.rank == 0:
+            _lib.check(lib.pnp_comm_unique_id(ctypes.c_void_p(self.ident.data_ptr())), "pnp_comm_unique_id")
         v = ctypes.c_int()
         _lib.check(lib.pnp_comm_version(ctypes.byref(v)), "pnp_comm_version")
         self.version = v.value
+        return self
+
+    def connect(self):
+        """collective part: EVERY rank of the group must call it (after all of them prepared successfully)"""
+        if self.world > 1:
+            dist.broadcast(self.ident, src=0, group=self.group)
+        _lib.check(_lib.load().pnp_comm_init(self.rank, self.world, ctypes.c_void_p(self.ident.data_ptr()), ctypes.byref(self.handle)),
+                   "pnp_comm_init")
+        return self
 
     def allreduce_(self, t, stream=None):
         """in-place sum of a contiguous float32 / float64 device tensor, enqueued on `stream` (default: the current stream)"""
@@ -54,7 +68,12 @@ class NativeComm(object):
         st = stream if stream is not None else torch.cuda.current_stream()
         _lib.check(_lib.load().pnp_comm_allreduce(self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(), dt, ctypes.c_void_p(st.cuda_stream)),
                    "pnp_comm_allreduce")
+        self.bytes_reduced += t.numel() * t.element_size()
         return t
+
+    def take_bytes(self):
+        n, self.bytes_reduced = self.bytes_reduced, 0
+        return n
 
     def destroy(self):
         if self.handle:
@@ -105,32 +124,50 @@ def init_distributed(backend=None):
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         if want_native:
             _bring_up_native(rank, world)
+        control_group()          # (a collective when it has to create the gloo side group: every rank is here)
     return rank, local, world
 
 
 _DATA_GROUP = None      # torch.distributed group that carries the data-path collectives when the native communicator is not up
 
 
+def _all_ok(flag):
+    ok = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return int(ok.item()) == 1
+
+
 def _bring_up_native(rank, world):
-    """NativeComm on every rank, or — if ANY rank fails to bring it up (a librccl.so that cannot be bound, an init error) — on none:
-    the ranks agree over gloo, and the data path then runs on torch.distributed's own nccl (= RCCL) group instead, loudly."""
+    """NativeComm on every rank or on none, agreed over the gloo control plane STAGE BY STAGE — a rank that fails must never leave
+    the others inside a collective it does not join:
+      1. every rank runs the local part (`prepare`: dlopen + symbols of librccl.so, rank 0 draws the unique id) under try/except;
+      2. all ranks all_reduce(MIN) the outcome.  Any failure: nobody enters the id broadcast or ncclCommInitRank; the data path runs on
+         torch.distributed's own nccl (= RCCL) group instead, loudly;
+      3. only if all succeeded, every rank runs the collective part (`connect`) unconditionally, then the ranks agree once more.
+    A failure INSIDE ncclCommInitRank on a subset of the ranks cannot be recovered from (the others are blocked inside RCCL's own
+    bootstrap, which no host-side agreement can interrupt): the job dies on RCCL's / the launcher's timeout.  What stage 3's agreement
+    buys is the symmetric case (every rank returns an error, e.g. an unusable id): all fall back together."""
     global _COMM, _DATA_GROUP
-    err = None
+    import logging
+    log = logging.getLogger(__name__)
+    comm, err = NativeComm(rank, world), None
     try:
-        _COMM = NativeComm(rank, world)
+        comm.prepare()
     except Exception as e:          # noqa: BLE001 — whatever went wrong, the other ranks must learn of it before anyone proceeds
         err = e
-        _COMM = None
-    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 1:
-        return
-    import logging
-    logging.getLogger(__name__).warning("native RCCL communicator (pnp_comm_*) unavailable on at least one rank (%s): "
-                                        "gradient all-reduce falls back to torch.distributed's nccl (RCCL) group", err)
-    if _COMM is not None:
-        _COMM.destroy()
-        _COMM = None
+    if _all_ok(err is None):
+        try:
+            comm.connect()
+        except Exception as e:      # noqa: BLE001
+            err = e
+        if _all_ok(err is None):
+            _COMM = comm
+            return
+        if err is None:
+            comm.destroy()
+    log.warning("native RCCL communicator (pnp_comm_*) unavailable on at least one rank (this rank: %s): gradient all-reduce falls "
+                "back to torch.distributed's nccl (RCCL) group", err if err is not None else "ok")
+    _COMM = None
     _DATA_GROUP = dist.new_group(backend="nccl")
 
 
@@ -138,9 +175,23 @@ def data_group():
     return _DATA_GROUP
 
 
+_CTRL_GROUP = None
+
+
+def control_group():
+    """group for HOST-side agreement between the ranks (tiny CPU tensors): the default group when it is gloo, a gloo side group when
+    the default group is torch.distributed's nccl (PNP_COMM=torch)"""
+    global _CTRL_GROUP
+    if dist.get_backend() != "nccl":
+        return None
+    if _CTRL_GROUP is None:
+        _CTRL_GROUP = dist.new_group(backend="gloo")
+    return _CTRL_GROUP
+
+
 def shutdown():
-    global _COMM, _DATA_GROUP
-    _DATA_GROUP = None
+    global _COMM, _DATA_GROUP, _CTRL_GROUP
+    _DATA_GROUP = _CTRL_GROUP = None
     if _COMM is not None:
         _COMM.destroy()
         _COMM = None
@@ -216,7 +267,18 @@ def rank_seed(rank):
 
 
 class GradReducer(object):
-    """Bucketed, backward-overlapped gradient all-reduce over a VariableStore's flat gradient arena."""
+    """Bucketed, backward-overlapped gradient all-reduce over a VariableStore's flat gradient arena.
+
+    Deadlock-proof by construction: every rank must enqueue the SAME collectives in the SAME order.
+      * ORDER.  Buckets are launched strictly in index order (bucket 0 = the last-created variables, whose gradients are ready first);
+        a bucket whose gradients are complete early waits for its predecessors.  The order in which autograd hooks fire therefore
+        cannot change the collective sequence.
+      * SET.  Which buckets a step reduces is a function of the `requires_grad` flags alone (the GAN steps switch them per variable
+        group: a dis step reduces the 91 MB of critic gradients, a gen step the 20 MB of adapt_*), never of which hooks happened to
+        fire.  Every step, BEFORE its first collective is enqueued, the ranks compare a checksum of the set over the host control plane
+        (one 16-byte gloo all-reduce, ~0.1 ms against a >= 35 ms step); a rank whose set differs makes EVERY rank raise instead of
+        hanging in RCCL.  (Checking a set only the first time it is seen would not be symmetric: the rank that diverges sees a NEW set
+        while the others see a known one and go straight to the collective.)"""
 
     def __init__(self, store, bucket_bytes=32 << 20, overlap=True, group=None):
         self.store = store
@@ -226,10 +288,14 @@ class GradReducer(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.overlap = overlap and self.world > 1 and store.arena.is_cuda
         self.buckets = []       # (start, end) element ranges of the arena, in reverse variable order
-        self._pending = []      # outstanding work handles
         self._remaining = []
         self._members = []      # variables of each bucket
         self._var_bucket = {}
+        self.sets_seen = set()  # distinct bucket sets reduced so far (bench.py's comm record)
+        self.launch_log = []    # bucket indices in launch order, this step (tests; bench.py's comm record)
+        self.bytes_step = 0     # payload all-reduced by the last finished step
+        self.exposed_ms = None  # with measure_exposed: time the compute stream waited for the side stream in the last step
+        self.measure_exposed = False
         tr = store.trainable()
         # buckets: walk variables from the LAST created (first gradient to be ready) to the first
         cur_end = None
@@ -270,9 +336,33 @@ class GradReducer(object):
 
     def reset(self):
         self._count = list(self._remaining)
-        self._pending = []
         self._launched = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
         self._seen = set()
+        self._active = None     # this step's bucket set (tuple of indices), fixed when the first bucket becomes ready
+        self._next = 0          # position in _active of the next bucket to launch
+        self.launch_log = []
+
+    # ---- which buckets this step reduces: requires_grad flags only -> identical on every rank of a correct program --------------
+    def active_set(self):
+        return tuple(b for b in range(len(self.buckets)) if any(v.tensor.requires_grad for v in self._members[b]))
+
+    def _begin_step(self):
+        if self._active is not None:
+            return
+        self._active = self.active_set()
+        self._next = 0
+        self.launch_log = []            # (the previous step's log stayed readable until now)
+        self.sets_seen.add(self._active)
+        if dist.is_initialized() and self.world > 1:
+            import zlib
+            h = zlib.crc32(repr((len(self.buckets), self._active)).encode())
+            t = torch.tensor([h, -h], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=control_group())     # host control plane; nothing of this step is enqueued yet
+            if int(t[0]) != h or int(t[1]) != -h:
+                raise RuntimeError("GradReducer: the ranks disagree on which gradient buckets this step reduces (rank %d: %s) — "
+                                   "requires_grad flags / graphs differ between ranks; refusing to enqueue mismatched collectives"
+                                   % (dist.get_rank(), (len(self.buckets), self._active)))
 
     def _make_hook(self, v):
         b = self._var_bucket[v.name]
@@ -287,13 +377,22 @@ class GradReducer(object):
             self._seen.add(name)
             self._count[b] -= 1
             if self._count[b] == 0:
-                self._launch(b)
+                self._mark_ready(b)
         return hook
+
+    def _mark_ready(self, b):
+        """bucket b is complete: launch it and every complete successor — but never ahead of an incomplete predecessor"""
+        self._begin_step()
+        self._ready[b] = True
+        while self._next < len(self._active) and self._ready[self._active[self._next]]:
+            self._launch(self._active[self._next])
+            self._next += 1
 
     def _launch(self, b):
         if self._launched[b]:
             return
         self._launched[b] = True
+        self.launch_log.append(b)
         s, e = self.buckets[b]
         view = self.store.grad_arena[s:e]
         ev = torch.cuda.Event()
@@ -310,18 +409,39 @@ class GradReducer(object):
         if self.world <= 1:
             return
         if self.overlap:
-            # buckets whose hook count did not reach zero: some member had no gradient this step.  A bucket none of whose
-            # variables is being trained in this step (the GAN steps switch requires_grad per variable group: a dis step only
-            # produces the 91 MB of critic gradients, a gen step the 20 MB of adapt_*) is skipped — identically on every rank.
-            for b in range(len(self.buckets)):
-                if not self._launched[b] and any(v.tensor.requires_grad for v in self._members[b]):
-                    self._launch(b)
-            torch.cuda.current_stream().wait_stream(self.side)
+            # buckets whose hook count did not reach zero (some member had no gradient this step) go out now, still in index order
+            self._begin_step()
+            for b in self._active[self._next:]:
+                self._launch(b)
+            self._next = len(self._active)
+            cur = torch.cuda.current_stream()
+            if self.measure_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self.side)
+                e1.record(cur)
+                self._exposed_events = (e0, e1)
+            else:
+                cur.wait_stream(self.side)
+            self.bytes_step = sum((self.buckets[b][1] - self.buckets[b][0]) * 4 for b in self.launch_log)
+            log = list(self.launch_log)
             self.reset()
+            self.launch_log = log              # stays readable until the next step's first bucket
         else:
-            for b, (s, e) in enumerate(self.buckets):
-                if any(v.tensor.requires_grad for v in self._members[b]):
-                    if self.native is not None:
-                        self.native.allreduce_(self.store.grad_arena[s:e])
-                    else:
-                        dist.all_reduce(self.store.grad_arena[s:e], op=dist.ReduceOp.SUM, group=self.group)
+            act = self.active_set()
+            self.launch_log = list(act)
+            for b in act:
+                s, e = self.buckets[b]
+                if self.native is not None:
+                    self.native.allreduce_(self.store.grad_arena[s:e])
+                else:
+                    dist.all_reduce(self.store.grad_arena[s:e], op=dist.ReduceOp.SUM, group=self.group)
+            self.bytes_step = sum((self.buckets[b][1] - self.buckets[b][0]) * 4 for b in act)
+
+    def exposed_time_ms(self):
+        """with measure_exposed: how long the compute stream sat behind the side stream at the end of the last step (synchronises)"""
+        ev = getattr(self, "_exposed_events", None)
+        if ev is None:
+            return None
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1])

@@ -146,7 +146,13 @@ class VariableStore(object):
         return v
 
     def finalize(self):
-        """Pack every variable into chunk-aligned flat arenas (trainable -> arena(+grad), others -> state arena)."""
+        """Pack every variable into chunk-aligned flat arenas (trainable -> arena(+grad), others -> state arena).
+
+        Every trainable variable registers a GRADIENT SINK (gradsink.py): the backward kernels ADD its gradient straight into its slot
+        of `grad_arena` and hand None to the autograd engine.  Consequences for code outside the step functions of this package:
+        `torch.autograd.grad(loss, params)`, tensor hooks on a weight and a second backward over a retained graph see None / add into
+        the arena as a side effect — wrap such code in `with gradsink.disabled():`; and `zero_grad()` must run before the forward pass
+        of a step (it re-arms the sinks' use counters)."""
         if self.finalized:
             return
         tr = [v for v in self.vars.values() if v.trainable]

@@ -57,6 +57,9 @@ for it in range(2):                       # twice: the hook counters must re-arm
     got = net.store.grad_arena
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err < 1e-6, (it, err)
+    logs = [None] * world
+    dist.all_gather_object(logs, list(red.launch_log))
+    assert all(l == logs[0] for l in logs) and logs[0] == sorted(logs[0]) and len(logs[0]) == len(red.buckets), logs   # same collective sequence
 # gradient scale: loss gradient carries 1/world (the sum over ranks is the average)
 assert net.world_size == world
 dist.barrier()

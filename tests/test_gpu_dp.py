@@ -31,7 +31,7 @@ def test_native_rccl_single_rank(dev):
     import torch
     from conftest import pkg
     par = pkg("parallel")
-    comm = par.NativeComm(0, 1)
+    comm = par.NativeComm(0, 1).prepare().connect()
     assert comm.version >= 20000 and bool(comm.handle)
     side = torch.cuda.Stream()
     for dt in (torch.float32, torch.float64):

@@ -37,6 +37,27 @@ def test_sink_counts_uses_and_announces_the_last_one():
     assert fired == ["ready", "ready"]
 
 
+def test_sink_refuses_the_forward_zero_grad_backward_order_and_untaped_uses():
+    """(a) a use recorded by a forward under no_grad (monitoring / evaluation: no backward will follow) must not count —
+    `taped` is evaluated by the caller of Function.apply; (b) zero_grad BETWEEN forward and backward wipes the recorded uses: the
+    backward's done() must raise instead of clamping at zero and announcing a shared variable after its first use."""
+    import pytest
+    gs = pkg("gradsink")
+    p = _param()
+    s = gs.register(p)
+    fired = []
+    gs.set_ready(p, lambda: fired.append(1))
+    assert gs.use(p, taped=False) is None and s.pending == 0
+    a, b = gs.use(p, True), gs.use(p, True)          # forward: two uses
+    gs.rearm([p])                                     # zero_grad in the wrong place
+    with pytest.raises(RuntimeError, match="zero_grad"):
+        gs.done(a)
+    assert fired == []                                # nothing was announced early
+    with gs.disabled():
+        assert gs.use(p) is None and gs.lookup(p) is None
+    assert gs.lookup(p) is s
+
+
 def test_sink_lookup_is_by_storage_and_dies_with_its_variable():
     gs = pkg("gradsink")
     p = _param(16)
