@@ -439,6 +439,10 @@ contour_map = {"bg": 0, "la_myo": 1, "la_blood": 2, "lv_blood": 3, "aa": 4}     
 verbose = True
 
 
+def _host(t):
+    return None if t is None else float(t)
+
+
 class _Null(object):
     def __enter__(self):
         return self
@@ -607,6 +611,8 @@ class Trainer(object):
                 self.net.restore(None, ck, no_gan=bool(tc.get("restore_from_baseline")), clear_rms=bool(tc.get("clear_rms")))
                 if not tc.get("restore_from_baseline"):
                     self.restore_optimizer(restored_path, clear_rms=bool(tc.get("clear_rms")), lr_update=bool(tc.get("lr_update")))
+        from .metrics import ScalarLog
+        self.scalars = ScalarLog(output_path, self.rank)
         ct_feed, mr_feed = self._feeder(self.ct_train_list), self._feeder(self.mr_train_list)
         ct_val, mr_val = self._feeder(self.ct_val_list), self._feeder(self.mr_val_list)
         dis_interval, gen_interval = tc.get('dis_interval', 1), tc.get('gen_interval', 1)
@@ -633,6 +639,9 @@ class Trainer(object):
                         dis_sub_iter += dis_inc
                         gen_sub_iter += gen_inc
                     self.step_times.append(time.time() - start)
+                    n_dis = dis_sub_iter if (dis_interval != 0 and step % dis_interval == 0 and step != 0) else 0
+                    n_gen = gen_sub_iter if (gen_interval != 0 and step % gen_interval == 0 and step != 0) else 0
+                    self.scalars.write("gan_step", step=step, epoch=epoch, host_time_s=self.step_times[-1], dis_updates=n_dis, gen_updates=n_gen)
                     logging.info("Training step %s epoch %s has been finished! Time elapsed %s seconds" % (step, epoch, time.time() - start))
                     if step % display_step == 0:
                         self.output_minibatch_stats(step, *ct_feed.next()[:2], *mr_feed.next()[:2])                # a training batch ...
@@ -646,6 +655,7 @@ class Trainer(object):
         finally:                 # reader threads, pinned buffers and copy streams go away also when a step raises
             for f in (ct_feed, mr_feed, ct_val, mr_val):
                 f.close()
+            self.scalars.close()
         if self.rank == 0:
             self.save_checkpoint(output_path)
         barrier()
@@ -656,6 +666,9 @@ class Trainer(object):
         from .lib import _indicator_eval
         ct_d, mr_d = self.net.evaluate(ct_batch, ct_batch_y, mr_batch, mr_batch_y, detail=detail)
         self.loss_dict["val" if detail else "train"] = (step, ct_d, mr_d)
+        if getattr(self, "scalars", None) is not None:      # evaluate() has just synchronised: the last losses cost nothing to read here
+            self.scalars.write("val_eval" if detail else "train_eval", step=step, ct_dice=ct_d, mr_dice=mr_d,
+                               dis_loss=_host(getattr(self.net, "dis_loss", None)), gen_loss=_host(getattr(self.net, "ct_gen_loss", None)))
         if detail:
             _indicator_eval(self.net.confusion_matrix, verbose=verbose)
 

@@ -423,6 +423,8 @@ class Trainer(object):
         now = time.time()
         self.step_times.append(now - max(start, self._last_done))
         self._last_done = now
+        if getattr(self, "scalars", None) is not None:
+            self.scalars.write("train_step", step=step, epoch=epoch, loss=lv, step_time_s=self.step_times[-1])
         logging.info("Training at step %s epoch %s , loss is %0.4f" % (str(step), str(epoch), lv))
         logging.info("Time elapsed %s seconds" % (str(self.step_times[-1])))
 
@@ -477,6 +479,8 @@ class Trainer(object):
                 print("Unable to restore, start from beginning")
             if self.lr_update_flag is True:
                 self.opt.lr = self._new_LR
+        from .metrics import ScalarLog
+        self.scalars = ScalarLog(output_path, self.rank)
         feed_all = self._feeder(self.train_list)
         feed_val = self._feeder(self.val_list)
         self._last_done = 0.0
@@ -508,6 +512,7 @@ class Trainer(object):
         finally:
             feed_all.close()
             feed_val.close()
+            self.scalars.close()
         logging.info("Optimization Finished!")
         if self.rank == 0:      # replicas hold identical weights; BN moving statistics are rank 0's (per-replica statistics)
             self.save_checkpoint(output_path)
@@ -518,6 +523,8 @@ class Trainer(object):
         """source_segmenter.py:525-539: logging-only forward (BN train mode, keep_prob 1: it DOES move the BN moving stats)"""
         self.net.evaluate(batch_x, batch_y, keep_prob=1.0, main_bn=True, adapt_bn=True)
         self.loss_dict["train"] = (step, float(self.net.cost), float(self.net.dice_eval))
+        if getattr(self, "scalars", None) is not None:
+            self.scalars.write("train_eval", step=step, cost=self.loss_dict["train"][1], dice=self.loss_dict["train"][2])
 
     def val_stats(self, step, batch_x, batch_y, detail=False):
         """source_segmenter.py:541-570"""
@@ -525,6 +532,8 @@ class Trainer(object):
         if detail:
             _indicator_eval(self.net.confusion_matrix, verbose=verbose)
         self.loss_dict["val"] = (step, float(self.net.cost), float(self.net.dice_eval))
+        if getattr(self, "scalars", None) is not None:
+            self.scalars.write("val_eval", step=step, cost=self.loss_dict["val"][1], dice=self.loss_dict["val"][2])
 
     # -- volume inference -------------------------------------------------------------------------------
     def _predict_batch(self, vol, slice_y):

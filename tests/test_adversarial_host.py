@@ -154,6 +154,15 @@ def test_gan_training_schedule_with_stub_steps(tmp_path):
     assert len(set(ct_used)) == len(ct_used)                              # every update sees a fresh CT batch
     assert tr.dis_optimizer.lr == 0.25 and tr.gen_optimizer.lr == 0.25    # checkpoints at steps 3 and 6
     assert Net.saved == 3                                                 # steps 3, 6 and the final one
+    # the scalar log (metrics.py): one gan_step row per iteration with the number of updates it ran, eval rows at display steps
+    import json
+    rows = [json.loads(l) for l in open(str(tmp_path / "o" / "metrics.jsonl"))]
+    gs = [r for r in rows if r["kind"] == "gan_step"]
+    assert [r["step"] for r in gs] == list(range(7)) and [r["dis_updates"] for r in gs] == [0, 2, 2, 2, 2, 3, 3]
+    assert [r["gen_updates"] for r in gs] == [0, 0, 1, 0, 1, 0, 1] and all(r["host_time_s"] >= 0 for r in gs)
+    ev = [r for r in rows if r["kind"].endswith("_eval")]
+    assert [(r["kind"], r["step"]) for r in ev] == [("train_eval", 0), ("val_eval", 0), ("train_eval", 5), ("val_eval", 5)]
+    assert all(r["ct_dice"] == 0.5 and r["dis_loss"] is None for r in ev)
 
 
 def test_baseline_hand_off_follows_the_reference_lists():
