@@ -624,13 +624,16 @@ class Trainer(object):
             for epoch in range(epochs):
                 for step in range(epoch * training_iters, (epoch + 1) * training_iters):
                     start = time.time()
+                    n_dis = n_gen = 0
                     if dis_interval != 0 and (step % dis_interval == 0) and step != 0:
+                        n_dis = dis_sub_iter
                         for _ in range(dis_sub_iter):
                             ct_x = ct_feed.next()[0]
                             mr_x = mr_feed.next()[0]
                             self.dis_step(mr_x, ct_x, dropout, seed)
                             seed += 1
                     if gen_interval != 0 and (step % gen_interval == 0) and step != 0:
+                        n_gen = gen_sub_iter
                         for _ in range(gen_sub_iter):
                             ct_x = ct_feed.next()[0]
                             self.gen_step(ct_x, dropout, seed)
@@ -639,8 +642,6 @@ class Trainer(object):
                         dis_sub_iter += dis_inc
                         gen_sub_iter += gen_inc
                     self.step_times.append(time.time() - start)
-                    n_dis = dis_sub_iter if (dis_interval != 0 and step % dis_interval == 0 and step != 0) else 0
-                    n_gen = gen_sub_iter if (gen_interval != 0 and step % gen_interval == 0 and step != 0) else 0
                     self.scalars.write("gan_step", step=step, epoch=epoch, host_time_s=self.step_times[-1], dis_updates=n_dis, gen_updates=n_gen)
                     logging.info("Training step %s epoch %s has been finished! Time elapsed %s seconds" % (step, epoch, time.time() - start))
                     if step % display_step == 0:
