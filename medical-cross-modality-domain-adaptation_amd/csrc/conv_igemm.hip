@@ -708,6 +708,177 @@ __global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS
     conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
 }
 
+// ---- the same tap-unrolled convolution with THREE LDS stages and a register ring of two global-load stages (narrow tiles) ------------
+// A 128x64 stage carries 32 MFMAs per wave — half of a 128x128 stage — for the same fixed part: barrier, the fragment reads of the next
+// stage's first slice that can only start behind it, and a global-load-to-LDS-store distance of three slices (24 MFMAs of cover instead of
+// 48).  PMC on the two-stage kernel: SQ_WAIT_INST_LDS per MFMA 1.05 against 0.50 on the wide tile, matrix-pipe utilisation 0.71 against
+// 0.92.  With a third LDS stage (3 x 27 KB = 81 408 B: two workgroups still fit a CU's 160 KB, to the byte) the barrier of stage s
+// publishes the data of stage s+2, so everything stage s+1 needs is already visible while stage s runs:
+//   * the first-slice fragment reads of stage s+1 are issued under the LAST slice of stage s, before the barrier — nothing is exposed
+//     behind it;
+//   * global loads run TWO stages ahead of their LDS store (ring of two register sets: one whole stage more cover).
+// Buffer rotation: stage s computes from LDS stage s % 3, stores the registers that hold stage s+2 into (s+2) % 3 (last read in stage
+// s-1: every wave is past that stage's barrier), and requests stage s+3 from memory.  The ring index must be a compile-time constant, so
+// the channel-group loop is unrolled by two where the tap count is odd; the host only picks this kernel when the workgroup's channel
+// groups come in pairs then (C % 64 == 0 and an un-split or evenly split reduction: every layer of the model that runs narrow tiles).
+template <int BM, int BN, int WM, int WN, int KIND, int R, int S>
+__global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
+    constexpr int NTAP = R * S;
+    static_assert(NTAP <= 32, "one validity bit per tap");
+    constexpr int CCU = (NTAP & 1) ? 2 : 1;          // channel groups per loop trip: an even number of stages
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int LDA = BK + 4, LDB = BN + 4;
+    constexpr int ASZ = BM * LDA, BSZ = BK * LDB, STG = ASZ + BSZ;
+    constexpr int NR = BM / 32;
+    constexpr int C4 = BN / 4, RPB = NTHREADS / C4, NPB = BK / RPB;
+    static_assert(3 * STG * 4 <= 81920, "three stages must leave room for two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) float lds[3 * STG];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nblk = a.nblk_m * a.nblk_n;
+    const int z = blockIdx.x / nblk;
+    int bid = blockIdx.x - z * nblk;
+    if (a.xcd_swizzle) bid = xcd_remap(bid, nblk);
+    int mt, nt;
+    tile_coords(bid, a.nblk_m, a.nblk_n, a.gn, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+    const int kg = t & 7, mrow = t >> 3;
+    int abase[NR];
+    unsigned amask[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        int m = m0 + mrow + 32 * i;
+        const bool ok = m < a.M;
+        if (!ok) m = 0;
+        const int n = m / a.OHW;
+        const int rem = m - n * a.OHW;
+        const int oh = rem / a.OW;
+        const int ow = rem - oh * a.OW;
+        const int vh0 = oh * a.stride - a.pad_t, vw0 = ow * a.stride - a.pad_l;
+        abase[i] = (((n * a.H + vh0) * a.W + vw0) * a.C + 4 * kg) * 4;
+        unsigned mk = 0;
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int ih = vh0 + (tap / S) * a.dil, iw = vw0 + (tap % S) * a.dil;
+            const bool v = ok & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            mk |= (v ? 1u : 0u) << tap;
+        }
+        amask[i] = mk;
+    }
+    const int bcol = t % C4, brow = t / C4;
+    unsigned boff[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+        boff[i] = (n0 + 4 * bcol < a.K) ? (unsigned)(((brow + RPB * i) * a.K + n0 + 4 * bcol) * 4) : OOB2;
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
+    struct Regs {
+        f32x4 a[NR];
+        f32x4 b[NPB];
+    };
+    Regs ring[2];
+    auto gload = [&](Regs& r, int cc, int tap) {     // tap is a compile-time constant at every call site (unrolled)
+        const int tshift = (((tap / S) * a.dil * a.W + (tap % S) * a.dil) * a.C) * 4;
+        const int sa = cc * (BK * 4);
+        const int sb = ((tap * a.C + cc * BK) * a.K) * 4;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const unsigned vo = ((amask[i] >> tap) & 1u) ? (unsigned)(abase[i] + tshift) : OOB2;
+            r.a[i] = bload4s(rx, vo, sa);
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) r.b[i] = bload4s(rw, boff[i], sb);
+    };
+    auto lstore = [&](const Regs& r, float* An, float* Bn) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) *reinterpret_cast<f32x4*>(An + (mrow + 32 * i) * LDA + 4 * kg) = r.a[i];
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) *reinterpret_cast<f32x4*>(Bn + (brow + RPB * i) * LDB + 4 * bcol) = r.b[i];
+    };
+
+    Acc<TM, TN> acc;
+    acc.zero();
+
+    const int ncc_total = a.C / BK;
+    const int cc_begin = z * (a.chunks_per_split / NTAP);
+    int cc_end = cc_begin + a.chunks_per_split / NTAP;
+    if (cc_end > ncc_total) cc_end = ncc_total;
+    const int cc_last = cc_end - 1;
+    // (stage index -> (channel group, tap)) d stages after (cc, tap); past the end the last group is fetched again (never contracted)
+#define PNP_T3_CC(cc, tap, d) (((cc) + ((tap) + (d)) / NTAP) < cc_end ? ((cc) + ((tap) + (d)) / NTAP) : cc_last)
+#define PNP_T3_TAP(tap, d) (((tap) + (d)) % NTAP)
+
+    // prologue: stages 0 and 1 into LDS, stage 2 in flight in ring[0]
+    gload(ring[0], cc_begin, 0);
+    gload(ring[1], PNP_T3_CC(cc_begin, 0, 1), PNP_T3_TAP(0, 1));
+    lstore(ring[0], lds, lds + ASZ);
+    gload(ring[0], PNP_T3_CC(cc_begin, 0, 2), PNP_T3_TAP(0, 2));
+    lstore(ring[1], lds + STG, lds + STG + ASZ);
+    __syncthreads();
+    Frag<TM, TN, true, LDA, LDB> f0, f1;
+    f0.load(lds, lds + ASZ, 0, wm0, wn0, lane);
+    int o_cur = 0, o_nxt = STG, o_st = 2 * STG;        // float offsets of the LDS stages holding s, s+1 and receiving s+2
+    constexpr int NMF = 4 * TM * TN;
+    constexpr int NDS = (TM + 4 * TN + NMF - 1) / NMF;
+    for (int cc0 = cc_begin; cc0 < cc_end; cc0 += CCU) {
+#pragma unroll
+        for (int u = 0; u < CCU; ++u) {
+            const int cc = cc0 + u;
+#pragma unroll
+            for (int tap = 0; tap < NTAP; ++tap) {
+                const int par = (u * NTAP + tap) & 1;            // compile-time after unrolling: stage parity inside the trip
+                const float* As = lds + o_cur;
+                const float* Bs = As + ASZ;
+                const float* An = lds + o_nxt;
+                const float* Bn = An + ASZ;
+                float* Ast = lds + o_st;
+                float* Bst = Ast + ASZ;
+                // ---- slice 0: this stage's slice-1 fragments, the global loads of stage s+3 into the ring slot stored LAST stage
+                f1.load(As, Bs, 1, wm0, wn0, lane);
+                gload(ring[par ^ 1], PNP_T3_CC(cc, tap, 3), PNP_T3_TAP(tap, 3));
+                f0.mma(acc);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + 4 * TN, 0);
+#pragma unroll
+                for (int i = 0; i < NMF; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                PNP_SCHED_FENCE();
+                PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), NMF, NDS)
+                PNP_SLICE(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), NMF, NDS)
+                // ---- last slice: the NEXT stage's slice-0 fragments (visible since the previous barrier) and the LDS stores of stage
+                // s+2 ride behind the MFMAs; the barrier then has nothing to wait for but the slowest wave
+                f0.load(An, Bn, 0, wm0, wn0, lane);
+                PNP_SCHED_FENCE();
+                f1.mma(acc);
+                lstore(ring[par], Ast, Bst);
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF / 2, 0);
+#pragma unroll
+                for (int i = 0; i < NMF / 2; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+                PNP_SCHED_FENCE();
+                __syncthreads();
+                const int o_t = o_cur;
+                o_cur = o_nxt;
+                o_nxt = o_st;
+                o_st = o_t;
+            }
+        }
+    }
+#undef PNP_T3_CC
+#undef PNP_T3_TAP
+
+    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
+}
+
 // ===================================== wgrad kernel ============================================
 // a.x = x, a.w = dy ([P][K]), a.y = dW or the split workspace.  grid.x = nblk_m*nblk_n*nsplit
 template <int BM, int BN, int WM, int WN, int MODE, bool VECB>
@@ -808,7 +979,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_wgrad_kernel(ConvArgs a) {
 // two half-waves load two consecutive pixels: two scalar rows per load, selected per lane).  The per-lane walk costs 1.45 VALU
 // instructions per MFMA (PMC), this form about 0.15.
 #ifndef PNP_WGRAD_UNIFORM_ROWS
-#define PNP_WGRAD_UNIFORM_ROWS 0
+#define PNP_WGRAD_UNIFORM_ROWS 1      // round 3: measured +2 % (512->512: 0.613 -> 0.601 ms, g10 3.07 -> 2.98 ms); PNP_WGRAD_UNI=0 at run time: off
 #endif
 // (UNI is folded into the depth parameter — DEPTH_ = 10 + depth — so that the measured kernels keep their symbol names.)
 #ifndef PNP_WGRAD_NARROW_WAVES
@@ -1572,6 +1743,9 @@ int choose_split(long long M, int K, int Kred, int tile) {
     return nsplit < 1 ? 1 : nsplit;
 }
 
+#ifndef PNP_TAPS3_DEFAULT
+#define PNP_TAPS3_DEFAULT 1
+#endif
 // filter shapes the tap-unrolled kernel is instantiated for: forward 3x3 / 5x5; data gradient 3x3 and the stride-phase sub-filters
 constexpr bool taps_shape(int kind, int R, int S) {
     if (R == 3 && S == 3) return true;
@@ -1582,8 +1756,20 @@ constexpr bool taps_shape(int kind, int R, int S) {
 
 template <int BM, int BN, int WM, int WN, int KIND>
 bool launch_taps(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    // three-stage kernel (conv_taps3_kernel) for the narrow tiles: its channel-group loop runs in pairs for odd tap counts
+    static const int env_t3 = getenv("PNP_CONV_TAPS3") ? atoi(getenv("PNP_CONV_TAPS3")) : PNP_TAPS3_DEFAULT;
+    const int cc_per = a.chunks_per_split / (a.R * a.S);
+    const bool t3 = env_t3 && BN <= 64 && ((a.R * a.S) % 2 == 0 || (cc_per % 2 == 0 && (a.nsplit == 1 || (a.C / BK) % cc_per == 0)));
 #define PNP_TAPS(RR, SS)                                                                                                   \
     if (a.R == RR && a.S == SS) {                                                                                          \
+        if constexpr (BN <= 64 && RR * SS <= 9) {     /* 5x5: 50 unrolled stages per trip and spills — stays on the two-stage kernel */ \
+            if (t3) {                                                                                                      \
+                PnpProfScope ps(prof_class(KIND), st, conv_flops(a), conv_bytes(a), "conv_taps3_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, \
+                                BN, WM, WN, KIND, RR, SS);                                                                  \
+                hipLaunchKernelGGL((conv_taps3_kernel<BM, BN, WM, WN, KIND, RR, SS>), grid, dim3(NTHREADS), 0, st, a);      \
+                return true;                                                                                               \
+            }                                                                                                              \
+        }                                                                                                                  \
         PnpProfScope ps(prof_class(KIND), st, conv_flops(a), conv_bytes(a), "conv_taps_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, \
                         WM, WN, KIND, RR, SS);                                                                              \
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, WM, WN, KIND, RR, SS>), grid, dim3(NTHREADS), 0, st, a);               \
@@ -1730,8 +1916,9 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
         PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "conv_wgrad_ring_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, depth);
         if constexpr (VECB) {
             bool done = false;
-            if constexpr (PNP_WGRAD_UNIFORM_ROWS != 0 && BM == 128) {          // opt-in build: scalar loader rows where a tile holds one tap
-                if (depth == 2 && (a.C % BM) == 0) {
+            if constexpr (PNP_WGRAD_UNIFORM_ROWS != 0 && BM == 128) {          // scalar loader rows where a tile holds one tap
+                static const int env_uni = getenv("PNP_WGRAD_UNI") ? atoi(getenv("PNP_WGRAD_UNI")) : 1;
+                if (env_uni && depth == 2 && (a.C % BM) == 0) {
                     hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 12>), grid, dim3(NTHREADS), 0, st, a);
                     done = true;
                 }

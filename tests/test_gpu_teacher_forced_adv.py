@@ -70,7 +70,9 @@ def _expect(units, dis):
 
 DIS_FAMILIES = {"conv_fwd_bn_fused", "bn_bwd_train", "wgrad_s2_k3", "wgrad_s2_k5", "wgrad_s4_k5", "dgrad_s2_k3", "dgrad_s2_k5",
                 "dgrad_s4_k5", "fc", "critic_input_fwd", "ps", "maxpool"}
-GEN_FAMILIES = DIS_FAMILIES | {"bn_bwd_frozen", "critic_input_bwd", "wgrad_s1_k3", "dgrad_s1_k3", "dgrad_s1_k5"}
+# (a generator step takes no filter gradient of the critics: their strided convolutions only run forward and data gradient)
+GEN_FAMILIES = {"conv_fwd_bn_fused", "bn_bwd_train", "bn_bwd_frozen", "critic_input_fwd", "critic_input_bwd", "wgrad_s1_k3", "dgrad_s1_k3",
+                "dgrad_s1_k5", "dgrad_s2_k3", "dgrad_s2_k5", "dgrad_s4_k5", "fc", "ps", "maxpool"}
 
 
 def _check(dev, V, sd, units, seed, tag, families):
