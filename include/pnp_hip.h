@@ -170,30 +170,33 @@ int pnp_bn_apply(const float* x, const float* mean, const float* var, const floa
                  const float* shortcut, int32_t Cs, float* y, int64_t P, int32_t C, float eps, float alpha,
                  void* stream);
 /* backward of pnp_bn_apply.  dz = dout * (out>0 ? 1 : alpha).  dbeta = sum dz, dgamma = sum dz*xhat.
+ * out == NULL (allowed when no shortcut entered the activation and `beta` is given): the sign of `out` is RECOMPUTED from x as
+ * fmaf(x-mean, gamma*rstd, beta) > 0 — bit for bit the value pnp_bn_apply activated — which saves one full read of the activation in
+ * the reduction and in the apply pass (these kernels sit on the HBM roof).
  * training=1 : dx = gamma*rstd*(dz - dbeta/P - xhat*dgamma/P);  training=0 (frozen stats): dx = gamma*rstd*dz
  * dx is then multiplied by the dropout mask of the producing conv when keep_prob<1 (layers.py:25: conv->dropout->BN).
  * dshortcut (optional) receives dz restricted to the Cs un-padded channels. */
-int pnp_bn_bwd(const float* dout, const float* out, const float* x, const float* mean, const float* var,
-               const float* gamma, float* dx, float* dgamma, float* dbeta, float* dshortcut, int32_t Cs,
+int pnp_bn_bwd(const float* dout, const float* out /*nullable*/, const float* x, const float* mean, const float* var,
+               const float* gamma, const float* beta /*nullable unless out == NULL*/, float* dx, float* dgamma, float* dbeta, float* dshortcut, int32_t Cs,
                int64_t P, int32_t C, float eps, float alpha, int32_t training,
                float keep_prob, uint64_t seed, uint32_t stream_id,
                void* workspace, size_t workspace_bytes, void* stream);
 /* Same, and the sums are ALSO added into dgamma_acc / dbeta_acc [C] (both or neither; e.g. the parameters' slots of a flat gradient
  * arena that may already hold another use's contribution) — no separate accumulation kernel per parameter.  dgamma / dbeta still
  * receive this call's own sums (the apply half needs them). */
-int pnp_bn_bwd_acc(const float* dout, const float* out, const float* x, const float* mean, const float* var,
-                   const float* gamma, float* dx, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc,
+int pnp_bn_bwd_acc(const float* dout, const float* out /*nullable*/, const float* x, const float* mean, const float* var,
+                   const float* gamma, const float* beta /*nullable unless out == NULL*/, float* dx, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc,
                    float* dshortcut, int32_t Cs, int64_t P, int32_t C, float eps, float alpha, int32_t training,
                    float keep_prob, uint64_t seed, uint32_t stream_id,
                    void* workspace, size_t workspace_bytes, void* stream);
 /* The two halves of pnp_bn_bwd, for synchronised batch statistics under data parallelism: reduce the local
  * sums, all-reduce dgamma / dbeta across ranks (caller, RCCL), then apply with P_norm = the GLOBAL row count behind them.
  * pnp_bn_bwd == reduce followed by apply with P_norm = P. */
-int pnp_bn_bwd_reduce(const float* dout, const float* out, const float* x, const float* mean, const float* var,
-                      float* dgamma, float* dbeta, int64_t P, int32_t C, float eps, float alpha,
+int pnp_bn_bwd_reduce(const float* dout, const float* out /*nullable*/, const float* x, const float* mean, const float* var,
+                      const float* gamma /*nullable unless out == NULL*/, const float* beta /*nullable unless out == NULL*/, float* dgamma, float* dbeta, int64_t P, int32_t C, float eps, float alpha,
                       void* workspace, size_t workspace_bytes, void* stream);
-int pnp_bn_bwd_apply(const float* dout, const float* out, const float* x, const float* mean, const float* var,
-                     const float* gamma, const float* dgamma, const float* dbeta, float* dx, float* dshortcut, int32_t Cs,
+int pnp_bn_bwd_apply(const float* dout, const float* out /*nullable*/, const float* x, const float* mean, const float* var,
+                     const float* gamma, const float* beta /*nullable unless out == NULL*/, const float* dgamma, const float* dbeta, float* dx, float* dshortcut, int32_t Cs,
                      int64_t P, int64_t P_norm, int32_t C, float eps, float alpha, int32_t training,
                      float keep_prob, uint64_t seed, uint32_t stream_id, void* stream);
 

@@ -22,7 +22,7 @@ PAD_SYMMETRIC = 1
 OPT_CHUNK = 1024
 DTYPE_F32, DTYPE_BF16, DTYPE_F64 = 0, 1, 2
 COMM_ID_BYTES = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvGeom(ctypes.Structure):
@@ -78,12 +78,12 @@ PROTOTYPES = {
     "pnp_bn_stats_update": (c_int, [_F, _F, _F, _F, _F, c_int64, c_int32, c_float, c_void_p, c_size_t, c_void_p]),
     "pnp_bn_update_moving": (c_int, [_F, _F, _F, _F, c_int64, c_int32, c_float, c_void_p]),
     "pnp_bn_apply": (c_int, [_F, _F, _F, _F, _F, _F, c_int32, _F, c_int64, c_int32, c_float, c_float, c_void_p]),
-    "pnp_bn_bwd": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int32, c_float, c_float, c_int32,
+    "pnp_bn_bwd": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int32, c_float, c_float, c_int32,
                            c_float, c_uint64, c_uint32, c_void_p, c_size_t, c_void_p]),
-    "pnp_bn_bwd_acc": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int32, c_float, c_float, c_int32,
+    "pnp_bn_bwd_acc": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int32, c_float, c_float, c_int32,
                                c_float, c_uint64, c_uint32, c_void_p, c_size_t, c_void_p]),
-    "pnp_bn_bwd_reduce": (c_int, [_F, _F, _F, _F, _F, _F, _F, c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
-    "pnp_bn_bwd_apply": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int64, c_int32, c_float, c_float, c_int32,
+    "pnp_bn_bwd_reduce": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    "pnp_bn_bwd_apply": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int64, c_int32, c_float, c_float, c_int32,
                                  c_float, c_uint64, c_uint32, c_void_p]),
     "pnp_maxpool2_fwd": (c_int, [_F, _F, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pnp_maxpool2_bwd": (c_int, [_F, _F, _F, c_int32, c_int32, c_int32, c_int32, c_void_p]),

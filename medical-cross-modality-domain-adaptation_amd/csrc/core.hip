@@ -65,7 +65,7 @@ PnpProfScope::~PnpProfScope() {
 
 extern "C" {
 
-int pnp_abi_version(void) { return 2; }
+int pnp_abi_version(void) { return 3; }
 
 int pnp_prof_enable(int mask) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

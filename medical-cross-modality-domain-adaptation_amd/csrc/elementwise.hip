@@ -30,6 +30,8 @@ struct ColArgs {
     const float* out;    // KIND1 (post activation), may be null when alpha<0
     const float* mean;   // KIND1
     const float* var;    // KIND1
+    const float* gamma;  // KIND1, out == null: the activation's sign is recomputed from x (needs gamma, beta)
+    const float* beta;
     float* ws;
     long long P;
     int C;
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(NT) colreduce_kernel(ColArgs a) {
     f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
     if (active) {
         const int c = cg * 4;
-        f32x4 m, rs;
+        f32x4 m, rs, gsc = {0, 0, 0, 0}, bet = {0, 0, 0, 0};
         if constexpr (KIND == 0) {
             m = ld4(a.x + c);   // shift
         } else {
@@ -59,6 +61,12 @@ __global__ void __launch_bounds__(NT) colreduce_kernel(ColArgs a) {
             f32x4 v = ld4(a.var + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) rs[e] = 1.0f / sqrtf(v[e] + a.eps);
+            if (!a.out && a.alpha >= 0.f) {
+                const f32x4 ga = ld4(a.gamma + c);
+                bet = ld4(a.beta + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gsc[e] = ga[e] * rs[e];
+            }
         }
         for (long long r = r0 + rsub; r < r1; r += rpi) {
             const size_t off = (size_t)r * a.C + c;
@@ -73,9 +81,14 @@ __global__ void __launch_bounds__(NT) colreduce_kernel(ColArgs a) {
             } else {
                 f32x4 g = ld4(a.dout + off);
                 if (a.alpha >= 0.f) {
-                    f32x4 o = ld4(a.out + off);
+                    if (a.out) {
+                        f32x4 o = ld4(a.out + off);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : g[e] * a.alpha;
+                        for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : g[e] * a.alpha;
+                    } else {        // the pre-activation value exactly as bn_apply_kernel formed it
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = fmaf(xv[e] - m[e], gsc[e], bet[e]) > 0.f ? g[e] : g[e] * a.alpha;
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -130,7 +143,10 @@ __global__ void colreduce_scalar_kernel(ColArgs a) {
             s1 = fmaf(d, d, s1);
         } else {
             float g = a.dout[off];
-            if (a.alpha >= 0.f) g = a.out[off] > 0.f ? g : g * a.alpha;
+            if (a.alpha >= 0.f) {
+                const float o = a.out ? a.out[off] : fmaf(xv - m, a.gamma[c] * rs, a.beta[c]);
+                g = o > 0.f ? g : g * a.alpha;
+            }
             s0 += g;
             s1 = fmaf(g, (xv - m) * rs, s1);
         }
@@ -315,7 +331,8 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(BnApplyArgs a) {
             f32x4 xv = ld4(a.x + i * 4), m = ld4(a.mean + c), v = ld4(a.var + c), g = ld4(a.gamma + c), b = ld4(a.beta + c);
             f32x4 r;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (xv[e] - m[e]) * (g[e] * (1.0f / sqrtf(v[e] + a.eps))) + b[e];
+            for (int e = 0; e < 4; ++e) r[e] = fmaf(xv[e] - m[e], g[e] * (1.0f / sqrtf(v[e] + a.eps)), b[e]);    // (explicit: the backward
+            // kernels recompute this value bit for bit when they are not handed `out`)
             if (a.shortcut) {
                 const int cs = c - cpad;
                 if (cs >= 0 && cs < a.Cs) {
@@ -331,7 +348,7 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(BnApplyArgs a) {
             st4(a.y + i * 4, r);
         } else {
             const int c = cv;
-            float r = (a.x[i] - a.mean[c]) * (a.gamma[c] * (1.0f / sqrtf(a.var[c] + a.eps))) + a.beta[c];
+            float r = fmaf(a.x[i] - a.mean[c], a.gamma[c] * (1.0f / sqrtf(a.var[c] + a.eps)), a.beta[c]);
             if (a.shortcut) {
                 const int cs = c - cpad;
                 if (cs >= 0 && cs < a.Cs) r += a.shortcut[row * a.Cs + cs];
@@ -343,7 +360,7 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(BnApplyArgs a) {
 }
 
 struct BnBwdArgs {
-    const float *dout, *out, *x, *mean, *var, *gamma, *dgamma, *dbeta;
+    const float *dout, *out, *x, *mean, *var, *gamma, *beta, *dgamma, *dbeta;      // out == null: sign recomputed from x (needs beta)
     float *dx, *dshortcut;
     long long P;
     long long P_norm;    // rows behind dgamma / dbeta: P, or the global row count when the sums were all-reduced (SyncBN)
@@ -368,16 +385,23 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(BnBwdArgs a) {
         if constexpr (VEC) {
             const int c = cv * 4;
             f32x4 g = ld4(a.dout + i * 4);
+            f32x4 xv = ld4(a.x + i * 4), m = ld4(a.mean + c), v = ld4(a.var + c), ga = ld4(a.gamma + c);
             if (a.alpha >= 0.f) {
-                f32x4 o = ld4(a.out + i * 4);
+                if (a.out) {
+                    f32x4 o = ld4(a.out + i * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : g[e] * a.alpha;
+                    for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : g[e] * a.alpha;
+                } else {
+                    const f32x4 b = ld4(a.beta + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        g[e] = fmaf(xv[e] - m[e], ga[e] * (1.0f / sqrtf(v[e] + a.eps)), b[e]) > 0.f ? g[e] : g[e] * a.alpha;
+                }
             }
             if (a.dshortcut) {
                 const int cs = c - cpad;
                 if (cs >= 0 && cs < a.Cs) st4(a.dshortcut + row * a.Cs + cs, g);
             }
-            f32x4 xv = ld4(a.x + i * 4), m = ld4(a.mean + c), v = ld4(a.var + c), ga = ld4(a.gamma + c);
             f32x4 r;
             if (a.training) {
                 f32x4 dg = ld4(a.dgamma + c), db = ld4(a.dbeta + c);
@@ -400,7 +424,10 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(BnBwdArgs a) {
         } else {
             const int c = cv;
             float g = a.dout[i];
-            if (a.alpha >= 0.f) g = a.out[i] > 0.f ? g : g * a.alpha;
+            if (a.alpha >= 0.f) {
+                const float o = a.out ? a.out[i] : fmaf(a.x[i] - a.mean[c], a.gamma[c] * (1.0f / sqrtf(a.var[c] + a.eps)), a.beta[c]);
+                g = o > 0.f ? g : g * a.alpha;
+            }
             if (a.dshortcut) {
                 const int cs = c - cpad;
                 if (cs >= 0 && cs < a.Cs) a.dshortcut[row * a.Cs + cs] = g;
@@ -744,29 +771,30 @@ int pnp_bn_apply(const float* x, const float* mean, const float* var, const floa
     return PNP_OK;
 }
 
-int pnp_bn_bwd_reduce(const float* dout, const float* out, const float* x, const float* mean, const float* var, float* dgamma,
-                      float* dbeta, int64_t P, int32_t C, float eps, float alpha, void* workspace, size_t workspace_bytes,
-                      void* stream) {
+int pnp_bn_bwd_reduce(const float* dout, const float* out, const float* x, const float* mean, const float* var, const float* gamma,
+                      const float* beta, float* dgamma, float* dbeta, int64_t P, int32_t C, float eps, float alpha, void* workspace,
+                      size_t workspace_bytes, void* stream) {
     PNP_REQUIRE(dout && x && mean && var && dgamma && dbeta && P > 0 && C > 0, "pnp_bn_bwd_reduce: bad argument");
-    PNP_REQUIRE(alpha < 0.f || out, "pnp_bn_bwd_reduce: `out` is required when an activation is fused");
+    PNP_REQUIRE(alpha < 0.f || out || (gamma && beta), "pnp_bn_bwd_reduce: a fused activation needs `out`, or gamma and beta to recompute its sign");
     PNP_REQUIRE((size_t)P * C < (1ull << 32), "pnp_bn_bwd_reduce: tensor exceeds 2^32 elements");
     ColArgs ca{};
     ca.x = x; ca.dout = dout; ca.out = out; ca.mean = mean; ca.var = var; ca.P = P; ca.C = C; ca.eps = eps; ca.alpha = alpha;
+    ca.gamma = gamma; ca.beta = beta;
     return run_colreduce<1>(ca, dbeta, dgamma, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_bwd_reduce");
 }
 
 int pnp_bn_bwd_apply(const float* dout, const float* out, const float* x, const float* mean, const float* var,
-                     const float* gamma, const float* dgamma, const float* dbeta, float* dx, float* dshortcut, int32_t Cs,
+                     const float* gamma, const float* beta, const float* dgamma, const float* dbeta, float* dx, float* dshortcut, int32_t Cs,
                      int64_t P, int64_t P_norm, int32_t C, float eps, float alpha, int32_t training, float keep_prob,
                      uint64_t seed, uint32_t stream_id, void* stream) {
     PNP_REQUIRE(dout && x && mean && var && gamma && dx && P > 0 && P_norm >= P && C > 0, "pnp_bn_bwd_apply: bad argument");
     PNP_REQUIRE(!training || (dgamma && dbeta), "pnp_bn_bwd_apply: training mode needs the dgamma / dbeta sums");
-    PNP_REQUIRE(alpha < 0.f || out, "pnp_bn_bwd_apply: `out` is required when an activation is fused");
+    PNP_REQUIRE(alpha < 0.f || out || (beta && !dshortcut), "pnp_bn_bwd_apply: a fused activation needs `out`, or beta (and no shortcut) to recompute its sign");
     PNP_REQUIRE((size_t)P * C < (1ull << 32), "pnp_bn_bwd_apply: tensor exceeds 2^32 elements");
     if (dshortcut) PNP_REQUIRE(Cs > 0 && Cs <= C && ((C - Cs) % 2) == 0, "pnp_bn_bwd_apply: bad shortcut channels");
     hipStream_t st = (hipStream_t)stream;
     BnBwdArgs a{};
-    a.dout = dout; a.out = out; a.x = x; a.mean = mean; a.var = var; a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.dout = dout; a.out = out; a.x = x; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.dgamma = dgamma; a.dbeta = dbeta;
     a.dx = dx; a.dshortcut = dshortcut; a.P = P; a.P_norm = P_norm; a.C = C; a.Cs = dshortcut ? Cs : C; a.eps = eps; a.alpha = alpha;
     a.training = training;
     a.do_drop = keep_prob < 1.f;
@@ -782,27 +810,28 @@ int pnp_bn_bwd_apply(const float* dout, const float* out, const float* x, const 
 }
 
 int pnp_bn_bwd(const float* dout, const float* out, const float* x, const float* mean, const float* var,
-               const float* gamma, float* dx, float* dgamma, float* dbeta, float* dshortcut, int32_t Cs, int64_t P,
+               const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, float* dshortcut, int32_t Cs, int64_t P,
                int32_t C, float eps, float alpha, int32_t training, float keep_prob, uint64_t seed, uint32_t stream_id,
                void* workspace, size_t workspace_bytes, void* stream) {
-    return pnp_bn_bwd_acc(dout, out, x, mean, var, gamma, dx, dgamma, dbeta, nullptr, nullptr, dshortcut, Cs, P, C, eps, alpha, training,
+    return pnp_bn_bwd_acc(dout, out, x, mean, var, gamma, beta, dx, dgamma, dbeta, nullptr, nullptr, dshortcut, Cs, P, C, eps, alpha, training,
                           keep_prob, seed, stream_id, workspace, workspace_bytes, stream);
 }
 
 int pnp_bn_bwd_acc(const float* dout, const float* out, const float* x, const float* mean, const float* var,
-                   const float* gamma, float* dx, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, float* dshortcut,
+                   const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, float* dshortcut,
                    int32_t Cs, int64_t P, int32_t C, float eps, float alpha, int32_t training, float keep_prob, uint64_t seed,
                    uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream) {
     PNP_REQUIRE(dout && x && mean && var && dgamma && dbeta && P > 0 && C > 0, "pnp_bn_bwd: bad argument");
-    PNP_REQUIRE(alpha < 0.f || out, "pnp_bn_bwd: `out` is required when an activation is fused");
+    PNP_REQUIRE(alpha < 0.f || out || (gamma && beta && !dshortcut), "pnp_bn_bwd: a fused activation needs `out`, or beta (and no shortcut) to recompute its sign");
     PNP_REQUIRE((size_t)P * C < (1ull << 32), "pnp_bn_bwd: tensor exceeds 2^32 elements");
     PNP_REQUIRE((dgamma_acc != nullptr) == (dbeta_acc != nullptr), "pnp_bn_bwd_acc: dgamma_acc and dbeta_acc go together");
     ColArgs ca{};
     ca.x = x; ca.dout = dout; ca.out = out; ca.mean = mean; ca.var = var; ca.P = P; ca.C = C; ca.eps = eps; ca.alpha = alpha;
+    ca.gamma = gamma; ca.beta = beta;
     if (int e = run_colreduce<1>(ca, dbeta, dgamma, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_bwd", nullptr, nullptr, 0.f,
                                  dbeta_acc, dgamma_acc))
         return e;
-    return pnp_bn_bwd_apply(dout, out, x, mean, var, gamma, dgamma, dbeta, dx, dshortcut, Cs, P, P, C, eps, alpha, training, keep_prob,
+    return pnp_bn_bwd_apply(dout, out, x, mean, var, gamma, beta, dgamma, dbeta, dx, dshortcut, Cs, P, P, C, eps, alpha, training, keep_prob,
                             seed, stream_id, stream);
 }
 

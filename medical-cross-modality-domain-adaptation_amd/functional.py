@@ -28,6 +28,10 @@ LEAK = 0.2         # tf.nn.leaky_relu default alpha (layers.py:12,35,166,187)
 FUSE_BN_INFER = os.environ.get("PNP_FUSE_BN_INFER", "1") != "0"
 # training-mode BN statistics from the convolution's epilogue (pnp_conv2d_fwd_stats) instead of a reduction pass over its output
 FUSE_BN_STATS = os.environ.get("PNP_FUSE_BN_STATS", "1") != "0"
+# backward of training-mode BN + activation WITHOUT a shortcut: the sign of the activation is recomputed from the BN input (bit for bit
+# the value the forward activated) instead of read back from the saved output — one activation-sized read less in the reduction and in
+# the apply kernel, and the unit's output is not kept for its own backward pass
+BN_RECOMPUTE_SIGN = os.environ.get("PNP_BN_RECOMPUTE_SIGN", "1") != "0"
 
 
 def sync_now():
@@ -96,7 +100,7 @@ def _wgrad(ctx, x, dy, sink):
     return K.conv2d_wgrad(x, dy, ctx.geom)
 
 
-def _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, keep, seed, sid):
+def _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, keep, seed, sid, beta=None):
     """backward of BN (+activation, +dropout mask of the conv in front).  With synchronised statistics the per-channel sums are
     all-reduced between the reduction and the apply kernel; the PARAMETER gradients stay local (the GradReducer sums them).
     Returns (dxc, dgamma, dbeta, dsc); dgamma / dbeta are None when they went straight into the variables' gradient slots."""
@@ -105,16 +109,17 @@ def _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, keep, seed, sid):
     if slots is not None and (slots[0] is None or slots[1] is None):
         slots = None
     if ctx.is_train and ctx.P_norm != xc.numel() // xc.shape[-1]:
-        sums = K.bn_bwd_reduce(dout, out, xc, mean, var, BN_EPS, ctx.alpha)
+        sums = K.bn_bwd_reduce(dout, out, xc, mean, var, BN_EPS, ctx.alpha, gamma, beta)
         gsums = par.all_sum_(sums.clone())
-        dxc, dsc = K.bn_bwd_apply(dout, out, xc, mean, var, gamma, gsums, ctx.P_norm, need_sc, BN_EPS, ctx.alpha, True, keep, seed, sid)
+        dxc, dsc = K.bn_bwd_apply(dout, out, xc, mean, var, gamma, gsums, ctx.P_norm, need_sc, BN_EPS, ctx.alpha, True, keep, seed, sid,
+                                  beta=beta)
         dgamma, dbeta = sums[0], sums[1]
         if slots is not None:                   # (opt-in SyncBN path: two [C]-sized adds)
             K.axpby(dgamma, slots[0], 1.0, 1.0)
             K.axpby(dbeta, slots[1], 1.0, 1.0)
     else:
         dxc, dgamma, dbeta, dsc = K.bn_bwd(dout, out, xc, mean, var, gamma, need_sc, BN_EPS, ctx.alpha, ctx.is_train, keep, seed, sid,
-                                           into=slots)
+                                           into=slots, beta=beta)
     if slots is not None:
         gradsink.done(sinks[0])
         gradsink.done(sinks[1])
@@ -201,12 +206,17 @@ class ConvBNActFn(Function):
         else:
             mean, var = _frozen_stats(ctx, moving_mean, moving_var)
         out = K.bn_apply(xc, mean, var, gamma, beta, sc, BN_EPS, alpha)
-        ctx.save_for_backward(x, w_, xc, out, mean, var, gamma)
+        # no shortcut: the backward kernels recompute the activation's sign from xc, gamma, beta — `out` is not kept for this unit
+        ctx.resign = BN_RECOMPUTE_SIGN and sc is None and alpha >= 0.0
+        ctx.save_for_backward(x, w_, xc, beta if ctx.resign else out, mean, var, gamma)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, w, xc, out, mean, var, gamma = ctx.saved_tensors
+        beta = None
+        if getattr(ctx, "resign", False):
+            out, beta = None, out
         _check_frozen_stats(ctx, mean, var)
         dout = _contig(dout)
         need_sc = ctx.sc_channels if ctx.needs_input_grad[6] else 0
@@ -215,7 +225,7 @@ class ConvBNActFn(Function):
                                       ctx.seed, ctx.sid)
             dgamma = dbeta = None
         else:
-            dxc, dgamma, dbeta, dsc = _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, ctx.keep, ctx.seed, ctx.sid)
+            dxc, dgamma, dbeta, dsc = _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, ctx.keep, ctx.seed, ctx.sid, beta)
         res = None
         if ctx.link is not None:
             if ctx.sc_channels:             # tail of a block: the head's data-gradient kernel adds the shortcut gradient

@@ -226,8 +226,9 @@ def bn_apply(x, mean, var, gamma, beta, shortcut=None, eps=1e-3, alpha=0.2):
 
 
 def bn_bwd(dout, out, x, mean, var, gamma, shortcut_channels=0, eps=1e-3, alpha=0.2, training=True, keep_prob=1.0, seed=0,
-           stream_id=0, into=None):
-    """`into` = (dgamma_slot, dbeta_slot): the parameter gradients are also ADDED to these [C] buffers (pnp_bn_bwd_acc)"""
+           stream_id=0, into=None, beta=None):
+    """`into` = (dgamma_slot, dbeta_slot): the parameter gradients are also ADDED to these [C] buffers (pnp_bn_bwd_acc).
+    out=None (with `beta`, units without a shortcut): the kernels recompute the activation's sign from x instead of reading `out`"""
     lib = _lib.load()
     C = x.shape[-1]
     P = x.numel() // C
@@ -239,31 +240,31 @@ def bn_bwd(dout, out, x, mean, var, gamma, shortcut_channels=0, eps=1e-3, alpha=
         dsc = torch.empty(x.shape[:-1] + (shortcut_channels,), dtype=torch.float32, device=x.device)
     ws = workspace(lib.pnp_bn_workspace_bytes(P, C), x.device)
     if into is not None:
-        check(lib.pnp_bn_bwd_acc(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(into[0]),
+        check(lib.pnp_bn_bwd_acc(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta), _p(into[0]),
                                  _p(into[1]), _p(dsc), shortcut_channels, P, C, float(eps), float(alpha), 1 if training else 0,
                                  float(keep_prob), int(seed), int(stream_id), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
               "pnp_bn_bwd_acc")
         return dx, dgamma, dbeta, dsc
-    check(lib.pnp_bn_bwd(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(dsc),
+    check(lib.pnp_bn_bwd(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta), _p(dsc),
                          shortcut_channels, P, C, float(eps), float(alpha), 1 if training else 0, float(keep_prob), int(seed),
                          int(stream_id), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_bn_bwd")
     return dx, dgamma, dbeta, dsc
 
 
-def bn_bwd_reduce(dout, out, x, mean, var, eps=1e-3, alpha=0.2):
+def bn_bwd_reduce(dout, out, x, mean, var, eps=1e-3, alpha=0.2, gamma=None, beta=None):
     """local sums (dgamma = sum dz*xhat, dbeta = sum dz) — first half of bn_bwd, for SyncBN"""
     lib = _lib.load()
     C = x.shape[-1]
     P = x.numel() // C
     sums = torch.empty((2, C), dtype=torch.float32, device=x.device)      # [dgamma, dbeta]
     ws = workspace(lib.pnp_bn_workspace_bytes(P, C), x.device)
-    check(lib.pnp_bn_bwd_reduce(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(sums[0]), _p(sums[1]), P, C, float(eps), float(alpha),
+    check(lib.pnp_bn_bwd_reduce(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(sums[0]), _p(sums[1]), P, C, float(eps), float(alpha),
                                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_bn_bwd_reduce")
     return sums
 
 
 def bn_bwd_apply(dout, out, x, mean, var, gamma, sums, P_norm, shortcut_channels=0, eps=1e-3, alpha=0.2, training=True, keep_prob=1.0,
-                 seed=0, stream_id=0):
+                 seed=0, stream_id=0, beta=None):
     """second half of bn_bwd with the (possibly all-reduced) sums and the row count behind them"""
     lib = _lib.load()
     C = x.shape[-1]
@@ -273,7 +274,7 @@ def bn_bwd_apply(dout, out, x, mean, var, gamma, sums, P_norm, shortcut_channels
     if shortcut_channels:
         dsc = torch.empty(x.shape[:-1] + (shortcut_channels,), dtype=torch.float32, device=x.device)
     dg, db = (sums[0], sums[1]) if sums is not None else (None, None)      # not read in inference mode
-    check(lib.pnp_bn_bwd_apply(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(dg), _p(db), _p(dx), _p(dsc),
+    check(lib.pnp_bn_bwd_apply(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(dg), _p(db), _p(dx), _p(dsc),
                                shortcut_channels, P, int(P_norm), C, float(eps), float(alpha), 1 if training else 0, float(keep_prob),
                                int(seed), int(stream_id), _stream()), "pnp_bn_bwd_apply")
     return dx, dsc

@@ -99,6 +99,13 @@ class Checker(object):
                     if need_sc:
                         errs["dshortcut"] = rel(dsc, sc.grad)
                     self.kernels.add("bn_bwd_train")
+                    if sc is None and alpha >= 0.0:
+                        # the product does not keep `out` for such a unit: the kernels recompute the activation's sign from the BN
+                        # input.  Must equal, BIT FOR BIT, the backward that is handed the kernels' own forward output.
+                        a = K.bn_bwd(f32(out.grad), out_hip, xc, mean_d, var_d, gam, 0, EPS, alpha, True, keep, self.seed, sid)
+                        b_ = K.bn_bwd(f32(out.grad), None, xc, mean_d, var_d, gam, 0, EPS, alpha, True, keep, self.seed, sid, beta=bet)
+                        errs["resign_bits"] = float(sum(int((u_ != v_).sum()) for u_, v_ in zip(a[:3], b_[:3])))
+                        self.kernels.add("bn_bwd_resign")
             else:
                 # frozen BN: the product folds it (+ shortcut + leaky-ReLU) into the convolution's epilogue (pnp_conv2d_fwd_bn)
                 out_hip = K.conv2d_fwd_bn(xin_d, wd, g, K.bn_fold(gam, bet, mm0, mv0, EPS), scd, alpha, keep, self.seed, sid)

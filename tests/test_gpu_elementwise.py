@@ -67,6 +67,14 @@ def test_bn_unit_fwd_bwd(dev, shape, Cs, alpha, training):
     assert _rel(dbeta, b_t.grad) < 1e-4
     if sc is not None:
         assert _rel(dsc, sc_t.grad) < 1e-5
+    if sc is None and alpha >= 0:
+        # `out` not handed in: the kernels recompute the activation's sign from the BN input (what functional.ConvBNActFn does for
+        # units without a shortcut) — bit for bit the backward that reads the saved output, scalar (C % 4 != 0) and vector kernels alike
+        dxr, dgr, dbr, _ = K.bn_bwd(torch.from_numpy(dout).to(dev), None, xcd, mean, var, gd, 0, 1e-3, alpha, training, keep, seed, sid,
+                                    beta=bd)
+        assert torch.equal(dxr, dxa) and torch.equal(dgr, dgamma) and torch.equal(dbr, dbeta)
+        with pytest.raises(pkg("_lib").PnpError):
+            K.bn_bwd(torch.from_numpy(dout).to(dev), None, xcd, mean, var, gd, 0, 1e-3, alpha, training, keep, seed, sid)      # no beta
     # pnp_bn_bwd_acc: the same sums also added into caller-owned slots, twice (a BN layer shared by two passes)
     sg, sb = torch.full((C,), 2.0, device=dev), torch.full((C,), -1.0, device=dev)
     for rep in (1, 2):
