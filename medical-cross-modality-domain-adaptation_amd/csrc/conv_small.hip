@@ -346,7 +346,8 @@ int launch_n16_fwd(const ConvArgs& a, int kind, hipStream_t st) {
 bool n16_wgrad_ok(const pnp_conv_geom* g) {
     if (n16_geom_ok(g)) return true;
     static const int off = getenv("PNP_CONV_NON16") ? 1 : 0;
-    if (off || (g->K != 32 && g->K != 64) || (g->C != 16 && g->C != 32) || g->R != 3 || g->S != 3 || g->stride != 1 || g->dil != 1) return false;
+    static const int maxk = getenv("PNP_N16W_MAXK") ? atoi(getenv("PNP_N16W_MAXK")) : 64;       // A/B against the ring kernel's 128x64 tiles
+    if (off || g->K > maxk || (g->K != 32 && g->K != 64) || (g->C != 16 && g->C != 32) || g->R != 3 || g->S != 3 || g->stride != 1 || g->dil != 1) return false;
     if (g->pad_mode != PNP_PAD_ZERO || g->pad_t > 1 || g->pad_l > 1 || g->dtype != PNP_DTYPE_F32) return false;
     if (g->OH != g->H + 2 * g->pad_t - 2 || g->OW != g->W + 2 * g->pad_l - 2) return false;
     return (long long)g->N * g->OH * g->OW >= 8192;

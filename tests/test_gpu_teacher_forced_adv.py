@@ -126,7 +126,9 @@ def test_every_kernel_of_every_adaptation_unit_teacher_forced_B16(dev):
               len(rows), np.median(eh), eh.max(), min(r[3] for r in rows), np.median(ec), ec.max(), min(r[4] for r in rows), float(loss),
               float(gen32), float(gen64), rel(net.ct_logits, logits64), rel(o32["ct_logits"], logits64)))
     assert rel(net.ct_logits, logits64) < 1e-4
-    assert abs(float(loss) - float(gen64)) < 1e-4 * abs(float(gen64)) + 1e-8
+    # (the loss is a 0.002-weighted mean of critic scores that nearly cancel: float32 evaluation noise on it is ~3e-4 relative — measured
+    # r3b: hip 3.1e-4, cpu-float32 2.5e-4 from float64 — so the bar is the float32 oracle's own distance, not 1e-4)
+    assert abs(float(loss) - float(gen64)) < max(3.0 * abs(float(gen32) - float(gen64)), 1e-4 * abs(float(gen64))) + 1e-8
     # "same error class as another float32 evaluation of the graph": the product may not be further from float64 than a small multiple of
     # what the float32 CPU oracle is (its own distance is pure evaluation-order noise amplified by leaky-ReLU / max-pool / dropout kinks)
     assert np.median(eh) < 5.0 * np.median(ec) + 1e-4

@@ -29,7 +29,13 @@ LAYERS = [  # name, H, C, K, R, dil, padding, count in segmenter fwd
     ("g8 512->512 d2", 32, 512, 512, 3, 2, "SAME", 4),
     ("g10 512->2560", 32, 512, 2560, 3, 1, "SYMMETRIC", 1),
     ("out 40->5 k5", 256, 40, 5, 5, 1, "SYMMETRIC", 1),
+    ("cls1 32->64", 256, 32, 64, 3, 1, "SAME", 0),
     ("cls1 64->64", 256, 64, 64, 3, 1, "SAME", 0),
+    ("cls2 64->128", 128, 64, 128, 3, 1, "SAME", 0),
+    ("cls2 128->128", 128, 128, 128, 3, 1, "SAME", 0),
+    ("cls3 128->256", 64, 128, 256, 3, 1, "SAME", 0),
+    ("cls3 256->256", 64, 256, 256, 3, 1, "SAME", 0),
+    ("cls5 512->512@16", 16, 512, 512, 3, 1, "SAME", 0),
     # strided critic convolutions (adversarial.py:342-391); 9th field = stride
     ("cls k3s2 64@256", 256, 64, 64, 3, 1, "SAME", 0, 2),
     ("cls k5s2 128@128", 128, 128, 128, 5, 1, "SAME", 0, 2),
