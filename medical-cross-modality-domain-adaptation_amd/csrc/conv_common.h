@@ -51,7 +51,26 @@ struct ConvArgs {
     // (un-split launches; split launches accumulate in the reduce kernel)
     const float* res_add;
     int accumulate;
+    // OW and OH*OW powers of two (every layer of the model): log2 of both, so that row -> (image, oh, ow) is two shifts and two masks
+    // instead of two integer divisions (~25 VALU each; a 128x64 tile of a 64-channel layer spends ~3 % of its life on them, the
+    // scattered epilogue of a stride-phase data gradient far more); -1: divide
+    int ow_sh, ohw_sh;
 };
+
+// output row m -> (image n, oh, ow)
+__device__ __forceinline__ void split_row(const ConvArgs& a, int m, int& n, int& oh, int& ow) {
+    if (a.ohw_sh >= 0) {            // uniform
+        n = m >> a.ohw_sh;
+        const int rem = m & (a.OHW - 1);
+        oh = rem >> a.ow_sh;
+        ow = rem & (a.OW - 1);
+    } else {
+        n = m / a.OHW;
+        const int rem = m - n * a.OHW;
+        oh = rem / a.OW;
+        ow = rem - oh * a.OW;
+    }
+}
 
 __device__ __forceinline__ float bn_epilogue(const ConvArgs& a, float v, int m, int n) {
     v = fmaf(v, a.ep_scale[n], a.ep_shift[n]);
@@ -64,10 +83,8 @@ __device__ __forceinline__ float bn_epilogue(const ConvArgs& a, float v, int m, 
 
 __device__ __forceinline__ size_t out_row(const ConvArgs& a, int m, bool scatter) {
     if (!scatter) return (size_t)m * a.K;
-    const int n = m / a.OHW;
-    const int rem = m - n * a.OHW;
-    const int oh = rem / a.OW;
-    const int ow = rem - oh * a.OW;
+    int n, oh, ow;
+    split_row(a, m, n, oh, ow);
     return ((size_t)(n * a.o_H + a.o_h0 + oh * a.o_s) * a.o_W + a.o_w0 + ow * a.o_s) * a.K;
 }
 

@@ -107,10 +107,8 @@ struct FwdALoader {
             int m = m0 + mrow + 32 * i;
             bool ok = m < a.M;
             if (!ok) m = 0;
-            int n = m / a.OHW;
-            int rem = m - n * a.OHW;
-            int oh = rem / a.OW;
-            int ow = rem - oh * a.OW;
+            int n, oh, ow;
+            split_row(a, m, n, oh, ow);
             pixbase[i] = n * a.H * a.W;
             vh0[i] = oh * a.stride - a.pad_t;
             vw0[i] = ow * a.stride - a.pad_l;
@@ -337,6 +335,32 @@ struct Frag {
                     acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[j][tn], acc.v[tm][tn], 0, 0, 0);
     }
 };
+// Split accumulation (narrow tiles): a wave with TM*TN <= 2 accumulator tiles rotates through only two dependent MFMA chains; with a
+// second accumulator set for the odd k of every 8-group it rotates through four, like the 2x2 tile (summed once in front of the epilogue).
+#ifndef PNP_SPLIT_ACC
+#define PNP_SPLIT_ACC 0
+#endif
+template <int TM, int TN, bool A_MMAJOR, int LDA, int LDB>
+__device__ __forceinline__ void frag_mma2(const Frag<TM, TN, A_MMAJOR, LDA, LDB>& f, Acc<TM, TN>& acc0, Acc<TM, TN>& acc1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                if (j & 1) acc1.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][j], f.b[j][tn], acc1.v[tm][tn], 0, 0, 0);
+                else acc0.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][j], f.b[j][tn], acc0.v[tm][tn], 0, 0, 0);
+            }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void acc_add(Acc<TM, TN>& a, const Acc<TM, TN>& b) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a.v[i][j][e] += b.v[i][j][e];
+}
 #define PNP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // Schedule of slices 1..3 of a stage (two Frag sets: the fragment reads of the NEXT slice and the MFMAs of THIS slice are independent).
 // PNP_CONV_ILV selects where the next stage's LDS stores go (compile-time; measured A/B/A/B on the 512-channel layers at B=16):
@@ -555,6 +579,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_dgrad_phases_kernel(GroupArg
     a.R = d.R; a.S = d.S; a.OH = d.OH; a.OW = d.OW; a.pad_t = d.pad_t; a.pad_l = d.pad_l;
     a.o_h0 = d.o_h0; a.o_w0 = d.o_w0;
     a.OHW = d.OH * d.OW;
+    a.ow_sh = a.ohw_sh = -1;                  // per-phase extents: divide
     a.M = a.N * a.OHW;
     a.Kred = d.R * d.S * a.C;
     a.w_bytes = (unsigned)(a.Kred * a.K) * 4u;
@@ -612,10 +637,8 @@ __global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS
         int m = m0 + mrow + 32 * i;
         const bool ok = m < a.M;
         if (!ok) m = 0;
-        const int n = m / a.OHW;
-        const int rem = m - n * a.OHW;
-        const int oh = rem / a.OW;
-        const int ow = rem - oh * a.OW;
+        int n, oh, ow;
+        split_row(a, m, n, oh, ow);
         const int vh0 = oh * a.stride - a.pad_t, vw0 = ow * a.stride - a.pad_l;
         abase[i] = (((n * a.H + vh0) * a.W + vw0) * a.C + 4 * kg) * 4;
         unsigned mk = 0;
@@ -754,10 +777,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
         int m = m0 + mrow + 32 * i;
         const bool ok = m < a.M;
         if (!ok) m = 0;
-        const int n = m / a.OHW;
-        const int rem = m - n * a.OHW;
-        const int oh = rem / a.OW;
-        const int ow = rem - oh * a.OW;
+        int n, oh, ow;
+        split_row(a, m, n, oh, ow);
         const int vh0 = oh * a.stride - a.pad_t, vw0 = ow * a.stride - a.pad_l;
         abase[i] = (((n * a.H + vh0) * a.W + vw0) * a.C + 4 * kg) * 4;
         unsigned mk = 0;
@@ -801,8 +822,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
         for (int i = 0; i < NPB; ++i) *reinterpret_cast<f32x4*>(Bn + (brow + RPB * i) * LDB + 4 * bcol) = r.b[i];
     };
 
-    Acc<TM, TN> acc;
+    constexpr bool SPLIT = PNP_SPLIT_ACC != 0 && TM * TN <= 2;
+    Acc<TM, TN> acc, accb;
     acc.zero();
+    if constexpr (SPLIT) accb.zero();
+#define PNP_T3_MMA(F) do { if constexpr (SPLIT) frag_mma2(F, acc, accb); else F.mma(acc); } while (0)
 
     const int ncc_total = a.C / BK;
     const int cc_begin = z * (a.chunks_per_split / NTAP);
@@ -841,7 +865,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
                 // ---- slice 0: this stage's slice-1 fragments, the global loads of stage s+3 into the ring slot stored LAST stage
                 f1.load(As, Bs, 1, wm0, wn0, lane);
                 gload(ring[par ^ 1], PNP_T3_CC(cc, tap, 3), PNP_T3_TAP(tap, 3));
-                f0.mma(acc);
+                PNP_T3_MMA(f0);
                 __builtin_amdgcn_sched_group_barrier(0x100, TM + 4 * TN, 0);
 #pragma unroll
                 for (int i = 0; i < NMF; ++i) {
@@ -850,13 +874,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
                 PNP_SCHED_FENCE();
-                PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), NMF, NDS)
-                PNP_SLICE(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), NMF, NDS)
+                PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), PNP_T3_MMA(f1), NMF, NDS)
+                PNP_SLICE(f1.load(As, Bs, 3, wm0, wn0, lane), PNP_T3_MMA(f0), NMF, NDS)
                 // ---- last slice: the NEXT stage's slice-0 fragments (visible since the previous barrier) and the LDS stores of stage
                 // s+2 ride behind the MFMAs; the barrier then has nothing to wait for but the slowest wave
                 f0.load(An, Bn, 0, wm0, wn0, lane);
                 PNP_SCHED_FENCE();
-                f1.mma(acc);
+                PNP_T3_MMA(f1);
                 lstore(ring[par], Ast, Bst);
                 __builtin_amdgcn_sched_group_barrier(0x008, NMF / 2, 0);
 #pragma unroll
@@ -875,6 +899,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
     }
 #undef PNP_T3_CC
 #undef PNP_T3_TAP
+#undef PNP_T3_MMA
+    if constexpr (SPLIT) acc_add(acc, accb);
 
     conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
 }
@@ -1687,6 +1713,9 @@ ConvArgs make_args(const float* x, const float* w, float* y, const pnp_conv_geom
     a.Kred = g->R * g->S * g->C;
     a.OHW = g->OH * g->OW;
     a.nsplit = 1; a.chunks_per_split = 0; a.split_stride = 0;
+    const bool p2 = (a.OW & (a.OW - 1)) == 0 && (a.OHW & (a.OHW - 1)) == 0;
+    a.ow_sh = p2 ? __builtin_ctz((unsigned)a.OW) : -1;
+    a.ohw_sh = p2 ? __builtin_ctz((unsigned)a.OHW) : -1;
     a.do_drop = 0; a.drop_scale = 1.f; a.drop_key = 0; a.drop_thresh = 0;
     static const int env_noswz = getenv("PNP_CONV_NOSWIZZLE") ? 1 : 0;
     a.xcd_swizzle = env_noswz ? 0 : 1;
