@@ -844,8 +844,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
     gload(ring[0], PNP_T3_CC(cc_begin, 0, 2), PNP_T3_TAP(0, 2));
     lstore(ring[1], lds + STG, lds + STG + ASZ);
     __syncthreads();
-    Frag<TM, TN, true, LDA, LDB> f0, f1;
-    f0.load(lds, lds + ASZ, 0, wm0, wn0, lane);
+    // Fragment ring of four 8-k slices: slice q of a stage is contracted while slice q+2 is being read — two slices (16 MFMAs of a 2x1
+    // wave tile) of cover for every LDS read instead of one, and the lookahead runs across the stage boundary (the next stage is visible)
+    Frag<TM, TN, true, LDA, LDB> fr[4];
+    fr[0].load(lds, lds + ASZ, 0, wm0, wn0, lane);
+    fr[1].load(lds, lds + ASZ, 1, wm0, wn0, lane);
     int o_cur = 0, o_nxt = STG, o_st = 2 * STG;        // float offsets of the LDS stages holding s, s+1 and receiving s+2
     constexpr int NMF = 4 * TM * TN;
     constexpr int NDS = (TM + 4 * TN + NMF - 1) / NMF;
@@ -862,10 +865,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
                 const float* Bn = An + ASZ;
                 float* Ast = lds + o_st;
                 float* Bst = Ast + ASZ;
-                // ---- slice 0: this stage's slice-1 fragments, the global loads of stage s+3 into the ring slot stored LAST stage
-                f1.load(As, Bs, 1, wm0, wn0, lane);
+                // ---- slice 0: fragments of slice 2, the global loads of stage s+3 into the ring slot stored LAST stage
+                fr[2].load(As, Bs, 2, wm0, wn0, lane);
                 gload(ring[par ^ 1], PNP_T3_CC(cc, tap, 3), PNP_T3_TAP(tap, 3));
-                PNP_T3_MMA(f0);
+                PNP_T3_MMA(fr[0]);
                 __builtin_amdgcn_sched_group_barrier(0x100, TM + 4 * TN, 0);
 #pragma unroll
                 for (int i = 0; i < NMF; ++i) {
@@ -874,13 +877,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
                 PNP_SCHED_FENCE();
-                PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), PNP_T3_MMA(f1), NMF, NDS)
-                PNP_SLICE(f1.load(As, Bs, 3, wm0, wn0, lane), PNP_T3_MMA(f0), NMF, NDS)
-                // ---- last slice: the NEXT stage's slice-0 fragments (visible since the previous barrier) and the LDS stores of stage
-                // s+2 ride behind the MFMAs; the barrier then has nothing to wait for but the slowest wave
-                f0.load(An, Bn, 0, wm0, wn0, lane);
+                PNP_SLICE(fr[3].load(As, Bs, 3, wm0, wn0, lane), PNP_T3_MMA(fr[1]), NMF, NDS)
+                // ---- slices 2, 3: the NEXT stage's slices 0, 1 (visible since the previous barrier); the LDS stores of stage s+2 ride
+                // behind the last MFMAs; the barrier then has nothing to wait for but the slowest wave
+                PNP_SLICE(fr[0].load(An, Bn, 0, wm0, wn0, lane), PNP_T3_MMA(fr[2]), NMF, NDS)
+                fr[1].load(An, Bn, 1, wm0, wn0, lane);
                 PNP_SCHED_FENCE();
-                PNP_T3_MMA(f1);
+                PNP_T3_MMA(fr[3]);
                 lstore(ring[par], Ast, Bst);
                 __builtin_amdgcn_sched_group_barrier(0x008, NMF / 2, 0);
 #pragma unroll

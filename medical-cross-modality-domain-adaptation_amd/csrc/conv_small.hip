@@ -350,6 +350,9 @@ bool n16_wgrad_ok(const pnp_conv_geom* g) {
     if (off || g->K > maxk || (g->K != 32 && g->K != 64) || (g->C != 16 && g->C != 32) || g->R != 3 || g->S != 3 || g->stride != 1 || g->dil != 1) return false;
     if (g->pad_mode != PNP_PAD_ZERO || g->pad_t > 1 || g->pad_l > 1 || g->dtype != PNP_DTYPE_F32) return false;
     if (g->OH != g->H + 2 * g->pad_t - 2 || g->OW != g->W + 2 * g->pad_l - 2) return false;
+    // 64 filters over >= 2^19 pixels (cls_1's 32 -> 64 at 256^2): the ring kernel's 128x64 tiles win there (measured B = 16: 0.728 ms here,
+    // 0.583 ms on conv_wgrad_ring_kernel); on the 64^2 layer of the same shape this kernel wins 0.054 vs 0.106
+    if (g->K == 64 && (long long)g->N * g->OH * g->OW >= (1ll << 19)) return false;
     return (long long)g->N * g->OH * g->OW >= 8192;
 }
 
