@@ -299,6 +299,8 @@ int pnp_comm_destroy(void* comm);
 
 /* y = a*x + b*y elementwise (gradient fan-in adds) */
 int pnp_axpby(const float* x, float* y, size_t n, float a, float b, void* stream);
+/* out = x + y (out may alias neither): the gradient sum of a tensor that feeds two branches of the graph (TF autodiff's AddN) */
+int pnp_add(const float* x, const float* y, float* out, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "pnp_critic_input_fwd": (c_int, [_F, c_int32, c_int32, _F, c_int32, _F, c_int32, _F, c_int32, _F, c_int32, _F, c_int64, c_void_p]),
     "pnp_critic_input_bwd": (c_int, [_F, _F, c_int32, c_int32, _F, c_int32, _F, c_int32, _F, c_int32, _F, c_int32, c_int64, c_void_p]),
     "pnp_axpby": (c_int, [_F, _F, c_size_t, c_float, c_float, c_void_p]),
+    "pnp_add": (c_int, [_F, _F, _F, c_size_t, c_void_p]),
     "pnp_wgan_loss": (c_int, [_F, _F, _F, _F, c_int32, c_float, c_float, c_float, c_float, _F, c_void_p]),
     "pnp_fill": (c_int, [_F, c_size_t, c_float, c_void_p]),
     "pnp_label_decomp": (c_int, [_F, _F, c_int64, c_int32, c_void_p]),

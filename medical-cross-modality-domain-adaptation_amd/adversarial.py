@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
-from .functional import Conv2dDropFn, CriticInputFn, WganLossFn
+from .functional import Conv2dDropFn, CriticInputFn, WganLossFn, fan_out
 from .layers import (DR_block, conv2d, conv_bn_relu2d, max_pool2d, residual_block, sharable_weight_variable, weight_variable)
 from .lib import _dice_eval, _label_decomp
 from .ops import PS
@@ -145,8 +145,8 @@ class Full_DRN(object):
                     b2 = residual_block(b1, wc, wd, keep_prob=keep_prob, is_train=bn, leak=True, bn_trainable=trainable, scope=bns(k, 2))
                     wl += [wa, wb, wc, wd]
                     h = max_pool2d(b2, n=2) if pool else b2
-                if k == 4:
-                    res[branch + "_c4"] = b2
+                if k == 4:          # conv4_2 feeds group 5 AND the feature critic
+                    h, res[branch + "_c4"] = fan_out(b2)
             res[branch + "_c6"] = h
         return res
 
@@ -163,10 +163,11 @@ class Full_DRN(object):
             wr7_3, wr7_4 = sw([3, 3, fb * 32, fb * 32], "Variable_2"), sw([3, 3, fb * 32, fb * 32], "Variable_3")
             block7_2 = residual_block(block7_1, wr7_3, wr7_4, keep_prob=keep_prob, leak=True, is_train=joint_bn,
                                       bn_trainable=joint_trainable, scope='pred_7_2')
+            b7_seg, block7_2 = fan_out(block7_2)        # feeds group 8 AND the feature critic (gradients summed by pnp_add)
             wl += [wr7_1, wr7_2, wr7_3, wr7_4]
         with st.variable_scope('group_8'):
             wr8_1, wr8_2 = sw([3, 3, fb * 32, fb * 32], "Variable"), sw([3, 3, fb * 32, fb * 32], "Variable_1")
-            block8_1 = DR_block(block7_2, wr8_1, wr8_2, keep_prob=keep_prob, leak=True, is_train=joint_bn, rate=2,
+            block8_1 = DR_block(b7_seg, wr8_1, wr8_2, keep_prob=keep_prob, leak=True, is_train=joint_bn, rate=2,
                                 bn_trainable=joint_trainable, scope='pred_8_1')
             wr8_3, wr8_4 = sw([3, 3, fb * 32, fb * 32], "Variable_2"), sw([3, 3, fb * 32, fb * 32], "Variable_3")
             block8_2 = DR_block(block8_1, wr8_3, wr8_4, keep_prob=keep_prob, leak=True, is_train=joint_bn, rate=2,
@@ -177,10 +178,11 @@ class Full_DRN(object):
             conv9_1 = conv_bn_relu2d(block8_2, w9_1, keep_prob, leak=True, is_train=joint_bn, bn_trainable=joint_trainable, scope='pred_9_1')
             w9_2 = sw([3, 3, fb * 32, fb * 32], "Variable_1")
             conv9_2 = conv_bn_relu2d(conv9_1, w9_2, keep_prob, leak=True, is_train=joint_bn, bn_trainable=joint_trainable, scope='pred_9_2')
+            c9_seg, conv9_2 = fan_out(conv9_2)          # feeds group 10 AND the feature critic
             wl += [w9_1, w9_2]
         with st.variable_scope('group_10'):
             w10_1 = sw([3, 3, fb * 32, 8 * 8 * num_cls * 8], "Variable")
-            conv10_1 = conv2d(conv9_2, w10_1, keep_prob_=keep_prob, padding='SYMMETRIC')
+            conv10_1 = conv2d(c9_seg, w10_1, keep_prob_=keep_prob, padding='SYMMETRIC')
             wl.append(w10_1)
             flat_conv10_1 = PS(conv10_1, r=8, n_channel=num_cls * 8, batch_size=self.batch_size)
         with st.variable_scope('output'):
@@ -284,7 +286,9 @@ class Full_DRN(object):
                 feats = {}
                 for br in ("ct", "mr"):          # CT first, then MR (adversarial.py:91-92)
                     if br + "_c6" in z:
-                        feats[br] = self.create_second_half(z[br + "_c6"], feature_base=self.feature_base, input_channel=3, num_cls=nc,
+                        # conv6_2 feeds the shared half AND the feature critic: two autograd edges, gradients summed by pnp_add (fan_out)
+                        c6_seg, z[br + "_c6"] = fan_out(z[br + "_c6"]) if critics else (z[br + "_c6"], z[br + "_c6"])
+                        feats[br] = self.create_second_half(c6_seg, feature_base=self.feature_base, input_channel=3, num_cls=nc,
                                                             keep_prob=keep_prob, joint_bn=joint_bn, joint_trainable=self.joint_trainable)
             for br in feats:
                 out[br + "_logits"] = feats[br][3]
@@ -294,7 +298,9 @@ class Full_DRN(object):
                 for br in ("ct", "mr"):
                     if br in feats:
                         c9, b8, b7, lg = feats[br]
-                        out[br + "_cls"] = self.create_classifier(z[br + "_c4"], z[br + "_c6"], b7, c9, lg, feature_base=self.feature_base,
+                        lg_cls, lg_mask = fan_out(lg)          # the logits feed both critics
+                        feats[br] = (c9, b8, b7, lg_mask)
+                        out[br + "_cls"] = self.create_classifier(z[br + "_c4"], z[br + "_c6"], b7, c9, lg_cls, feature_base=self.feature_base,
                                                                   cls_trainable=self.cls_trainable, **ckw)
                         out[br + "_logits"] = lg
             with st.variable_scope("mask_cls_scope"):
@@ -347,7 +353,7 @@ class Full_DRN(object):
         use_mask = lam != 0.0
         loss = WganLossFn.apply(o["ct_cls"], o["mr_cls"], o["ct_mask"] if use_mask else None, o["mr_mask"] if use_mask else None,
                                 (mu, -mu, lam * mu, -lam * mu), 1.0 / self.world_size)
-        loss.backward()
+        loss.backward(self.store.unit_grad(1))
         self.dis_loss = loss.detach()
         self.ct_logits, self.mr_logits = o["ct_logits"], o["mr_logits"]
         return self.dis_loss
@@ -360,7 +366,7 @@ class Full_DRN(object):
         lam, mu = self.lambda_mask_loss, self.miu_gen
         use_mask = lam != 0.0
         loss = WganLossFn.apply(o["ct_cls"], None, o["ct_mask"] if use_mask else None, None, (-mu, 0.0, -lam * mu, 0.0), 1.0 / self.world_size)
-        loss.backward()
+        loss.backward(self.store.unit_grad(1))
         self.ct_gen_loss = loss.detach()
         self.ct_logits = o["ct_logits"]
         return self.ct_gen_loss

@@ -473,6 +473,17 @@ __global__ void __launch_bounds__(NT) axpby_kernel(const float* __restrict__ x, 
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += gs) y[i] = a * x[i] + b * y[i];
 }
 
+// out = x + y: the sum TF's autodiff emits as AddN where a tensor feeds two branches (functional.FanOutFn)
+__global__ void __launch_bounds__(NT) add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, size_t n) {
+    const size_t gs = (size_t)gridDim.x * NT;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += gs) {
+        const f32x4 xv = ld4(x + i * 4), yv = ld4(y + i * 4);
+        st4(out + i * 4, xv + yv);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += gs) out[i] = x[i] + y[i];
+}
+
 // ---- 2x2/2 max-pool -----------------------------------------------------------------------------
 template <bool BWD>
 __global__ void __launch_bounds__(NT) maxpool2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -844,6 +855,14 @@ int pnp_dropout(const float* x, float* y, size_t n, float keep_prob, uint64_t se
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, (hipStream_t)stream, x, y, n,
                        pnp_drop_key(seed, stream_id), thresh, scale);
     PNP_CHECK_LAUNCH("pnp_dropout");
+    return PNP_OK;
+}
+
+int pnp_add(const float* x, const float* y, float* out, size_t n, void* stream) {
+    PNP_REQUIRE(x && y && out, "pnp_add: null pointer");
+    if (n == 0) return PNP_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, (hipStream_t)stream, x, y, out, n);
+    PNP_CHECK_LAUNCH("pnp_add");
     return PNP_OK;
 }
 

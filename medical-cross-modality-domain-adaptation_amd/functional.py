@@ -355,6 +355,29 @@ class CriticInputFn(Function):
         return da, db, dc, dd, dl, None
 
 
+class FanOutFn(Function):
+    """One tensor consumed by TWO branches of the graph (adversarial.py:91-119: conv4_2 / conv6_2 / block7_2 / conv9_2 / the logits feed
+    the segmenter's next layer AND a critic).  TF's autodiff sums the two gradients with AddN; left to torch's engine that sum is an
+    `aten::add` launch — here it is pnp_add, so that every arithmetic result of a step comes from libpnp_hip.so."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g2 if g1 is None else g1
+        return K.add(_contig(g1), _contig(g2))
+
+
+def fan_out(x):
+    """(x, x) as two autograd edges whose gradients are summed by pnp_add; plain (x, x) where no tape is recorded / on meta tensors"""
+    if x.is_meta or not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    return FanOutFn.apply(x)
+
+
 class WganLossFn(Function):
     """scalar = sum_i coef_i * mean(critic_logits_i)  (adversarial.py:455-459).  Must be the ROOT of backward: the upstream
     gradient is `gscale` (1/world_size under data parallelism); each input receives the constant coef_i * gscale / B."""

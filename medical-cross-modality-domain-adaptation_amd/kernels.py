@@ -457,6 +457,18 @@ def axpby(x, y, a, b):
     return y
 
 
+def add(x, y):
+    """x + y into a new tensor (pnp_add)"""
+    out = torch.empty_like(x)
+    check(_lib.load().pnp_add(_p(x), _p(y), _p(out), x.numel(), _stream()), "pnp_add")
+    return out
+
+
+def fill_(t, value):
+    check(_lib.load().pnp_fill(_p(t), t.numel(), float(value), _stream()), "pnp_fill")
+    return t
+
+
 def critic_input_fwd(a, tile_a, b, c, d, logits):
     lib = _lib.load()
     P = logits.numel() // logits.shape[-1]

@@ -257,7 +257,7 @@ class Full_DRN(object):
         self.store.zero_grad()
         logits = self.forward(x, keep_prob, main_bn, adapt_bn, drop_seed)
         lv = self._get_cost(logits, y)
-        lv[0].backward()
+        lv.backward(self.store.unit_grad(3))      # SegLossFn: element 0 is the root (cost); the upstream gradient is taken to be 1
         self.cost, self.weighted_loss, self.dice_loss = lv[0].detach(), lv[1].detach(), lv[2].detach()
         return self.cost
 

@@ -220,8 +220,26 @@ class VariableStore(object):
         return done, missing
 
     def zero_grad(self):
-        self.grad_arena.zero_()
+        if self.grad_arena.is_cuda:
+            from . import kernels as K
+            K.fill_(self.grad_arena, 0.0)          # pnp_fill, like every other value of a step
+        else:
+            self.grad_arena.zero_()                # host-side stores (graph / naming / data-parallel logic tests)
         gradsink.rearm(v.tensor for v in self.trainable())
+
+    def unit_grad(self, n=1):
+        """the root gradient handed to backward(): ones, filled once by pnp_fill (torch's implicit root gradient is a fill launch per
+        backward pass; the loss Functions take the upstream gradient to be 1 and fold the data-parallel 1/W into their kernels)"""
+        cache = self.__dict__.setdefault("_unit_grads", {})
+        t = cache.get(n)
+        if t is None:
+            if self.device.type == "cuda":
+                from . import kernels as K
+                t = K.filled((n,), 1.0, self.device)
+            else:
+                t = torch.ones(n)
+            cache[n] = t
+        return t
 
     def state_dict(self):
         return OrderedDict((k, v.tensor.detach().cpu().numpy().copy()) for k, v in self.vars.items())
