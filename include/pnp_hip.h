@@ -127,17 +127,6 @@ int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_
  * stride-1 MFMA kernels; other geometries add it with one more pass. */
 int pnp_conv2d_dgrad_add(const float* dy, const float* w, const float* residual, float* dx, const pnp_conv_geom* g,
                          void* workspace, size_t workspace_bytes, void* stream);
-/* Data gradient that ALSO leaves the two per-channel sums of the batch-norm backward of the unit in front of this convolution: when
- * dx (+ residual) is the upstream gradient of a conv -> dropout -> BN -> leaky-ReLU unit WITHOUT a shortcut whose output feeds only this
- * convolution (the head of layers.residual_block / DR_block, layers.py:145-189), sum(g) and sum(g * xhat), g = dx * act'(.), are
- * accumulated in the epilogue of the kernel that writes dx (per pixel-tile partials [nparts][2][C], combined by pnp_bn_bwd_finish) and
- * that unit's backward skips its reduction pass over three activation-sized tensors.  bn_x = the unit's BN input [N,H,W,C]; the
- * activation's sign is recomputed from it like pnp_bn_bwd does with out == NULL.  pnp_conv2d_dgrad_bnred_parts == 0: not available for
- * this geometry (strided / SYMMETRIC / 16-channel / reduction-split launches). */
-int32_t pnp_conv2d_dgrad_bnred_parts(const pnp_conv_geom* g);
-int pnp_conv2d_dgrad_bnred(const float* dy, const float* w, const float* residual /*nullable*/, float* dx, const pnp_conv_geom* g,
-                           void* workspace, size_t workspace_bytes, const float* bn_x, const float* mean, const float* var,
-                           const float* gamma, const float* beta, float eps, float alpha, float* parts, size_t parts_bytes, void* stream);
 
 /* gradient w.r.t. the filter (Conv2DBackpropFilter). dw [R,S,C,K] is overwritten. */
 size_t pnp_conv2d_wgrad_workspace_bytes(const pnp_conv_geom* g);
@@ -206,10 +195,6 @@ int pnp_bn_bwd_acc(const float* dout, const float* out /*nullable*/, const float
 int pnp_bn_bwd_reduce(const float* dout, const float* out /*nullable*/, const float* x, const float* mean, const float* var,
                       const float* gamma /*nullable unless out == NULL*/, const float* beta /*nullable unless out == NULL*/, float* dgamma, float* dbeta, int64_t P, int32_t C, float eps, float alpha,
                       void* workspace, size_t workspace_bytes, void* stream);
-/* The reduce half from partials that a data-gradient kernel left behind (pnp_conv2d_dgrad_bnred): combines them in double, fixed order;
- * dgamma_acc / dbeta_acc (both or neither) as in pnp_bn_bwd_acc.  The partial list is consumed. */
-int pnp_bn_bwd_finish(float* parts, int32_t nparts, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, int32_t C,
-                      void* stream);
 int pnp_bn_bwd_apply(const float* dout, const float* out /*nullable*/, const float* x, const float* mean, const float* var,
                      const float* gamma, const float* beta /*nullable unless out == NULL*/, const float* dgamma, const float* dbeta, float* dx, float* dshortcut, int32_t Cs,
                      int64_t P, int64_t P_norm, int32_t C, float eps, float alpha, int32_t training,

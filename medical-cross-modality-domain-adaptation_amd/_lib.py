@@ -61,8 +61,6 @@ PROTOTYPES = {
     "pnp_conv2d_dgrad_workspace_bytes": (c_size_t, [_G]),
     "pnp_conv2d_dgrad": (c_int, [_F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
     "pnp_conv2d_dgrad_add": (c_int, [_F, _F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
-    "pnp_conv2d_dgrad_bnred_parts": (c_int32, [_G]),
-    "pnp_conv2d_dgrad_bnred": (c_int, [_F, _F, _F, _F, _G, c_void_p, c_size_t, _F, _F, _F, _F, _F, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "pnp_conv2d_wgrad_workspace_bytes": (c_size_t, [_G]),
     "pnp_conv2d_wgrad": (c_int, [_F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
     "pnp_conv2d_wgrad_acc": (c_int, [_F, _F, _F, _G, c_void_p, c_size_t, c_void_p]),
@@ -84,7 +82,6 @@ PROTOTYPES = {
                            c_float, c_uint64, c_uint32, c_void_p, c_size_t, c_void_p]),
     "pnp_bn_bwd_acc": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int32, c_float, c_float, c_int32,
                                c_float, c_uint64, c_uint32, c_void_p, c_size_t, c_void_p]),
-    "pnp_bn_bwd_finish": (c_int, [c_void_p, c_int32, _F, _F, _F, _F, c_int32, c_void_p]),
     "pnp_bn_bwd_reduce": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, c_int64, c_int32, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "pnp_bn_bwd_apply": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, c_int32, c_int64, c_int64, c_int32, c_float, c_float, c_int32,
                                  c_float, c_uint64, c_uint32, c_void_p]),

@@ -46,18 +46,6 @@ struct ConvArgs {
     // (v - stat_shift[k]) and its square over the rows the wave owns, written to stat_ws[(part*2 + q)*K + k]; null: off
     float* stat_ws;
     const float* stat_shift;
-    // stat_mode 1 (data gradients): this kernel's output IS the upstream gradient dout of a conv -> BN -> leaky-ReLU unit without a
-    // shortcut (the head of a residual block: its output feeds this convolution only), so the two per-channel sums its BN backward needs,
-    // sum(g) and sum(g * xhat) with g = dout * act'(.), leave from here as per (pixel tile, wave row) partials — the unit's backward
-    // then skips its 3-read reduction pass.  br_x = the unit's BN input [M][K] (rows = this kernel's output rows); the activation's sign
-    // is recomputed from it exactly as bn_apply_kernel formed the value (fmaf(x - mean, gamma * rstd, beta) > 0).
-    int stat_mode;
-    const float* br_x;
-    const float* br_mean;
-    const float* br_var;
-    const float* br_gamma;
-    const float* br_beta;
-    float br_eps, br_alpha;
     // data gradient: dx = conv + res_add ([M][K] rows like the output; the gradient that reaches the same tensor through a residual
     // shortcut) — added by the workgroups of reduction split 0.  filter gradient: accumulate != 0 adds into dW instead of overwriting
     // (un-split launches; split launches accumulate in the reduce kernel)
@@ -181,21 +169,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, T
     const int l31 = lane & 31, h = lane >> 5;
     const bool scatter = a.o_s != 0 && a.nsplit == 1;                  // split partials stay row-major; the reduce kernel scatters them
     const bool stats = a.stat_ws != nullptr;
-    const bool bnred = stats && a.stat_mode == 1;
-    float ssum[TN], ssq[TN], shift[TN], b_rs[TN], b_gsc[TN], b_beta[TN];
+    float ssum[TN], ssq[TN], shift[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int n = n0 + wn0 + tn * 32 + l31;
         ssum[tn] = 0.f;
         ssq[tn] = 0.f;
         shift[tn] = (stats && a.stat_shift && n < a.K) ? a.stat_shift[n] : 0.f;
-        b_rs[tn] = b_gsc[tn] = b_beta[tn] = 0.f;
-        if (bnred && n < a.K) {
-            shift[tn] = a.br_mean[n];
-            b_rs[tn] = 1.0f / sqrtf(a.br_var[n] + a.br_eps);
-            b_gsc[tn] = a.br_gamma[n] * b_rs[tn];
-            b_beta[tn] = a.br_beta[n];
-        }
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -210,12 +190,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, T
                     const size_t idx = (size_t)m * a.K + n;
                     if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
                     if (res) v += res[idx];
-                    if (bnred) {
-                        const float xm = a.br_x[idx] - shift[tn];
-                        const float g = (a.br_alpha >= 0.f && !(fmaf(xm, b_gsc[tn], b_beta[tn]) > 0.f)) ? v * a.br_alpha : v;
-                        ssum[tn] += g;
-                        ssq[tn] = fmaf(g, xm * b_rs[tn], ssq[tn]);
-                    } else if (stats) {
+                    if (stats) {
                         const float d = v - shift[tn];
                         ssum[tn] += d;
                         ssq[tn] = fmaf(d, d, ssq[tn]);

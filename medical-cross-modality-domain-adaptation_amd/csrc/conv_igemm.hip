@@ -2323,56 +2323,8 @@ size_t pnp_conv2d_dgrad_workspace_bytes(const pnp_conv_geom* g) {
     return b;
 }
 
-// BN-backward sums of the unit whose output this data gradient is the upstream gradient of (ConvArgs::stat_mode 1)
-struct BnRed {
-    const float *x, *mean, *var, *gamma, *beta;
-    float eps, alpha;
-    float* parts;
-};
 static int dgrad_impl(const float* dy, const float* w, float* dx, const pnp_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream,
-                      const float* residual, const BnRed* bnred = nullptr);
-
-// geometry of the stride-1 data gradient as a convolution over dy
-static pnp_conv_geom dgrad_as_conv(const pnp_conv_geom* g) {
-    pnp_conv_geom d{};
-    d.N = g->N; d.H = g->OH; d.W = g->OW; d.C = g->K; d.K = g->C; d.R = g->R; d.S = g->S;
-    d.OH = g->H; d.OW = g->W;
-    d.stride = 1; d.dil = g->dil;
-    d.pad_t = g->dil * (g->R - 1) - g->pad_t;
-    d.pad_l = g->dil * (g->S - 1) - g->pad_l;
-    d.pad_mode = PNP_PAD_ZERO;
-    d.dtype = g->dtype;
-    return d;
-}
-
-// Partials the data gradient of `g` can leave for the BN backward of the unit in front of it (0: not on this geometry — strided /
-// SYMMETRIC convolutions, the 16-channel and narrow vector-ALU kernels, reduction-split launches: the caller runs pnp_bn_bwd instead)
-int32_t pnp_conv2d_dgrad_bnred_parts(const pnp_conv_geom* g) {
-    static const int off = getenv("PNP_CONV_NOBNRED") ? 1 : 0;
-    if (off || !g || check_geom(g, "pnp_conv2d_dgrad_bnred_parts") != PNP_OK) return 0;
-    if (g->stride != 1 || g->pad_mode != PNP_PAD_ZERO || g->dtype != PNP_DTYPE_F32) return 0;
-    const pnp_conv_geom d = dgrad_as_conv(g);
-    if (d.pad_t < 0 || d.pad_l < 0 || n16_geom_ok(&d) || narrow_fwd_ok(&d, nullptr)) return 0;
-    const long long M = (long long)d.N * d.OH * d.OW;
-    const int tile = choose_tile(M, d.K);
-    if (tile == 3 || choose_split(M, d.K, d.R * d.S * d.C, tile) > 1) return 0;
-    return pnp_cdiv(M, 128) * ((tile == 0 || tile == 1) ? 2 : 4);        // pixel tiles x wave rows of the tile (WM)
-}
-
-int pnp_conv2d_dgrad_bnred(const float* dy, const float* w, const float* residual, float* dx, const pnp_conv_geom* g, void* workspace,
-                           size_t workspace_bytes, const float* bn_x, const float* mean, const float* var, const float* gamma,
-                           const float* beta, float eps, float alpha, float* parts, size_t parts_bytes, void* stream) {
-    PNP_REQUIRE(bn_x && mean && var && gamma && beta && parts, "pnp_conv2d_dgrad_bnred: null pointer");
-    PNP_REQUIRE(residual != dx, "pnp_conv2d_dgrad_bnred: residual must be a tensor of its own");
-    const int nparts = pnp_conv2d_dgrad_bnred_parts(g);
-    PNP_REQUIRE(nparts > 0, "pnp_conv2d_dgrad_bnred: no epilogue sums for this geometry (pnp_conv2d_dgrad_bnred_parts == 0)");
-    if (parts_bytes < (size_t)nparts * 2 * g->C * sizeof(float)) {
-        pnp_set_error("pnp_conv2d_dgrad_bnred: parts buffer too small (%zu < %zu)", parts_bytes, (size_t)nparts * 2 * g->C * sizeof(float));
-        return PNP_EWORKSPACE;
-    }
-    const BnRed br{bn_x, mean, var, gamma, beta, eps, alpha, parts};
-    return dgrad_impl(dy, w, dx, g, workspace, workspace_bytes, stream, residual, &br);
-}
+                      const float* residual);
 
 int pnp_conv2d_dgrad(const float* dy, const float* w, float* dx, const pnp_conv_geom* g, void* workspace,
                      size_t workspace_bytes, void* stream) {
@@ -2388,7 +2340,7 @@ int pnp_conv2d_dgrad_add(const float* dy, const float* w, const float* residual,
 // residual != null: dx = data gradient + residual.  Fused into the epilogue on the stride-1 MFMA paths (the residual blocks); every
 // other geometry computes the gradient and adds the residual with one more pass (pnp_axpby).
 static int dgrad_impl(const float* dy, const float* w, float* dx, const pnp_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream,
-                      const float* residual, const BnRed* bnred) {
+                      const float* residual) {
     if (int e = check_geom(g, "pnp_conv2d_dgrad")) return e;
     PNP_REQUIRE(dy && w && dx && workspace, "pnp_conv2d_dgrad: null pointer");
     PNP_REQUIRE(workspace_bytes >= pnp_conv2d_dgrad_workspace_bytes(g), "pnp_conv2d_dgrad: workspace too small");
@@ -2470,11 +2422,6 @@ static int dgrad_impl(const float* dy, const float* w, float* dx, const pnp_conv
     float* split_ws = (workspace_bytes > poff) ? (float*)((char*)workspace + poff) : nullptr;
     const bool fuse_res = residual && !sym && g->stride == 1;          // rows of the GEMM == pixels of dx, plain row-major output
     if (fuse_res) a.res_add = residual;
-    if (bnred) {           // (pnp_conv2d_dgrad_bnred_parts vouched for: stride 1, zero padding, MFMA tiles, un-split reduction)
-        a.stat_ws = bnred->parts; a.stat_mode = 1;
-        a.br_x = bnred->x; a.br_mean = bnred->mean; a.br_var = bnred->var; a.br_gamma = bnred->gamma; a.br_beta = bnred->beta;
-        a.br_eps = bnred->eps; a.br_alpha = bnred->alpha;
-    }
     if (int e = (g->stride > 1 ? launch_fwd<2>(a, st, split_ws) : launch_fwd<1>(a, st, split_ws))) return e;
     if (sym) {
         const size_t total = (size_t)g->N * g->H * g->W * g->C;

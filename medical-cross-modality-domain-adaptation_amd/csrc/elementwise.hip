@@ -794,14 +794,6 @@ int pnp_bn_bwd_reduce(const float* dout, const float* out, const float* x, const
     return run_colreduce<1>(ca, dbeta, dgamma, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_bwd_reduce");
 }
 
-int pnp_bn_bwd_finish(float* parts, int32_t nparts, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, int32_t C,
-                      void* stream) {
-    PNP_REQUIRE(parts && dgamma && dbeta && nparts > 0 && C > 0, "pnp_bn_bwd_finish: bad argument");
-    PNP_REQUIRE((dgamma_acc != nullptr) == (dbeta_acc != nullptr), "pnp_bn_bwd_finish: dgamma_acc and dbeta_acc go together");
-    return launch_colreduce_final<1>(parts, nullptr, dbeta, dgamma, nparts, C, 0, nullptr, nullptr, 0.f, (hipStream_t)stream,
-                                     "pnp_bn_bwd_finish", dbeta_acc, dgamma_acc);
-}
-
 int pnp_bn_bwd_apply(const float* dout, const float* out, const float* x, const float* mean, const float* var,
                      const float* gamma, const float* beta, const float* dgamma, const float* dbeta, float* dx, float* dshortcut, int32_t Cs,
                      int64_t P, int64_t P_norm, int32_t C, float eps, float alpha, int32_t training, float keep_prob,

@@ -77,25 +77,14 @@ def _contig(t):
 RES_LINK = os.environ.get("PNP_RES_LINK", "1") != "0"
 
 
-# the BN-backward sums of a block's head unit leave from the epilogue of the tail convolution's data-gradient kernel
-# (pnp_conv2d_dgrad_bnred) instead of a reduction pass over dout / BN input
-BN_BWD_FROM_DGRAD = os.environ.get("PNP_BN_BWD_FROM_DGRAD", "1") != "0"
-
-
 class ResLink(object):
-    """Ties the two conv-BN units of a residual / DR block (layers.residual_block, DR_block):
-      * both consume the SAME block input x: the tail unit (x = its shortcut) parks the shortcut gradient here, the head unit (x = its
-        conv input) adds it to its data gradient (pnp_conv2d_dgrad_add).  The tail's backward always runs before the head's (the head's
-        output feeds the tail);
-      * the head's output feeds ONLY the tail's convolution, so the tail's data-gradient kernel produces the head's complete upstream
-        gradient: its epilogue also accumulates the head's BN-backward sums (head_bn -> head_red), and the head's backward skips its
-        reduction pass."""
-    __slots__ = ("dsc", "head_bn", "head_red")
+    """Ties the two conv-BN units of a residual / DR block that consume the SAME block input x (layers.residual_block, DR_block):
+    the tail unit (x = its shortcut) parks the shortcut gradient here, the head unit (x = its conv input) adds it to its data
+    gradient.  The tail's backward always runs before the head's (the head's output feeds the tail)."""
+    __slots__ = ("dsc",)
 
     def __init__(self):
         self.dsc = None
-        self.head_bn = None      # forward of the head: (xc, mean, var, gamma, beta, alpha) when its BN backward can take epilogue sums
-        self.head_red = None     # backward of the tail: (parts, data_ptr of the dx they belong to)
 
     def take(self):
         d, self.dsc = self.dsc, None
@@ -131,23 +120,6 @@ def _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, keep, seed, sid, beta
     else:
         dxc, dgamma, dbeta, dsc = K.bn_bwd(dout, out, xc, mean, var, gamma, need_sc, BN_EPS, ctx.alpha, ctx.is_train, keep, seed, sid,
                                            into=slots, beta=beta)
-    if slots is not None:
-        gradsink.done(sinks[0])
-        gradsink.done(sinks[1])
-        return dxc, None, None, dsc
-    return dxc, dgamma, dbeta, dsc
-
-
-def _bn_bwd_from_parts(ctx, parts, dout, xc, mean, var, gamma, beta):
-    """BN backward of a head unit whose sums were accumulated by the tail convolution's data-gradient kernel: finish + apply"""
-    sinks = getattr(ctx, "bn_sinks", None)
-    slots = (sinks[0].grad(), sinks[1].grad()) if sinks is not None else None
-    if slots is not None and (slots[0] is None or slots[1] is None):
-        slots = None
-    dgamma, dbeta = K.bn_bwd_finish(parts, xc.shape[-1], into=slots)
-    sums = (dgamma, dbeta)
-    dxc, dsc = K.bn_bwd_apply(dout, None, xc, mean, var, gamma, sums, ctx.P_norm, 0, BN_EPS, ctx.alpha, True, ctx.keep, ctx.seed, ctx.sid,
-                              beta=beta)
     if slots is not None:
         gradsink.done(sinks[0])
         gradsink.done(sinks[1])
@@ -237,11 +209,6 @@ class ConvBNActFn(Function):
         # no shortcut: the backward kernels recompute the activation's sign from xc, gamma, beta — `out` is not kept for this unit
         ctx.resign = BN_RECOMPUTE_SIGN and sc is None and alpha >= 0.0
         ctx.save_for_backward(x, w_, xc, beta if ctx.resign else out, mean, var, gamma)
-        if ctx.link is not None and sc is None:
-            # head of a block in training mode, per-replica statistics: offer the tail's data gradient the BN-backward reduction
-            ctx.link.head_bn = (xc, mean, var, gamma, beta, alpha) if (BN_BWD_FROM_DGRAD and ctx.resign and is_train and taped
-                                                                         and ctx.P_norm == P) else None
-            ctx.link.head_red = None
         return out
 
     @staticmethod
@@ -258,13 +225,7 @@ class ConvBNActFn(Function):
                                       ctx.seed, ctx.sid)
             dgamma = dbeta = None
         else:
-            red = ctx.link.head_red if (ctx.link is not None and not ctx.sc_channels) else None
-            if red is not None and red[1] == dout.data_ptr() and tuple(dout.shape) == tuple(xc.shape):
-                # head of a block: the sums came out of the tail convolution's data-gradient epilogue
-                ctx.link.head_red = None
-                dxc, dgamma, dbeta, dsc = _bn_bwd_from_parts(ctx, red[0], dout, xc, mean, var, gamma, beta)
-            else:
-                dxc, dgamma, dbeta, dsc = _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, ctx.keep, ctx.seed, ctx.sid, beta)
+            dxc, dgamma, dbeta, dsc = _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, ctx.keep, ctx.seed, ctx.sid, beta)
         res = None
         if ctx.link is not None:
             if ctx.sc_channels:             # tail of a block: the head's data-gradient kernel adds the shortcut gradient
@@ -272,15 +233,7 @@ class ConvBNActFn(Function):
             else:                           # head of a block
                 res = ctx.link.take()
         if ctx.needs_input_grad[0]:
-            hb = ctx.link.head_bn if (ctx.link is not None and ctx.sc_channels) else None
-            if hb is not None and K.conv_dgrad_bnred_parts(ctx.geom) > 0 and tuple(hb[0].shape) == tuple(x.shape):
-                # tail of a block: x is the head's output and feeds this convolution only -> dx is the head's whole upstream gradient
-                dx, parts = K.conv2d_dgrad_bnred(dxc, w, ctx.geom, hb[0], hb[1], hb[2], hb[3], hb[4], BN_EPS, hb[5], residual=res)
-                ctx.link.head_red = (parts, dx.data_ptr())
-            else:
-                dx = K.conv2d_dgrad(dxc, w, ctx.geom, residual=res)
-            if ctx.link is not None and ctx.sc_channels:
-                ctx.link.head_bn = None
+            dx = K.conv2d_dgrad(dxc, w, ctx.geom, residual=res)
         else:
             dx = None
         dw = _wgrad(ctx, x, dxc, ctx.w_sink) if ctx.needs_input_grad[1] else None

@@ -157,39 +157,6 @@ def conv2d_dgrad(dy, w, g, residual=None):
     return dx
 
 
-def conv_dgrad_bnred_parts(g):
-    """partial rows the data gradient of `g` can leave for the BN backward of the unit in front of it (0: not available)"""
-    return int(_lib.load().pnp_conv2d_dgrad_bnred_parts(ctypes.byref(g)))
-
-
-def conv2d_dgrad_bnred(dy, w, g, bn_x, mean, var, gamma, beta, eps, alpha, residual=None):
-    """conv2d_dgrad whose epilogue also accumulates sum(g), sum(g * xhat) of the BN backward of the unit that produced this convolution's
-    input (pnp_conv2d_dgrad_bnred) -> (dx, (parts, nparts)); the partials get a buffer of their own (the consumer's backward may run
-    after other convolutions)"""
-    lib = _lib.load()
-    dx = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dy.device)
-    nparts = conv_dgrad_bnred_parts(g)
-    ws = workspace(lib.pnp_conv2d_dgrad_workspace_bytes(ctypes.byref(g)), dy.device)
-    parts = torch.empty(nparts * 2 * g.C * 4, dtype=torch.uint8, device=dy.device)
-    if tuple(bn_x.shape) != tuple(dx.shape):
-        raise ValueError("conv2d_dgrad_bnred: BN input %s does not match dx %s" % (tuple(bn_x.shape), tuple(dx.shape)))
-    check(lib.pnp_conv2d_dgrad_bnred(_p(dy), _p(w), _p(residual), _p(dx), ctypes.byref(g), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
-                                     _p(bn_x), _p(mean), _p(var), _p(gamma), _p(beta), float(eps), float(alpha),
-                                     ctypes.c_void_p(parts.data_ptr()), parts.numel(), _stream()), "pnp_conv2d_dgrad_bnred")
-    return dx, (parts, nparts)
-
-
-def bn_bwd_finish(parts_n, C, into=None):
-    """(dgamma, dbeta) from the partials of conv2d_dgrad_bnred; `into` = (dgamma_slot, dbeta_slot) as in bn_bwd"""
-    parts, nparts = parts_n
-    dgamma = torch.empty(C, dtype=torch.float32, device=parts.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=parts.device)
-    acc = (into[0], into[1]) if into is not None else (None, None)
-    check(_lib.load().pnp_bn_bwd_finish(ctypes.c_void_p(parts.data_ptr()), int(nparts), _p(dgamma), _p(dbeta), _p(acc[0]), _p(acc[1]), int(C),
-                                        _stream()), "pnp_bn_bwd_finish")
-    return dgamma, dbeta
-
-
 def conv2d_wgrad(x, dy, g, into=None):
     """filter gradient; `into` ([R,S,C,K], e.g. the variable's slot of the gradient arena): dw is ADDED to it (pnp_conv2d_wgrad_acc)
     and `into` is returned"""

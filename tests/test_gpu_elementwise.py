@@ -264,89 +264,3 @@ def test_no_epilogue_statistics_where_the_forward_is_not_on_the_mfma_tiles(dev):
     assert K.conv_stats_parts(K.conv_geom((16, 256, 256, 16), (3, 3, 16, 16), 1, 1, "SAME")) == 0       # narrow-output vector-ALU kernel
     assert K.conv_stats_parts(K.conv_geom((16, 16, 16, 512), (5, 5, 512, 512), 4, 1, "SAME")) == 0      # reduction-split tiny layer
     assert K.conv_stats_parts(K.conv_geom((2, 64, 64, 64), (3, 3, 64, 64), 1, 1, "SAME")) == 0          # few tiles at a small batch: split too
-
-
-@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, 1), (2, 32, 32, 512, 512, 2), (3, 64, 64, 64, 128, 1), (2, 19, 23, 96, 72, 1)],
-                         ids=lambda c: "x".join(str(v) for v in c))
-def test_bn_backward_sums_from_the_data_gradient_epilogue(dev, case):
-    """pnp_conv2d_dgrad_bnred: the data gradient of the convolution BEHIND a conv -> BN -> leaky-ReLU unit leaves that unit's two
-    BN-backward sums from its epilogue.  dx must be the plain data gradient bit for bit; the sums must equal the reduction pass of
-    pnp_bn_bwd over the same tensors (float64 sums as the referee); with a residual the sums are those of dx + residual."""
-    K = pkg("kernels")
-    N, H, W, C, Kf, dil = case                  # the convolution behind the unit: C (= the unit's channels) -> Kf
-    rng = np.random.default_rng(sum(case))
-    w = torch.from_numpy((rng.standard_normal((3, 3, C, Kf)) * np.sqrt(2.0 / (9 * C))).astype(np.float32)).to(dev)
-    dy = torch.from_numpy(rng.standard_normal((N, H, W, Kf)).astype(np.float32)).to(dev)
-    xc = torch.from_numpy((rng.standard_normal((N, H, W, C)) * 1.3 + 0.2).astype(np.float32)).to(dev)      # the unit's BN input
-    gamma = torch.from_numpy((1 + 0.1 * rng.standard_normal(C)).astype(np.float32)).to(dev)
-    beta = torch.from_numpy((0.1 * rng.standard_normal(C)).astype(np.float32)).to(dev)
-    res = torch.from_numpy(rng.standard_normal((N, H, W, C)).astype(np.float32)).to(dev)
-    g = K.conv_geom((N, H, W, C), (3, 3, C, Kf), 1, dil, "SAME")
-    mean, var = K.bn_stats(xc)
-    assert K.conv_dgrad_bnred_parts(g) > 0
-    for residual in (None, res):
-        dx0 = K.conv2d_dgrad(dy, w, g, residual=residual)
-        dx1, parts = K.conv2d_dgrad_bnred(dy, w, g, xc, mean, var, gamma, beta, 1e-3, 0.2, residual=residual)
-        assert torch.equal(dx0, dx1)
-        slot_g, slot_b = torch.full((C,), 3.0, device=dev), torch.full((C,), -2.0, device=dev)
-        dgamma, dbeta = K.bn_bwd_finish(parts, C, into=(slot_g, slot_b))
-        _, dg_ref, db_ref, _ = K.bn_bwd(dx0, None, xc, mean, var, gamma, 0, 1e-3, 0.2, True, 1.0, 0, 0, beta=beta)
-        # float64 referee
-        x64, m64, v64 = xc.double().reshape(-1, C), mean.double(), var.double()
-        rs = 1.0 / torch.sqrt(v64 + 1e-3)
-        pre = torch.addcmul(beta.double(), x64 - m64, gamma.double() * rs)
-        out32 = K.bn_apply(xc, mean, var, gamma, beta, None, 1e-3, 0.2).reshape(-1, C)            # the sign the kernels see is the float32 one
-        g64 = torch.where(out32 > 0, dx0.double().reshape(-1, C), 0.2 * dx0.double().reshape(-1, C))
-        db64, dg64 = g64.sum(0), (g64 * (x64 - m64) * rs).sum(0)
-        e = {"dgamma": _rel(dgamma, dg64), "dbeta": _rel(dbeta, db64), "dgamma_pass": _rel(dg_ref, dg64), "dbeta_pass": _rel(db_ref, db64)}
-        print("bnred %s residual=%s: %s" % (case, residual is not None, {k_: "%.2e" % v_ for k_, v_ in e.items()}))
-        assert e["dgamma"] < 2e-6 and e["dbeta"] < 2e-6, e
-        assert _rel(slot_g, 3.0 + dgamma) < 1e-6 and _rel(slot_b, -2.0 + dbeta) < 1e-6
-        del pre
-
-
-def test_no_bn_backward_sums_where_the_data_gradient_is_not_on_the_mfma_tiles(dev):
-    K = pkg("kernels")
-    for shape, wshape, stride, pad in (((16, 256, 256, 16), (3, 3, 16, 16), 1, "SAME"),        # 16 input channels: conv_small.hip
-                                       ((4, 64, 64, 64), (3, 3, 64, 64), 2, "SAME"),           # strided: stride phases
-                                       ((2, 32, 32, 512), (3, 3, 512, 2560), 1, "SYMMETRIC"),  # in-kernel mirror padding
-                                       ((16, 34, 34, 512), (3, 3, 512, 2560), 1, "VALID")):    # g10: reduction-split data gradient
-        g = K.conv_geom(shape, wshape, stride, 1, pad)
-        assert K.conv_dgrad_bnred_parts(g) == 0, (shape, wshape)
-
-
-def test_residual_block_backward_with_and_without_the_epilogue_sums(dev):
-    """functional.ResLink: the head unit's BN backward fed by the tail convolution's data-gradient epilogue == the separate reduction pass
-    (summation order differs: 1e-6), through the real autograd units, gradient sinks and shortcut link included"""
-    F, L, V = pkg("functional"), pkg("layers"), pkg("variables")
-    rng = np.random.default_rng(3)
-    x_np = rng.standard_normal((4, 32, 32, 128)).astype(np.float32)
-    dout_np = rng.standard_normal((4, 32, 32, 256)).astype(np.float32)
-    grads = {}
-    for fused in (True, False):
-        F.BN_BWD_FROM_DGRAD = fused
-        try:
-            st = V.VariableStore(dev, seed=5)
-            x = torch.from_numpy(x_np).to(dev).requires_grad_(True)
-            with st.as_default():
-                st.begin_trace(7)
-                w1 = L.weight_variable([3, 3, 128, 256], stddev=0.03)
-                w2 = L.weight_variable([3, 3, 256, 256], stddev=0.03)
-                L.residual_block(torch.empty((4, 32, 32, 128), device="meta"), w1, w2, 0.75, inc_dim=True, is_train=True, scope="blk",
-                                 leak=True)                 # symbolic build pass: creates the BN variables
-                st.finalize()
-                st.begin_trace(7)
-                w1 = L.weight_variable([3, 3, 128, 256], stddev=0.03)          # same names -> the finalized variables
-                w2 = L.weight_variable([3, 3, 256, 256], stddev=0.03)
-                st.zero_grad()
-                out = L.residual_block(x, w1, w2, 0.75, inc_dim=True, is_train=True, scope="blk", leak=True)
-            out.backward(torch.from_numpy(dout_np).to(dev))
-            grads[fused] = {"x": x.grad.clone(), "arena": st.grad_arena.clone(), "out": out.detach().clone()}
-        finally:
-            F.BN_BWD_FROM_DGRAD = True
-    assert torch.equal(grads[True]["out"], grads[False]["out"])
-    for k_ in ("x", "arena"):
-        e = _rel(grads[True][k_], grads[False][k_])
-        print("residual block, epilogue sums vs reduction pass: %s %.2e" % (k_, e))
-        assert 0 <= e < 5e-6
-    assert float(grads[True]["arena"].abs().max()) > 0
