@@ -94,7 +94,8 @@ class ResLink(object):
 def _wgrad(ctx, x, dy, sink):
     """filter gradient of a conv call site: into the variable's arena slot when it has one (returns None to the engine)"""
     if sink is not None and sink.grad() is not None:
-        K.conv2d_wgrad(x, dy, ctx.geom, into=sink.grad())
+        g = ctx.geom
+        K.conv2d_wgrad(x, dy, g, into=sink.grad().view(g.R, g.S, g.C, g.K))
         gradsink.done(sink)
         return None
     return K.conv2d_wgrad(x, dy, ctx.geom)

@@ -68,7 +68,9 @@ def lookup(t):
     if s is None:
         return None
     p = s.param()
-    if p is None or p.grad is None or p.data_ptr() != t.data_ptr() or tuple(p.shape) != tuple(t.shape):
+    # (same address and element count = the same variable, possibly viewed with another shape: the critics' [D, 1] matmul weights run as
+    # 1x1 convolutions [1, 1, D, 1])
+    if p is None or p.grad is None or p.data_ptr() != t.data_ptr() or p.numel() != t.numel():
         if p is None:
             _SINKS.pop(t.data_ptr(), None)          # the store that owned this address is gone
         return None
