@@ -1054,7 +1054,10 @@ __global__ void __launch_bounds__(NTHREADS, (BN <= 64 ? PNP_WGRAD_NARROW_WAVES :
     // OUTPUT walk are the compares ih >= ih_lim / iw >= iw_lim
     const int l_dh = r_u * a.dil - a.pad_t, l_dw = s_u * a.dil - a.pad_l;
     const int iw_lim = a.OW * a.stride + l_dw, ih_lim = a.OH * a.stride + l_dh;
-    const int step_w = BK * a.stride, step_off = BK * a.stride * a.C * 4;
+    // one stage = BK consecutive output pixels = adv_h whole rows + adv_w pixels (rows of >= BK pixels: 0 rows + BK pixels; the 16^2 / 8^2
+    // maps of the critics' last blocks: 2 / 4 rows + 0 pixels); at most one row wrap and one image wrap per step either way (host-checked)
+    const int adv_h = BK / a.OW, adv_w = BK - adv_h * a.OW;
+    const int step_w = adv_w * a.stride, step_h = adv_h * a.stride, step_off = (step_h * a.W + step_w) * a.C * 4;
     const int wrap_w = a.OW * a.stride, wrap_w_off = a.stride * (a.W - a.OW) * a.C * 4;
     const int wrap_h = a.OH * a.stride, wrap_h_off = (a.H - a.OH * a.stride) * a.W * a.C * 4;
     int l_iw[ANP], l_ih[ANP], l_off[ANP];
@@ -1116,6 +1119,7 @@ __global__ void __launch_bounds__(NTHREADS, (BN <= 64 ? PNP_WGRAD_NARROW_WAVES :
                     const bool ok = ((unsigned)u_ih[i][h] < (unsigned)a.H) & ((unsigned)u_iw[i][h] < (unsigned)a.W);
                     so[h] = ok ? (unsigned)u_off[i][h] : OOB2;          // + lane_c (< 2 KiB) stays out of range: x < 2 GiB on this path
                     u_iw[i][h] += step_w;
+                    u_ih[i][h] += step_h;
                     u_off[i][h] += step_off;
                     const bool ww = u_iw[i][h] >= u_iw_lim;
                     u_iw[i][h] -= ww ? wrap_w : 0;
@@ -1135,8 +1139,9 @@ __global__ void __launch_bounds__(NTHREADS, (BN <= 64 ? PNP_WGRAD_NARROW_WAVES :
             const bool ok = mok & ((unsigned)l_ih[i] < (unsigned)a.H) & ((unsigned)l_iw[i] < (unsigned)a.W);
             st.a[i] = bload4(rx, ok ? (unsigned)l_off[i] : OOB);
             l_iw[i] += step_w;
+            l_ih[i] += step_h;
             l_off[i] += step_off;
-            const bool ww = l_iw[i] >= iw_lim;                  // at most one wrap per step because OW >= 32
+            const bool ww = l_iw[i] >= iw_lim;                  // at most one wrap per step (adv_w < OW)
             l_iw[i] -= ww ? wrap_w : 0;
             l_ih[i] += ww ? a.stride : 0;
             l_off[i] += ww ? wrap_w_off : 0;
@@ -1936,9 +1941,12 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     if (nsplit > 1) a.accumulate = 0;
     dim3 grid((unsigned)(nblk * nsplit));
     static const int env_nolin = getenv("PNP_CONV_NOLIN") ? 1 : 0;
-    const bool lin_any = !env_nolin && a.pad_mode == PNP_PAD_ZERO && (a.C % 4) == 0 && a.OW >= BK && a.x_bytes < 0x80000000u &&
-                         a.w_bytes < 0x80000000u;                  // conv_wgrad_ring_kernel walks strided outputs too
-    const bool lin = lin_any && a.stride == 1;
+    // conv_wgrad_ring_kernel walks strided outputs too, and maps whose rows are shorter than a stage when a stage is a whole number of
+    // rows inside one image (16^2, 8^2: the critics' last blocks ran on conv_wgrad_kernel's per-row divisions at 0.49 of peak before)
+    const bool rows_ok = a.OW >= BK || ((BK % a.OW) == 0 && a.OH > BK / a.OW && (a.OHW % BK) == 0);
+    const bool lin_any = !env_nolin && a.pad_mode == PNP_PAD_ZERO && (a.C % 4) == 0 && rows_ok && a.x_bytes < 0x80000000u &&
+                         a.w_bytes < 0x80000000u;
+    const bool lin = lin_any && a.stride == 1 && a.OW >= BK;
     if (lin && VECB && a.dtype == PNP_DTYPE_BF16) {
         const bool launched = launch_wgrad_bf16(a, BN == 128 ? 0 : (BN == 64 ? 1 : 2), grid, st);
         PNP_REQUIRE(launched, "conv_wgrad_bf16_kernel: no instance for a %dx%d tile", BM, BN);

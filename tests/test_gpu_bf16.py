@@ -164,3 +164,59 @@ def test_segmenter_bf16_forward_within_budget_and_trains(dev):
     # the bf16 run tracks the fp32 run step by step (same data, same dropout masks, same Adam): within 2 % after four updates
     assert all(np.isfinite(v) for v in losses16)
     assert all(abs(a_ - b_) < 0.02 * abs(b_) + 1e-3 for a_, b_ in zip(losses16, losses32)), (losses16, losses32)
+
+
+def test_joint_step_bf16_within_budget(dev):
+    """BASELINE configs[4] is the JOINT segmenter+GAN step in bf16: one discriminator step and one generator step of the adaptation graph
+    with bf16 MFMA operands against the same steps in float32 (same state, same dropout masks).  Operand rounding moves a 50-layer
+    graph's outputs by ~1e-2 relative (tests/test_bf16_budget.py measures the segmenter's share on the CPU); gradients keep their
+    direction.  Also checked: the bf16 kernels really ran (observed through pnp_prof_*), master weights stay float32."""
+    adv, F, L = pkg("adversarial"), pkg("functional"), pkg("_lib")
+    from test_gpu_adversarial import COST as GCOST, NETCFG, he_state
+    B = 2
+    rng = np.random.default_rng(0)
+    mr = torch.from_numpy(rng.standard_normal((B, 256, 256, 3)).astype(np.float32)).to(dev)
+    ct = torch.from_numpy((rng.standard_normal((B, 256, 256, 3)) * 1.2 + 0.1).astype(np.float32)).to(dev)
+    net0 = adv.Full_DRN(channels=3, n_class=5, batch_size=B, cost_kwargs=dict(GCOST), network_config=dict(NETCFG), device=dev, seed=1)
+    sd = he_state(net0, 7)
+    del net0
+
+    def run(dtype):
+        F.set_conv_dtype(dtype)
+        try:
+            net = adv.Full_DRN(channels=3, n_class=5, batch_size=B, cost_kwargs=dict(GCOST), network_config=dict(NETCFG), device=dev, seed=1)
+            net.store.load_state_dict(sd)
+            L.prof_summary()
+            L.prof_enable(L.PROF_CONV_FWD | L.PROF_CONV_DGRAD | L.PROF_CONV_WGRAD)
+            dl = float(net.dis_loss_and_grads(mr, ct, 0.75, drop_seed=11))
+            g_dis = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if "cls" in v.name}
+            lg = net.ct_logits.cpu().clone()
+            net.store.load_state_dict(sd)
+            gl = float(net.gen_loss_and_grads(ct, 0.75, drop_seed=12))
+            g_gen = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if v.name.startswith("adapt_")}
+            torch.cuda.synchronize()
+            L.prof_enable(0)
+            names = [r_["name"] for r_ in L.prof_summary() for _ in range(r_["launches"])]
+            assert net.store.arena.dtype == torch.float32
+            return dl, gl, lg, g_dis, g_gen, names
+        finally:
+            L.prof_enable(0)
+            F.set_conv_dtype("f32")
+    d16, g16, lg16, gd16, gg16, names16 = run("bf16")
+    d32, g32, lg32, gd32, gg32, names32 = run("f32")
+    share = sum("bf16" in n for n in names16) / float(len(names16))
+    assert not any("bf16" in n for n in names32) and share > 0.5, share
+
+    def cos(a, b):
+        a, b = a.double().reshape(-1), b.double().reshape(-1)
+        return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+    c_dis = np.array([cos(gd16[k], gd32[k]) for k in gd32 if float(gd32[k].abs().max()) > 0])
+    c_gen = np.array([cos(gg16[k], gg32[k]) for k in gg32 if float(gg32[k].abs().max()) > 0])
+    e_lg = _rel(lg16, lg32)
+    print("joint step bf16 vs fp32 (B=2): dis loss %.6e vs %.6e, gen loss %.6e vs %.6e, CT logits %.3e; gradient cosine dis median %.5f "
+          "min %.5f, gen median %.5f min %.5f; %.0f %% of %d conv launches on bf16 kernels" % (
+              d16, d32, g16, g32, e_lg, np.median(c_dis), c_dis.min(), np.median(c_gen), c_gen.min(), 100 * share, len(names16)))
+    assert np.isfinite([d16, g16]).all()
+    assert 1e-4 < e_lg < 0.1                                      # the segmenter's budget (tests/test_bf16_budget.py: 1.1e-2 typical)
+    assert abs(d16 - d32) < 0.1 * abs(d32) + 1e-6 and abs(g16 - g32) < 0.1 * abs(g32) + 1e-6
+    assert np.median(c_dis) > 0.99 and np.median(c_gen) > 0.98 and c_dis.min() > 0.8 and c_gen.min() > 0.8
