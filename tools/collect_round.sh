@@ -1,13 +1,18 @@
 # Regenerates everything under profiles/ for the current round on a GPU box:  bash tools/collect_round.sh   (raw output: gpurun_out/$R/)
 # Every step runs under its own `timeout`: in round 2 a `rocprofv3 --pmc` pass hung and ate the remaining 26 GPU-minutes of the round.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${R:-r2f}; O=gpurun_out/$R; mkdir -p $O
-if [ -z "$SKIP_TESTS" ]; then timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $O/tests.log 2>&1; tail -3 $O/tests.log; fi
+R=${R:-r3z}; O=gpurun_out/$R; mkdir -p $O
+P=$GRAFT_REPO_ROOT/medical-cross-modality-domain-adaptation_amd
+# -s: the parity tests PRINT their measured errors (the whole-step bars are set from these numbers: profiles/rNN_pytest_gpu.log)
+if [ -z "$SKIP_TESTS" ]; then timeout 1800 python -m pytest tests -m gpu -q -s --durations=15 > $O/tests.log 2>&1; tail -3 $O/tests.log; fi
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 # the driver's line (joint segmenter+GAN step, segmenter sub-record, joint cpu_baseline), the segmenter workload as its own line, bf16
-timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 400 $O/bench_n1.json
+timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 400 $O/bench_n1.json
 timeout 600 python bench.py --workload segmenter --no-sub > $O/bench_segmenter_n1.json 2>/dev/null
 timeout 600 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16_n1.json 2>/dev/null
+[ -z "$FAST" ] && timeout 600 python bench.py --dtype bf16 --batch 32 --no-cpu-baseline --no-sub > $O/bench_bf16_B32_n1.json 2>/dev/null
+# the CPU path at the GPU line's own batch, once (2 steps after 1 warm-up: ~3 min of host time; the default line bounds the sample with B=2)
+[ -z "$FAST" ] && timeout 900 python bench.py --steps 3 --warmup 1 --no-probe --no-sub --cpu-batch 16 --cpu-steps 2 --cpu-warmup 1 > $O/bench_cpu_B16.json 2>/dev/null
 # kernel traces (rocprofv3 --kernel-trace --stats), same command lines as the bench
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub"
 timeout 420 rocprofv3 --kernel-trace --stats -d $O/prof_joint -o joint -- $B > $O/bench_prof_joint.json 2>/dev/null
@@ -21,27 +26,43 @@ for w in joint seg bf16; do
   python tools/rocpd_summary.py $(find $O/prof_$w -name "*.db" | head -1) $O/${w}_kernel_stats.txt --last-ms $X > /dev/null 2>&1
 done
 head -12 $O/joint_kernel_stats.txt | cut -c1-170
-# PMC passes, each on its own (never together with other trace domains)
-P="python bench.py --steps 2 --warmup 1 --no-probe --no-cpu-baseline --no-sub"
-timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- $P > /dev/null 2>&1
-timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- $P > /dev/null 2>&1
-timeout 420 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -o s -- $P > /dev/null 2>&1
-python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_counters.json > /dev/null 2>$O/pmc_summary.err; tail -2 $O/pmc_summary.err
-# instruction mix of the filter-gradient kernel (segmenter workload): separate small passes, a pass with an unknown counter name just fails
-PS="python bench.py --workload segmenter --steps 2 --warmup 1 --no-probe --no-cpu-baseline --no-sub"
-timeout 420 rocprofv3 -L > $O/counters_available.txt 2>&1
-timeout 420 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_seg_sq -o s -- $PS > /dev/null 2>&1
-timeout 420 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_seg_insts -o i -- $PS > /dev/null 2>&1
-timeout 420 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $O/pmc_seg_insts2 -o j -- $PS > /dev/null 2>&1
-python tools/pmc_raw.py $O/pmc_seg_sq $O/pmc_seg_insts $O/pmc_seg_insts2 > $O/pmc_segmenter_raw.txt 2>&1; head -30 $O/pmc_segmenter_raw.txt
 # per-layer tables
 timeout 300 python tools/bench_conv.py > $O/conv_layers_f32.txt 2>/dev/null
 DTYPE=bf16 timeout 300 python tools/bench_conv.py > $O/conv_layers_bf16.txt 2>/dev/null
-# A/B: BN statistics from the conv epilogue vs the reduction pass
 if [ -z "$FAST" ]; then
-for i in 1 2; do for f in 1 0; do PNP_FUSE_BN_STATS=$f python bench.py --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FUSE_BN_STATS=$f', r['value'], r['ms_per_step'], r['segmenter_step']['value'])" >> $O/ab_bn_stats.txt; done; done; cat $O/ab_bn_stats.txt
 python tools/e2e_segmenter.py 2>&1 | grep "E2E" > $O/e2e.txt; cat $O/e2e.txt
+timeout 400 python tools/e2e_gan.py 2>&1 | grep "E2E" > $O/e2e_gan.txt; cat $O/e2e_gan.txt
+# host side of the library under AddressSanitizer (device code uninstrumented): the conv parity tests through libpnp_hip_asan.so
+if [ -f $P/libpnp_hip_asan.so ]; then
+  LD_PRELOAD=$(/opt/rocm/bin/hipcc -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 PNP_LIB=$P/libpnp_hip_asan.so \
+    timeout 600 python -m pytest tests/test_abi.py tests/test_gpu_conv.py -q > $O/asan_gpu.log 2>&1; tail -2 $O/asan_gpu.log
 fi
+fi
+# ---- PMC passes LAST, each on its own (never together with other trace domains), each under a short timeout; after the first pass that
+# times out the rest are skipped (round 2 lost 26 GPU-minutes to one hung pass)
+PMC_OK=1
+pmc() {   # pmc <outdir> <prefix> <counters...> -- <command...>
+  [ "$PMC_OK" = 1 ] || return 0
+  local d=$1 o=$2; shift 2; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  timeout -k 10 240 rocprofv3 --pmc "${ctr[@]}" --kernel-trace --output-format csv -d $d -o $o -- "$@" > /dev/null 2>&1
+  local rc=$?; if [ $rc -ge 124 ]; then echo "PMC pass $d timed out (rc $rc): skipping the remaining passes"; PMC_OK=0; fi
+}
+P1="python bench.py --steps 2 --warmup 1 --no-probe --no-cpu-baseline --no-sub"
+pmc $O/pmc_fetch f FETCH_SIZE -- $P1
+pmc $O/pmc_write w WRITE_SIZE -- $P1
+pmc $O/pmc_sq s GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES -- $P1
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_counters.json > /dev/null 2>$O/pmc_summary.err; tail -2 $O/pmc_summary.err
+# bf16 symbols (configs[4]): HBM traffic + matrix-pipe utilisation
+PB="$P1 --dtype bf16"
+pmc $O/pmc_bf16_fetch f FETCH_SIZE -- $PB
+pmc $O/pmc_bf16_write w WRITE_SIZE -- $PB
+pmc $O/pmc_bf16_sq s GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES -- $PB
+python tools/pmc_summary.py $O/pmc_bf16_fetch $O/pmc_bf16_write $O/pmc_bf16_sq $O/bf16_pmc_counters.json > /dev/null 2>>$O/pmc_summary.err
+# instruction mix (segmenter workload): a pass with an unknown counter name just fails
+PS="python bench.py --workload segmenter --steps 2 --warmup 1 --no-probe --no-cpu-baseline --no-sub"
+pmc $O/pmc_seg_sq s GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES -- $PS
+pmc $O/pmc_seg_insts i SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES -- $PS
+pmc $O/pmc_seg_insts2 j SQ_INST_CYCLES_VMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA -- $PS
+python tools/pmc_raw.py $O/pmc_seg_sq $O/pmc_seg_insts $O/pmc_seg_insts2 > $O/pmc_segmenter_raw.txt 2>&1; head -30 $O/pmc_segmenter_raw.txt
 rm -rf $O/prof_joint $O/prof_seg $O/prof_bf16     # the sqlite traces are large; the summaries stay
 ls $O
