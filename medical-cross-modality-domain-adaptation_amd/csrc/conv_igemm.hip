@@ -335,6 +335,32 @@ struct Frag {
                     acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[j][tn], acc.v[tm][tn], 0, 0, 0);
     }
 };
+// Split accumulation (narrow tiles): a wave with TM*TN <= 2 accumulator tiles rotates through only two dependent MFMA chains; with a
+// second accumulator set for the odd k of every 8-group it rotates through four, like the 2x2 tile (summed once in front of the epilogue).
+#ifndef PNP_SPLIT_ACC
+#define PNP_SPLIT_ACC 0
+#endif
+template <int TM, int TN, bool A_MMAJOR, int LDA, int LDB>
+__device__ __forceinline__ void frag_mma2(const Frag<TM, TN, A_MMAJOR, LDA, LDB>& f, Acc<TM, TN>& acc0, Acc<TM, TN>& acc1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                if (j & 1) acc1.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][j], f.b[j][tn], acc1.v[tm][tn], 0, 0, 0);
+                else acc0.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][j], f.b[j][tn], acc0.v[tm][tn], 0, 0, 0);
+            }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void acc_add(Acc<TM, TN>& a, const Acc<TM, TN>& b) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a.v[i][j][e] += b.v[i][j][e];
+}
 #define PNP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // Schedule of slices 1..3 of a stage (two Frag sets: the fragment reads of the NEXT slice and the MFMAs of THIS slice are independent).
 // PNP_CONV_ILV selects where the next stage's LDS stores go (compile-time; measured A/B/A/B on the 512-channel layers at B=16):
@@ -718,11 +744,6 @@ __global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS
 // s-1: every wave is past that stage's barrier), and requests stage s+3 from memory.  The ring index must be a compile-time constant, so
 // the channel-group loop is unrolled by two where the tap count is odd; the host only picks this kernel when the workgroup's channel
 // groups come in pairs then (C % 64 == 0 and an un-split or evenly split reduction: every layer of the model that runs narrow tiles).
-// PERSISTENT form: the grid may hold fewer workgroups than there are tiles (host: un-split launches with >= 1024 tiles run 512 workgroups,
-// two per CU).  A workgroup then walks tiles blockIdx.x, + gridDim.x, ... as ONE stream of stages: the global loads issued during the last
-// three stages of a tile already fetch the first three stages of the next one (its row offsets / tap masks were computed while this tile
-// ran), so a tile's prologue — row split, masks, first loads — never stands in front of its MFMAs, and its epilogue runs while the next
-// tile's loads are in flight.  (A 64-channel layer at 256^2 gives a tile only 18 stages: ~15 us of MFMAs between ~4 us of fixed cost.)
 template <int BM, int BN, int WM, int WN, int KIND, int R, int S>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
     constexpr int NTAP = R * S;
@@ -740,47 +761,40 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nblk = a.nblk_m * a.nblk_n;
-    const int total = nblk * a.nsplit;                 // work units: (reduction split, tile); more than one per workgroup only un-split
+    const int z = blockIdx.x / nblk;
+    int bid = blockIdx.x - z * nblk;
+    if (a.xcd_swizzle) bid = xcd_remap(bid, nblk);
+    int mt, nt;
+    tile_coords(bid, a.nblk_m, a.nblk_n, a.gn, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
-    const int kg = t & 7, mrow = t >> 3;
-    const int bcol = t % C4, brow = t / C4;
 
-    struct Tile {
-        int m0, n0, mt, z;
-        int abase[NR];
-        unsigned amask[NR];
-        unsigned boff[NPB];
-    };
-    auto setup = [&](int unit, Tile& T) {
-        T.z = unit / nblk;
-        int bid = unit - T.z * nblk;
-        if (a.xcd_swizzle) bid = xcd_remap(bid, nblk);
-        int nt;
-        tile_coords(bid, a.nblk_m, a.nblk_n, a.gn, T.mt, nt);
-        T.m0 = T.mt * BM;
-        T.n0 = nt * BN;
+    const int kg = t & 7, mrow = t >> 3;
+    int abase[NR];
+    unsigned amask[NR];
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            int m = T.m0 + mrow + 32 * i;
-            const bool ok = m < a.M;
-            if (!ok) m = 0;
-            int n, oh, ow;
-            split_row(a, m, n, oh, ow);
-            const int vh0 = oh * a.stride - a.pad_t, vw0 = ow * a.stride - a.pad_l;
-            T.abase[i] = (((n * a.H + vh0) * a.W + vw0) * a.C + 4 * kg) * 4;
-            unsigned mk = 0;
+    for (int i = 0; i < NR; ++i) {
+        int m = m0 + mrow + 32 * i;
+        const bool ok = m < a.M;
+        if (!ok) m = 0;
+        int n, oh, ow;
+        split_row(a, m, n, oh, ow);
+        const int vh0 = oh * a.stride - a.pad_t, vw0 = ow * a.stride - a.pad_l;
+        abase[i] = (((n * a.H + vh0) * a.W + vw0) * a.C + 4 * kg) * 4;
+        unsigned mk = 0;
 #pragma unroll
-            for (int tap = 0; tap < NTAP; ++tap) {
-                const int ih = vh0 + (tap / S) * a.dil, iw = vw0 + (tap % S) * a.dil;
-                const bool v = ok & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-                mk |= (v ? 1u : 0u) << tap;
-            }
-            T.amask[i] = mk;
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int ih = vh0 + (tap / S) * a.dil, iw = vw0 + (tap % S) * a.dil;
+            const bool v = ok & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            mk |= (v ? 1u : 0u) << tap;
         }
+        amask[i] = mk;
+    }
+    const int bcol = t % C4, brow = t / C4;
+    unsigned boff[NPB];
 #pragma unroll
-        for (int i = 0; i < NPB; ++i)
-            T.boff[i] = (T.n0 + 4 * bcol < a.K) ? (unsigned)(((brow + RPB * i) * a.K + T.n0 + 4 * bcol) * 4) : OOB2;
-    };
+    for (int i = 0; i < NPB; ++i)
+        boff[i] = (n0 + 4 * bcol < a.K) ? (unsigned)(((brow + RPB * i) * a.K + n0 + 4 * bcol) * 4) : OOB2;
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
@@ -789,21 +803,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
         f32x4 b[NPB];
     };
     Regs ring[2];
-    Tile cur, nxt;
-    // stage (cc, tap) of the current tile, or — `over` (uniform) — of the next one
-    auto gload = [&](Regs& r, int cc, int tap, bool over) {     // tap is a compile-time constant at every call site (unrolled)
+    auto gload = [&](Regs& r, int cc, int tap) {     // tap is a compile-time constant at every call site (unrolled)
         const int tshift = (((tap / S) * a.dil * a.W + (tap % S) * a.dil) * a.C) * 4;
         const int sa = cc * (BK * 4);
         const int sb = ((tap * a.C + cc * BK) * a.K) * 4;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const unsigned mk = over ? nxt.amask[i] : cur.amask[i];
-            const int ab = over ? nxt.abase[i] : cur.abase[i];
-            const unsigned vo = ((mk >> tap) & 1u) ? (unsigned)(ab + tshift) : OOB2;
+            const unsigned vo = ((amask[i] >> tap) & 1u) ? (unsigned)(abase[i] + tshift) : OOB2;
             r.a[i] = bload4s(rx, vo, sa);
         }
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) r.b[i] = bload4s(rw, over ? nxt.boff[i] : cur.boff[i], sb);
+        for (int i = 0; i < NPB; ++i) r.b[i] = bload4s(rw, boff[i], sb);
     };
     auto lstore = [&](const Regs& r, float* An, float* Bn) {
 #pragma unroll
@@ -812,29 +822,26 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
         for (int i = 0; i < NPB; ++i) *reinterpret_cast<f32x4*>(Bn + (brow + RPB * i) * LDB + 4 * bcol) = r.b[i];
     };
 
-    Acc<TM, TN> acc;
+    constexpr bool SPLIT = PNP_SPLIT_ACC != 0 && TM * TN <= 2;
+    Acc<TM, TN> acc, accb;
     acc.zero();
+    if constexpr (SPLIT) accb.zero();
+#define PNP_T3_MMA(F) do { if constexpr (SPLIT) frag_mma2(F, acc, accb); else F.mma(acc); } while (0)
 
-    int unit = blockIdx.x;
-    setup(unit, cur);
-    nxt = cur;
     const int ncc_total = a.C / BK;
-    const int ncc_w = a.chunks_per_split / NTAP;       // channel groups per work unit (all of them when un-split)
-    int cc_begin = cur.z * ncc_w;
-    int cc_end = cc_begin + ncc_w;
+    const int cc_begin = z * (a.chunks_per_split / NTAP);
+    int cc_end = cc_begin + a.chunks_per_split / NTAP;
     if (cc_end > ncc_total) cc_end = ncc_total;
-    // d stages after (cc, tap): inside this tile, or — past its end — in the next tile of this workgroup (same channel-group range:
-    // several tiles per workgroup exist only un-split); clamped so that very short reductions still fetch valid addresses
-#define PNP_T3_RAW(cc, tap, d) ((cc) + ((tap) + (d)) / NTAP)
-#define PNP_T3_OVER(cc, tap, d) (PNP_T3_RAW(cc, tap, d) >= cc_end)
-#define PNP_T3_CC(cc, tap, d) (PNP_T3_OVER(cc, tap, d) ? min(PNP_T3_RAW(cc, tap, d) - (cc_end - cc_begin), cc_end - 1) : PNP_T3_RAW(cc, tap, d))
+    const int cc_last = cc_end - 1;
+    // (stage index -> (channel group, tap)) d stages after (cc, tap); past the end the last group is fetched again (never contracted)
+#define PNP_T3_CC(cc, tap, d) (((cc) + ((tap) + (d)) / NTAP) < cc_end ? ((cc) + ((tap) + (d)) / NTAP) : cc_last)
 #define PNP_T3_TAP(tap, d) (((tap) + (d)) % NTAP)
 
-    // prologue: stages 0 and 1 of the first tile into LDS, stage 2 in flight in ring[0]
-    gload(ring[0], cc_begin, 0, false);
-    gload(ring[1], PNP_T3_CC(cc_begin, 0, 1), PNP_T3_TAP(0, 1), PNP_T3_OVER(cc_begin, 0, 1));
+    // prologue: stages 0 and 1 into LDS, stage 2 in flight in ring[0]
+    gload(ring[0], cc_begin, 0);
+    gload(ring[1], PNP_T3_CC(cc_begin, 0, 1), PNP_T3_TAP(0, 1));
     lstore(ring[0], lds, lds + ASZ);
-    gload(ring[0], PNP_T3_CC(cc_begin, 0, 2), PNP_T3_TAP(0, 2), PNP_T3_OVER(cc_begin, 0, 2));
+    gload(ring[0], PNP_T3_CC(cc_begin, 0, 2), PNP_T3_TAP(0, 2));
     lstore(ring[1], lds + STG, lds + STG + ASZ);
     __syncthreads();
     // Fragment ring of four 8-k slices: slice q of a stage is contracted while slice q+2 is being read — two slices (16 MFMAs of a 2x1
@@ -845,64 +852,60 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
     int o_cur = 0, o_nxt = STG, o_st = 2 * STG;        // float offsets of the LDS stages holding s, s+1 and receiving s+2
     constexpr int NMF = 4 * TM * TN;
     constexpr int NDS = (TM + 4 * TN + NMF - 1) / NMF;
-    for (; unit < total; unit += gridDim.x) {
-        if (unit + (int)gridDim.x < total) setup(unit + gridDim.x, nxt);       // (uniform) the tile whose first stages this one's last stages fetch
-        for (int cc0 = cc_begin; cc0 < cc_end; cc0 += CCU) {
+    for (int cc0 = cc_begin; cc0 < cc_end; cc0 += CCU) {
 #pragma unroll
-            for (int u = 0; u < CCU; ++u) {
-                const int cc = cc0 + u;
+        for (int u = 0; u < CCU; ++u) {
+            const int cc = cc0 + u;
 #pragma unroll
-                for (int tap = 0; tap < NTAP; ++tap) {
-                    const int par = (u * NTAP + tap) & 1;            // compile-time after unrolling: stage parity inside the trip
-                    const float* As = lds + o_cur;
-                    const float* Bs = As + ASZ;
-                    const float* An = lds + o_nxt;
-                    const float* Bn = An + ASZ;
-                    float* Ast = lds + o_st;
-                    float* Bst = Ast + ASZ;
-                    // ---- slice 0: fragments of slice 2, the global loads of stage s+3 into the ring slot stored LAST stage
-                    fr[2].load(As, Bs, 2, wm0, wn0, lane);
-                    gload(ring[par ^ 1], PNP_T3_CC(cc, tap, 3), PNP_T3_TAP(tap, 3), PNP_T3_OVER(cc, tap, 3));
-                    fr[0].mma(acc);
-                    __builtin_amdgcn_sched_group_barrier(0x100, TM + 4 * TN, 0);
+            for (int tap = 0; tap < NTAP; ++tap) {
+                const int par = (u * NTAP + tap) & 1;            // compile-time after unrolling: stage parity inside the trip
+                const float* As = lds + o_cur;
+                const float* Bs = As + ASZ;
+                const float* An = lds + o_nxt;
+                const float* Bn = An + ASZ;
+                float* Ast = lds + o_st;
+                float* Bst = Ast + ASZ;
+                // ---- slice 0: fragments of slice 2, the global loads of stage s+3 into the ring slot stored LAST stage
+                fr[2].load(As, Bs, 2, wm0, wn0, lane);
+                gload(ring[par ^ 1], PNP_T3_CC(cc, tap, 3), PNP_T3_TAP(tap, 3));
+                PNP_T3_MMA(fr[0]);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + 4 * TN, 0);
 #pragma unroll
-                    for (int i = 0; i < NMF; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    }
-                    PNP_SCHED_FENCE();
-                    PNP_SLICE(fr[3].load(As, Bs, 3, wm0, wn0, lane), fr[1].mma(acc), NMF, NDS)
-                    // ---- slices 2, 3: the NEXT stage's slices 0, 1 (visible since the previous barrier); the LDS stores of stage s+2
-                    // ride behind the last MFMAs; the barrier then has nothing to wait for but the slowest wave
-                    PNP_SLICE(fr[0].load(An, Bn, 0, wm0, wn0, lane), fr[2].mma(acc), NMF, NDS)
-                    fr[1].load(An, Bn, 1, wm0, wn0, lane);
-                    PNP_SCHED_FENCE();
-                    fr[3].mma(acc);
-                    lstore(ring[par], Ast, Bst);
-                    __builtin_amdgcn_sched_group_barrier(0x008, NMF / 2, 0);
-#pragma unroll
-                    for (int i = 0; i < NMF / 2; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    }
-                    PNP_SCHED_FENCE();
-                    __syncthreads();
-                    const int o_t = o_cur;
-                    o_cur = o_nxt;
-                    o_nxt = o_st;
-                    o_st = o_t;
+                for (int i = 0; i < NMF; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
+                PNP_SCHED_FENCE();
+                PNP_SLICE(fr[3].load(As, Bs, 3, wm0, wn0, lane), PNP_T3_MMA(fr[1]), NMF, NDS)
+                // ---- slices 2, 3: the NEXT stage's slices 0, 1 (visible since the previous barrier); the LDS stores of stage s+2 ride
+                // behind the last MFMAs; the barrier then has nothing to wait for but the slowest wave
+                PNP_SLICE(fr[0].load(An, Bn, 0, wm0, wn0, lane), PNP_T3_MMA(fr[2]), NMF, NDS)
+                fr[1].load(An, Bn, 1, wm0, wn0, lane);
+                PNP_SCHED_FENCE();
+                PNP_T3_MMA(fr[3]);
+                lstore(ring[par], Ast, Bst);
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF / 2, 0);
+#pragma unroll
+                for (int i = 0; i < NMF / 2; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+                PNP_SCHED_FENCE();
+                __syncthreads();
+                const int o_t = o_cur;
+                o_cur = o_nxt;
+                o_nxt = o_st;
+                o_st = o_t;
             }
         }
-        conv_epilogue<TM, TN>(a, acc, a.y + (size_t)cur.z * a.split_stride, cur.m0, cur.n0, wm0, wn0, lane, cur.mt * WM + wave / WN, cur.z == 0);
-        acc.zero();
-        cur = nxt;
     }
-#undef PNP_T3_RAW
-#undef PNP_T3_OVER
 #undef PNP_T3_CC
 #undef PNP_T3_TAP
+#undef PNP_T3_MMA
+    if constexpr (SPLIT) acc_add(acc, accb);
+
+    conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
 }
 
 // ===================================== wgrad kernel ============================================
@@ -1794,18 +1797,13 @@ bool launch_taps(const ConvArgs& a, dim3 grid, hipStream_t st) {
     static const int env_t3 = getenv("PNP_CONV_TAPS3") ? atoi(getenv("PNP_CONV_TAPS3")) : PNP_TAPS3_DEFAULT;
     const int cc_per = a.chunks_per_split / (a.R * a.S);
     const bool t3 = env_t3 && BN <= 64 && ((a.R * a.S) % 2 == 0 || (cc_per % 2 == 0 && (a.nsplit == 1 || (a.C / BK) % cc_per == 0)));
-    // persistent launch of the three-stage kernel: un-split, many more tiles than the 512 workgroups the chip holds (2 per CU), and at
-    // least four stages per tile (the lookahead of three stays inside the next tile)
-    static const int env_persist = getenv("PNP_CONV_PERSIST") ? atoi(getenv("PNP_CONV_PERSIST")) : 1;
-    const bool persist = env_persist && a.nsplit == 1 && a.nblk_m * a.nblk_n >= 1024 && cc_per * a.R * a.S >= 4;
-    const dim3 pgrid(persist ? 512u : grid.x);
 #define PNP_TAPS(RR, SS)                                                                                                   \
     if (a.R == RR && a.S == SS) {                                                                                          \
         if constexpr (BN <= 64 && RR * SS <= 9) {     /* 5x5: 50 unrolled stages per trip and spills — stays on the two-stage kernel */ \
             if (t3) {                                                                                                      \
                 PnpProfScope ps(prof_class(KIND), st, conv_flops(a), conv_bytes(a), "conv_taps3_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, \
                                 BN, WM, WN, KIND, RR, SS);                                                                  \
-                hipLaunchKernelGGL((conv_taps3_kernel<BM, BN, WM, WN, KIND, RR, SS>), pgrid, dim3(NTHREADS), 0, st, a);     \
+                hipLaunchKernelGGL((conv_taps3_kernel<BM, BN, WM, WN, KIND, RR, SS>), grid, dim3(NTHREADS), 0, st, a);      \
                 return true;                                                                                               \
             }                                                                                                              \
         }                                                                                                                  \
