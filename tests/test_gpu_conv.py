@@ -169,6 +169,8 @@ def test_conv_full_size_vs_naive_kernel(dev, shape):
     (16, 256, 256, 3, 16, 3, 1, 1, "SAME"), (16, 256, 256, 16, 16, 3, 1, 1, "SAME"), (16, 260, 260, 40, 5, 5, 1, 1, "VALID"),
     (16, 128, 128, 16, 32, 3, 1, 1, "SAME"), (16, 128, 128, 32, 32, 3, 1, 1, "SAME"), (16, 64, 64, 32, 64, 3, 1, 1, "SAME"),
     (16, 256, 256, 40, 5, 5, 1, 1, "SYMMETRIC"), (16, 256, 256, 64, 64, 3, 2, 1, "SAME"),
+    (16, 256, 256, 64, 64, 3, 1, 1, "SAME"), (16, 256, 256, 32, 64, 3, 1, 1, "SAME"),      # cls_1 (8192 tiles of the three-stage kernel)
+    (5, 250, 250, 64, 64, 3, 1, 1, "SAME"),                                                   # ... ragged last tile, extents not powers of two
     (16, 128, 128, 128, 128, 5, 2, 1, "SAME"), (16, 64, 64, 256, 256, 3, 2, 1, "SAME"), (16, 16, 16, 512, 512, 5, 4, 1, "SAME"),
     (16, 4, 4, 512, 512, 3, 2, 1, "SYMMETRIC")])
 def test_conv_full_size_adjoint_identities(dev, shape):

@@ -230,7 +230,8 @@ def test_fused_conv_bn_inference_equals_separate_kernels(dev, case):
 
 @pytest.mark.parametrize("case", [(16, 32, 32, 256, 256, 3, 1, 1, 0.75), (8, 64, 64, 64, 64, 3, 1, 1, 1.0), (13, 37, 41, 96, 72, 3, 1, 1, 0.75),
                                   (8, 128, 128, 64, 64, 3, 2, 1, 0.75), (16, 32, 32, 512, 512, 3, 1, 2, 0.75), (2, 256, 256, 32, 64, 3, 1, 1, 0.75),
-                                  (5, 120, 100, 32, 64, 3, 1, 1, 0.75)],       # 938 partials: compacted in 7 slabs, the last one 170 long
+                                  (5, 120, 100, 32, 64, 3, 1, 1, 0.75),        # 938 partials: compacted in 7 slabs, the last one 170 long
+                                  (4, 256, 256, 64, 64, 3, 1, 1, 0.75)],       # cls_1 at 256^2: 4096 partials
                          ids=lambda c: "x".join(str(v) for v in c))
 def test_bn_statistics_from_the_conv_epilogue(dev, case):
     """pnp_conv2d_fwd_stats + pnp_bn_stats_finish == pnp_conv2d_fwd + pnp_bn_stats (+ pnp_bn_update_moving): same output tensor bit
