@@ -162,6 +162,11 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off) 
 // Epilogue of the forward / data-gradient kernels.  C/D layout of the 32x32 MFMAs: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // dropout (counter hash on the flat output index) -> optional BN statistics partials -> optional fused inference BN -> store
 // (plain rows, or scattered to a stride phase's pixels).  part = index of this wave's row block among all (pixel tile, wave row) pairs.
+// The epilogue runs in PHASES, each a loop over the wave's 16*TM*TN values with its (uniform) feature test OUTSIDE the loop: first every
+// phase that reads memory or only computes (dropout, residual add, statistics, fused inference BN + shortcut + activation), then ONE phase
+// of pure stores.  Round 3's stage trace (tools/experiments/stage_trace.py) showed why: with loads and stores interleaved per value the
+// compiler fenced every store with s_waitcnt vmcnt(0) (a later load may alias it), i.e. one memory round trip PER VALUE — the epilogue of a
+// 128x64 tile took as long as its 18-stage main loop (44.6k vs 40.7k clocks), 24 % of a 72-stage tile's life, 13 % of a 128x128 tile's.
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, TN>& acc, float* __restrict__ yout, int m0, int n0, int wm0,
                                               int wn0, int lane, int part, bool first_split = true) {
@@ -169,49 +174,104 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, T
     const int l31 = lane & 31, h = lane >> 5;
     const bool scatter = a.o_s != 0 && a.nsplit == 1;                  // split partials stay row-major; the reduce kernel scatters them
     const bool stats = a.stat_ws != nullptr;
-    float ssum[TN], ssq[TN], shift[TN];
+    Acc<TM, TN> o = acc;                      // the values on their way out (register copy)
+    int ncol[TN];
+    bool cok[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + wn0 + tn * 32 + l31;
-        ssum[tn] = 0.f;
-        ssq[tn] = 0.f;
-        shift[tn] = (stats && a.stat_shift && n < a.K) ? a.stat_shift[n] : 0.f;
+        ncol[tn] = n0 + wn0 + tn * 32 + l31;
+        cok[tn] = ncol[tn] < a.K;
     }
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn0 + tn * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < a.M && n < a.K) {
-                    float v = acc.v[tm][tn][r];
-                    const size_t idx = (size_t)m * a.K + n;
-                    if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-                    if (res) v += res[idx];
-                    if (stats) {
-                        const float d = v - shift[tn];
-                        ssum[tn] += d;
-                        ssq[tn] = fmaf(d, d, ssq[tn]);
-                    }
-                    if (a.ep_scale) v = bn_epilogue(a, v, m, n);
-                    yout[out_row(a, m, scatter) + n] = v;
-                }
-            }
+    const int mbase = m0 + wm0 + 4 * h;
+#define PNP_EP_FOR                                                      \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                   \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)               \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)
+#define PNP_EP_M (mbase + tm * 32 + (r & 3) + 8 * (r >> 2))
+    // ---- dropout (counter hash on the flat output index)
+    if (a.do_drop) {
+        PNP_EP_FOR {
+            const uint32_t idx = (uint32_t)((size_t)PNP_EP_M * a.K + ncol[tn]);
+            o.v[tm][tn][r] = pnp_drop_keep(idx, a.drop_key, a.drop_thresh) ? o.v[tm][tn][r] * a.drop_scale : 0.f;
         }
+    }
+    // ---- residual add (data gradients: the gradient that reaches the same tensor through a shortcut): all loads, then all adds
+    if (res) {
+        Acc<TM, TN> rv;
+        PNP_EP_FOR {
+            const int m = PNP_EP_M;
+            const bool ok = (m < a.M) & cok[tn];
+            rv.v[tm][tn][r] = res[ok ? (size_t)m * a.K + ncol[tn] : 0];
+        }
+        PNP_EP_FOR o.v[tm][tn][r] += rv.v[tm][tn][r];
+    }
+    // ---- batch-norm statistics partials of the (post-dropout) output
     if (stats) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            const float s = ssum[tn] + __shfl_xor(ssum[tn], 32, 64);     // the two half-waves hold the same column, disjoint rows
-            const float q = ssq[tn] + __shfl_xor(ssq[tn], 32, 64);
-            const int n = n0 + wn0 + tn * 32 + l31;
-            if (h == 0 && n < a.K) {
-                a.stat_ws[((size_t)part * 2 + 0) * a.K + n] = s;
-                a.stat_ws[((size_t)part * 2 + 1) * a.K + n] = q;
+            const float shift = (a.stat_shift && cok[tn]) ? a.stat_shift[ncol[tn]] : 0.f;
+            float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = (PNP_EP_M < a.M) ? o.v[tm][tn][r] - shift : 0.f;
+                    ssum += d;
+                    ssq = fmaf(d, d, ssq);
+                }
+            const float s = ssum + __shfl_xor(ssum, 32, 64);     // the two half-waves hold the same column, disjoint rows
+            const float q = ssq + __shfl_xor(ssq, 32, 64);
+            if (h == 0 && cok[tn]) {
+                a.stat_ws[((size_t)part * 2 + 0) * a.K + ncol[tn]] = s;
+                a.stat_ws[((size_t)part * 2 + 1) * a.K + ncol[tn]] = q;
             }
         }
     }
+    // ---- fused inference-mode BN (+ shortcut, channel zero-padded) + leaky-ReLU
+    if (a.ep_scale) {
+        float sc[TN], sh[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            sc[tn] = cok[tn] ? a.ep_scale[ncol[tn]] : 0.f;
+            sh[tn] = cok[tn] ? a.ep_shift[ncol[tn]] : 0.f;
+        }
+        PNP_EP_FOR o.v[tm][tn][r] = fmaf(o.v[tm][tn][r], sc[tn], sh[tn]);
+        if (a.ep_res) {
+            const int cpad = (a.K - a.ep_cs) >> 1;
+            Acc<TM, TN> rv;
+            PNP_EP_FOR {
+                const int m = PNP_EP_M;
+                const int cs = ncol[tn] - cpad;
+                const bool ok = (m < a.M) & ((unsigned)cs < (unsigned)a.ep_cs);
+                const float x = a.ep_res[ok ? (size_t)m * a.ep_cs + cs : 0];
+                rv.v[tm][tn][r] = ok ? x : 0.f;
+            }
+            PNP_EP_FOR o.v[tm][tn][r] += rv.v[tm][tn][r];
+        }
+        if (a.ep_alpha >= 0.f) {
+            PNP_EP_FOR o.v[tm][tn][r] = o.v[tm][tn][r] < 0.f ? o.v[tm][tn][r] * a.ep_alpha : o.v[tm][tn][r];
+        }
+    }
+    // ---- stores, nothing else (plain rows, or scattered to a stride phase's pixels)
+    if (scatter) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = PNP_EP_M;
+                const size_t row = out_row(a, m < a.M ? m : 0, true);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    if ((m < a.M) & cok[tn]) yout[row + ncol[tn]] = o.v[tm][tn][r];
+            }
+    } else {
+        PNP_EP_FOR {
+            const int m = PNP_EP_M;
+            if ((m < a.M) & cok[tn]) yout[(size_t)m * a.K + ncol[tn]] = o.v[tm][tn][r];
+        }
+    }
+#undef PNP_EP_FOR
+#undef PNP_EP_M
 }
 
 // Epilogue of the filter-gradient kernels: the wave's 32x32 accumulator tiles -> dW rows [m' = (tap, channel)][k] (or this split's
@@ -220,6 +280,29 @@ template <int TM, int TN>
 __device__ __forceinline__ void wgrad_epilogue(const ConvArgs& a, const Acc<TM, TN>& acc, float* __restrict__ out, int mm0, int n0, int wm0, int wn0,
                                                int lane) {
     const int l31 = lane & 31, h = lane >> 5;
+    Acc<TM, TN> o = acc;
+    const int mbase = mm0 + wm0 + 4 * h;
+    if (a.accumulate) {            // (loads first, then stores only: see conv_epilogue)
+        Acc<TM, TN> old;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = n0 + wn0 + tn * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + tm * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool ok = (m < a.Kred) & (n < a.K);
+                    old.v[tm][tn][r] = out[ok ? (size_t)m * a.K + n : 0];
+                }
+            }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o.v[tm][tn][r] += old.v[tm][tn][r];
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -227,11 +310,8 @@ __device__ __forceinline__ void wgrad_epilogue(const ConvArgs& a, const Acc<TM, 
             const int n = n0 + wn0 + tn * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < a.Kred && n < a.K) {
-                    const size_t idx = (size_t)m * a.K + n;
-                    out[idx] = a.accumulate ? out[idx] + acc.v[tm][tn][r] : acc.v[tm][tn][r];
-                }
+                const int m = mbase + tm * 32 + (r & 3) + 8 * (r >> 2);
+                if ((m < a.Kred) & (n < a.K)) out[(size_t)m * a.K + n] = o.v[tm][tn][r];
             }
         }
 }

@@ -36,6 +36,25 @@
 
 using namespace pnpconv;
 
+// Timing-experiment builds only (make variant NAME=trace EXTRA=-DPNP_TRACE=1): wave 0 of the first 256 workgroups of the two tap-unrolled
+// forward kernels writes the shader clock at kernel entry, after the tile set-up, at the start of the main loop, after every stage's
+// barrier, and around the epilogue; tools/experiments/stage_trace.py reads it back (pnp_debug_trace_read).  Never in the shipped library.
+#ifdef PNP_TRACE
+constexpr int TRACE_WG = 256, TRACE_N = 192;
+__device__ unsigned long long g_trace[TRACE_WG][TRACE_N];
+#define PNP_TRACE_MARK(slot)                                                                             \
+    do {                                                                                                 \
+        const unsigned tr_ = blockIdx.x - (gridDim.x > 4352u ? 4096u : 0u);      /* big launches: workgroups of the steady state */  \
+        if (threadIdx.x == 0 && tr_ < (unsigned)TRACE_WG && (slot) < TRACE_N) g_trace[tr_][(slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int pnp_debug_trace_read(void* host, size_t bytes) {
+    if (bytes > sizeof(unsigned long long) * TRACE_WG * TRACE_N) bytes = sizeof(unsigned long long) * TRACE_WG * TRACE_N;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#else
+#define PNP_TRACE_MARK(slot) do { } while (0)
+#endif
+
 namespace {
 
 // ---- B tile (weights for fwd, dy for wgrad): row-major [rows][ncols] global matrix ------------
@@ -616,6 +635,7 @@ __global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS
     constexpr int C4 = BN / 4, RPB = NTHREADS / C4, NPB = BK / RPB;
     __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
 
+    PNP_TRACE_MARK(0);
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -688,9 +708,11 @@ __global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS
     int cc_end = cc_begin + a.chunks_per_split / NTAP;
     if (cc_end > ncc_total) cc_end = ncc_total;
 
+    PNP_TRACE_MARK(1);
     gload(cc_begin, 0);
     lstore(lds, lds + 2 * ASZ);
     __syncthreads();
+    PNP_TRACE_MARK(2);
     Frag<TM, TN, true, LDA, LDB> f0, f1;
     f0.load(lds, lds + 2 * ASZ, 0, wm0, wn0, lane);
     int sc = 0;   // stage counter (LDS buffer parity)
@@ -724,11 +746,14 @@ __global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS
             PNP_SLICE2(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), lstore(An, Bn), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
             PNP_LAST_SLICE(f1.mma(acc), lstore(An, Bn), 4 * TM * TN)
             __syncthreads();
+            PNP_TRACE_MARK(3 + sc);
             f0.load(An, Bn, 0, wm0, wn0, lane);
         }
     }
+    PNP_TRACE_MARK(4 + sc);
 
     conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
+    PNP_TRACE_MARK(5 + sc);
 }
 
 // ---- the same tap-unrolled convolution with THREE LDS stages and a register ring of two global-load stages (narrow tiles) ------------
@@ -757,6 +782,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
     static_assert(3 * STG * 4 <= 81920, "three stages must leave room for two workgroups per CU");
     __shared__ __attribute__((aligned(16))) float lds[3 * STG];
 
+    PNP_TRACE_MARK(0);
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -838,6 +864,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
 #define PNP_T3_TAP(tap, d) (((tap) + (d)) % NTAP)
 
     // prologue: stages 0 and 1 into LDS, stage 2 in flight in ring[0]
+    PNP_TRACE_MARK(1);
+    int tsc = 0;
+    (void)tsc;
     gload(ring[0], cc_begin, 0);
     gload(ring[1], PNP_T3_CC(cc_begin, 0, 1), PNP_T3_TAP(0, 1));
     lstore(ring[0], lds, lds + ASZ);
@@ -849,6 +878,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
     Frag<TM, TN, true, LDA, LDB> fr[4];
     fr[0].load(lds, lds + ASZ, 0, wm0, wn0, lane);
     fr[1].load(lds, lds + ASZ, 1, wm0, wn0, lane);
+    PNP_TRACE_MARK(2);
     int o_cur = 0, o_nxt = STG, o_st = 2 * STG;        // float offsets of the LDS stages holding s, s+1 and receiving s+2
     constexpr int NMF = 4 * TM * TN;
     constexpr int NDS = (TM + 4 * TN + NMF - 1) / NMF;
@@ -893,6 +923,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
                 }
                 PNP_SCHED_FENCE();
                 __syncthreads();
+                ++tsc;
+                PNP_TRACE_MARK(2 + tsc);
                 const int o_t = o_cur;
                 o_cur = o_nxt;
                 o_nxt = o_st;
@@ -905,7 +937,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
 #undef PNP_T3_MMA
     if constexpr (SPLIT) acc_add(acc, accb);
 
+    PNP_TRACE_MARK(3 + tsc);
     conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
+    PNP_TRACE_MARK(4 + tsc);
 }
 
 // ===================================== wgrad kernel ============================================
