@@ -157,6 +157,10 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
+// a store whose byte offset is past the end of the buffer is DROPPED by the hardware: masked lanes need no branch around the store
+__device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
 
 
 // Epilogue of the forward / data-gradient kernels.  C/D layout of the 32x32 MFMAs: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -197,11 +201,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, T
     }
     // ---- residual add (data gradients: the gradient that reaches the same tensor through a shortcut): all loads, then all adds
     if (res) {
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(res, (unsigned)((size_t)a.M * a.K * 4));     // [M][K] rows like the output
         Acc<TM, TN> rv;
         PNP_EP_FOR {
             const int m = PNP_EP_M;
-            const bool ok = (m < a.M) & cok[tn];
-            rv.v[tm][tn][r] = res[ok ? (size_t)m * a.K + ncol[tn] : 0];
+            rv.v[tm][tn][r] = bload1(rr, ((m < a.M) & cok[tn]) ? (unsigned)(m * a.K + ncol[tn]) * 4u : OOB);      // out of range: 0
         }
         PNP_EP_FOR o.v[tm][tn][r] += rv.v[tm][tn][r];
     }
@@ -252,24 +256,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, T
             PNP_EP_FOR o.v[tm][tn][r] = o.v[tm][tn][r] < 0.f ? o.v[tm][tn][r] * a.ep_alpha : o.v[tm][tn][r];
         }
     }
-    // ---- stores, nothing else (plain rows, or scattered to a stride phase's pixels)
-    if (scatter) {
+    // ---- stores, nothing else (plain rows, or scattered to a stride phase's pixels).  Buffer stores: a masked value gets an offset past
+    // the end of the tensor and the hardware drops it — no exec-mask branch per value, 32-bit offsets (host: tensors < 2^30 elements)
+    const size_t yelems = scatter ? (size_t)a.N * a.o_H * a.o_W * a.K : (size_t)a.M * a.K;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(yout, (unsigned)(yelems * 4));
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = PNP_EP_M;
-                const size_t row = out_row(a, m < a.M ? m : 0, true);
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    if ((m < a.M) & cok[tn]) yout[row + ncol[tn]] = o.v[tm][tn][r];
-            }
-    } else {
-        PNP_EP_FOR {
+        for (int r = 0; r < 16; ++r) {
             const int m = PNP_EP_M;
-            if ((m < a.M) & cok[tn]) yout[(size_t)m * a.K + ncol[tn]] = o.v[tm][tn][r];
+            const bool mok = m < a.M;
+            const unsigned row = scatter ? (unsigned)out_row(a, mok ? m : 0, true) : (unsigned)(m * a.K);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bstore1(ry, (mok & cok[tn]) ? (row + ncol[tn]) * 4u : OOB, o.v[tm][tn][r]);
         }
-    }
 #undef PNP_EP_FOR
 #undef PNP_EP_M
 }

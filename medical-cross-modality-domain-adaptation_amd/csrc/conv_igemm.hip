@@ -40,7 +40,7 @@ using namespace pnpconv;
 // forward kernels writes the shader clock at kernel entry, after the tile set-up, at the start of the main loop, after every stage's
 // barrier, and around the epilogue; tools/experiments/stage_trace.py reads it back (pnp_debug_trace_read).  Never in the shipped library.
 #ifdef PNP_TRACE
-constexpr int TRACE_WG = 256, TRACE_N = 192;
+constexpr int TRACE_WG = 512, TRACE_N = 192;
 __device__ unsigned long long g_trace[TRACE_WG][TRACE_N];
 #define PNP_TRACE_MARK(slot)                                                                             \
     do {                                                                                                 \

@@ -85,24 +85,32 @@ __global__ void __launch_bounds__(256) conv_n16_kernel(ConvArgs a, int tiles_w, 
                 }
             }
         }
-        // epilogue: lane holds rows (pixels) 4g+i, column (filter) p of each tile
+        // epilogue: lane holds rows (pixels) 4g+i, column (filter) p of each tile.  Phases like conv_epilogue (conv_common.h): everything
+        // that reads memory first, then stores only — interleaved, every store was fenced with vmcnt(0) against the next value's loads
+        float ov[4][4];
+        size_t oidx[4][4];
+        bool ook[4][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int oh = oh0 + 2 * wave + (q >> 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ow = ow0 + 16 * (q & 1) + 4 * g + i;
-                if (oh < a.OH && ow < a.OW) {
-                    const int m = (n * a.OH + oh) * a.OW + ow;
-                    const size_t idx = (size_t)m * 16 + p;
-                    float v = acc[q][i];
-                    if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-                    if (a.res_add) v += a.res_add[idx];
-                    if (a.ep_scale) v = bn_epilogue(a, v, m, p);
-                    a.y[idx] = v;
-                }
+                ook[q][i] = oh < a.OH && ow < a.OW;
+                const int m = ook[q][i] ? (n * a.OH + oh) * a.OW + ow : 0;
+                oidx[q][i] = (size_t)m * 16 + p;
+                float v = acc[q][i];
+                if (a.do_drop) v = pnp_drop_keep((uint32_t)oidx[q][i], a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                if (a.res_add) v += a.res_add[oidx[q][i]];
+                if (a.ep_scale) v = bn_epilogue(a, v, m, p);
+                ov[q][i] = v;
             }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (ook[q][i]) a.y[oidx[q][i]] = ov[q][i];
     }
 }
 
@@ -231,19 +239,24 @@ __global__ void __launch_bounds__(256) conv_c3n16_kernel(ConvArgs a, int tiles_w
 #pragma unroll
             for (int i = 0; i < 7; ++i) acc = mfma16(lds[base + aoff[i]], wreg[i], acc);
             const int oh = oh0 + 2 * wave + (q >> 1);
+            float ov[4];
+            size_t oidx[4];
+            bool ook[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i) {           // (loads first, then stores only: see conv_n16_kernel)
                 const int ow = ow0 + 16 * (q & 1) + 4 * g + i;
-                if (oh < a.OH && ow < a.OW) {
-                    const int m = (n * a.OH + oh) * a.OW + ow;
-                    const size_t idx = (size_t)m * 16 + p;
-                    float v = acc[i];
-                    if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-                    if (a.res_add) v += a.res_add[idx];
-                    if (a.ep_scale) v = bn_epilogue(a, v, m, p);
-                    a.y[idx] = v;
-                }
+                ook[i] = oh < a.OH && ow < a.OW;
+                const int m = ook[i] ? (n * a.OH + oh) * a.OW + ow : 0;
+                oidx[i] = (size_t)m * 16 + p;
+                float v = acc[i];
+                if (a.do_drop) v = pnp_drop_keep((uint32_t)oidx[i], a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                if (a.res_add) v += a.res_add[oidx[i]];
+                if (a.ep_scale) v = bn_epilogue(a, v, m, p);
+                ov[i] = v;
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (ook[i]) a.y[oidx[i]] = ov[i];
         }
     }
 }

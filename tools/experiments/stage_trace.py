@@ -19,7 +19,7 @@ for which in sys.argv[1:] or ["narrow", "long64", "wide", "wide36"]:
     for _ in range(3):
         y = K.conv2d_fwd(x, w, g)
     torch.cuda.synchronize()
-    buf = np.zeros((256, 192), np.uint64)
+    buf = np.zeros((512, 192), np.uint64)
     L.load()
     raw = ctypes.CDLL(L.LIB_PATH)                  # same handle as the loaded library: reads its g_trace
     raw.pnp_debug_trace_read.restype = ctypes.c_int
@@ -44,3 +44,6 @@ for which in sys.argv[1:] or ["narrow", "long64", "wide", "wide36"]:
         tot = t[:, base + 2 + S] - t[:, 0]
         line += ", epilogue %6.0f, whole workgroup %7.0f clk (main loop %.0f %%)" % (np.median(ep), np.median(tot), 100 * np.median((ep0 - t[:, 2]) / tot))
     print(line)
+    t0, t1 = t[:, 0], t[:, base + 2 + S] if base + 2 + S < 192 else t[:, 2]
+    print("        first instruction of the traced workgroups spread over %7.0f clk (p50 - min %6.0f); last instruction spread %7.0f; first start -> last end %8.0f clk"
+          % (t0.max() - t0.min(), np.median(t0) - t0.min(), t1.max() - t1.min(), t1.max() - t0.min()))
