@@ -661,14 +661,13 @@ __global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS
         split_row(a, m, n, oh, ow);
         const int vh0 = oh * a.stride - a.pad_t, vw0 = ow * a.stride - a.pad_l;
         abase[i] = (((n * a.H + vh0) * a.W + vw0) * a.C + 4 * kg) * 4;
-        unsigned mk = 0;
+        // tap (r, s) is valid iff its row AND its column are inside the image: R + S tests and R shifted ORs instead of R*S full tests
+        unsigned wm = 0, mk = 0;
 #pragma unroll
-        for (int tap = 0; tap < NTAP; ++tap) {
-            const int ih = vh0 + (tap / S) * a.dil, iw = vw0 + (tap % S) * a.dil;
-            const bool v = ok & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-            mk |= (v ? 1u : 0u) << tap;
-        }
-        amask[i] = mk;
+        for (int sx = 0; sx < S; ++sx) wm |= ((unsigned)(vw0 + sx * a.dil) < (unsigned)a.W ? 1u : 0u) << sx;
+#pragma unroll
+        for (int ry = 0; ry < R; ++ry) mk |= ((unsigned)(vh0 + ry * a.dil) < (unsigned)a.H ? wm : 0u) << (ry * S);
+        amask[i] = ok ? mk : 0u;
     }
     // ---- per-thread B rows ------------------------------------------------------------------------------------------
     const int bcol = t % C4, brow = t / C4;
@@ -807,14 +806,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
         split_row(a, m, n, oh, ow);
         const int vh0 = oh * a.stride - a.pad_t, vw0 = ow * a.stride - a.pad_l;
         abase[i] = (((n * a.H + vh0) * a.W + vw0) * a.C + 4 * kg) * 4;
-        unsigned mk = 0;
+        // tap (r, s) is valid iff its row AND its column are inside the image: R + S tests and R shifted ORs instead of R*S full tests
+        unsigned wm = 0, mk = 0;
 #pragma unroll
-        for (int tap = 0; tap < NTAP; ++tap) {
-            const int ih = vh0 + (tap / S) * a.dil, iw = vw0 + (tap % S) * a.dil;
-            const bool v = ok & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-            mk |= (v ? 1u : 0u) << tap;
-        }
-        amask[i] = mk;
+        for (int sx = 0; sx < S; ++sx) wm |= ((unsigned)(vw0 + sx * a.dil) < (unsigned)a.W ? 1u : 0u) << sx;
+#pragma unroll
+        for (int ry = 0; ry < R; ++ry) mk |= ((unsigned)(vh0 + ry * a.dil) < (unsigned)a.H ? wm : 0u) << (ry * S);
+        amask[i] = ok ? mk : 0u;
     }
     const int bcol = t % C4, brow = t / C4;
     unsigned boff[NPB];
