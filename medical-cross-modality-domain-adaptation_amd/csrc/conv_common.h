@@ -55,9 +55,6 @@ struct ConvArgs {
     // instead of two integer divisions (~25 VALU each; a 128x64 tile of a 64-channel layer spends ~3 % of its life on them, the
     // scattered epilogue of a stride-phase data gradient far more); -1: divide
     int ow_sh, ohw_sh;
-    // wave priority of the non-MFMA parts (tile set-up, epilogue): a workgroup that starts or finishes while its CU neighbour saturates
-    // the matrix pipe gets its integer work and its stores issued first (s_setprio); 0: off
-    int prio;
 };
 
 // output row m -> (image n, oh, ow)

@@ -636,7 +636,6 @@ __global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS
     __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
 
     PNP_TRACE_MARK(0);
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -713,7 +712,6 @@ __global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS
     lstore(lds, lds + 2 * ASZ);
     __syncthreads();
     PNP_TRACE_MARK(2);
-    if (a.prio) __builtin_amdgcn_s_setprio(0);
     Frag<TM, TN, true, LDA, LDB> f0, f1;
     f0.load(lds, lds + 2 * ASZ, 0, wm0, wn0, lane);
     int sc = 0;   // stage counter (LDS buffer parity)
@@ -752,7 +750,6 @@ __global__ void __launch_bounds__(NTHREADS, ((BN <= 64 && R * S <= 9) ? PNP_TAPS
         }
     }
     PNP_TRACE_MARK(4 + sc);
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
 
     conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
     PNP_TRACE_MARK(5 + sc);
@@ -785,7 +782,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[3 * STG];
 
     PNP_TRACE_MARK(0);
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -881,7 +877,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
     fr[0].load(lds, lds + ASZ, 0, wm0, wn0, lane);
     fr[1].load(lds, lds + ASZ, 1, wm0, wn0, lane);
     PNP_TRACE_MARK(2);
-    if (a.prio) __builtin_amdgcn_s_setprio(0);
     int o_cur = 0, o_nxt = STG, o_st = 2 * STG;        // float offsets of the LDS stages holding s, s+1 and receiving s+2
     constexpr int NMF = 4 * TM * TN;
     constexpr int NDS = (TM + 4 * TN + NMF - 1) / NMF;
@@ -941,7 +936,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_taps3_kernel(ConvArgs a) {
     if constexpr (SPLIT) acc_add(acc, accb);
 
     PNP_TRACE_MARK(3 + tsc);
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
     conv_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, z == 0);
     PNP_TRACE_MARK(4 + tsc);
 }
@@ -1760,8 +1754,6 @@ ConvArgs make_args(const float* x, const float* w, float* y, const pnp_conv_geom
     a.OHW = g->OH * g->OW;
     a.nsplit = 1; a.chunks_per_split = 0; a.split_stride = 0;
     const bool p2 = (a.OW & (a.OW - 1)) == 0 && (a.OHW & (a.OHW - 1)) == 0;
-    static const int env_prio = getenv("PNP_CONV_PRIO") ? atoi(getenv("PNP_CONV_PRIO")) : 1;
-    a.prio = env_prio;
     a.ow_sh = p2 ? __builtin_ctz((unsigned)a.OW) : -1;
     a.ohw_sh = p2 ? __builtin_ctz((unsigned)a.OHW) : -1;
     a.do_drop = 0; a.drop_scale = 1.f; a.drop_key = 0; a.drop_thresh = 0;
