@@ -1,18 +1,19 @@
 # Regenerates everything under profiles/ for the current round on a GPU box:  bash tools/collect_round.sh   (raw output: gpurun_out/$R/)
-# Every step runs under its own `timeout`: in round 2 a `rocprofv3 --pmc` pass hung and ate the remaining 26 GPU-minutes of the round.
+# Every step runs under its own `timeout`; the benchmark lines come FIRST (a box that has just run the 12-minute test suite clocks ~3 % lower),
+# the `rocprofv3 --pmc` passes LAST and guarded: in round 2 one hung pass ate the remaining 26 GPU-minutes of the round.
+# PART=A: smoke, bench lines, kernel traces, per-layer tables, entry-point loops, the whole -m gpu suite.  PART=B: ASAN run, CPU path at
+# B=16, PMC passes.  Default: both.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=${R:-r3z}; O=gpurun_out/$R; mkdir -p $O
 P=$GRAFT_REPO_ROOT/medical-cross-modality-domain-adaptation_amd
-# -s: the parity tests PRINT their measured errors (the whole-step bars are set from these numbers: profiles/rNN_pytest_gpu.log)
-if [ -z "$SKIP_TESTS" ]; then timeout 1800 python -m pytest tests -m gpu -q -s --durations=15 > $O/tests.log 2>&1; tail -3 $O/tests.log; fi
+PART=${PART:-AB}
+if [[ $PART == *A* ]]; then
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 # the driver's line (joint segmenter+GAN step, segmenter sub-record, joint cpu_baseline), the segmenter workload as its own line, bf16
 timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 400 $O/bench_n1.json
 timeout 600 python bench.py --workload segmenter --no-sub > $O/bench_segmenter_n1.json 2>/dev/null
 timeout 600 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16_n1.json 2>/dev/null
 [ -z "$FAST" ] && timeout 600 python bench.py --dtype bf16 --batch 32 --no-cpu-baseline --no-sub > $O/bench_bf16_B32_n1.json 2>/dev/null
-# the CPU path at the GPU line's own batch, once (2 steps after 1 warm-up: ~3 min of host time; the default line bounds the sample with B=2)
-[ -z "$FAST" ] && timeout 900 python bench.py --steps 3 --warmup 1 --no-probe --no-sub --cpu-batch 16 --cpu-steps 2 --cpu-warmup 1 > $O/bench_cpu_B16.json 2>/dev/null
 # kernel traces (rocprofv3 --kernel-trace --stats), same command lines as the bench
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub"
 timeout 420 rocprofv3 --kernel-trace --stats -d $O/prof_joint -o joint -- $B > $O/bench_prof_joint.json 2>/dev/null
@@ -32,12 +33,19 @@ DTYPE=bf16 timeout 300 python tools/bench_conv.py > $O/conv_layers_bf16.txt 2>/d
 if [ -z "$FAST" ]; then
 python tools/e2e_segmenter.py 2>&1 | grep "E2E" > $O/e2e.txt; cat $O/e2e.txt
 timeout 400 python tools/e2e_gan.py 2>&1 | grep "E2E" > $O/e2e_gan.txt; cat $O/e2e_gan.txt
+fi
+# -s: the parity tests PRINT their measured errors (the whole-step bars are set from these numbers: profiles/rNN_pytest_gpu.log)
+if [ -z "$SKIP_TESTS" ]; then timeout 1800 python -m pytest tests -m gpu -q -s --durations=15 > $O/tests.log 2>&1; tail -3 $O/tests.log; fi
+rm -rf $O/prof_joint $O/prof_seg $O/prof_bf16     # the sqlite traces are large; the summaries stay
+fi
+if [[ $PART == *B* ]]; then
 # host side of the library under AddressSanitizer (device code uninstrumented): the conv parity tests through libpnp_hip_asan.so
 if [ -f $P/libpnp_hip_asan.so ]; then
   LD_PRELOAD=$(/opt/rocm/bin/hipcc -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 PNP_LIB=$P/libpnp_hip_asan.so \
     timeout 600 python -m pytest tests/test_abi.py tests/test_gpu_conv.py -q > $O/asan_gpu.log 2>&1; tail -2 $O/asan_gpu.log
 fi
-fi
+# the CPU path at the GPU line's own batch, once (2 steps after 1 warm-up: ~3 min of host time; the default line bounds the sample with B=2)
+[ -z "$FAST" ] && timeout 900 python bench.py --steps 3 --warmup 1 --no-probe --no-sub --cpu-batch 16 --cpu-steps 2 --cpu-warmup 1 > $O/bench_cpu_B16.json 2>/dev/null
 # ---- PMC passes LAST, each on its own (never together with other trace domains), each under a short timeout; after the first pass that
 # times out the rest are skipped (round 2 lost 26 GPU-minutes to one hung pass)
 PMC_OK=1
@@ -64,5 +72,5 @@ pmc $O/pmc_seg_sq s GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_W
 pmc $O/pmc_seg_insts i SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES -- $PS
 pmc $O/pmc_seg_insts2 j SQ_INST_CYCLES_VMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA -- $PS
 python tools/pmc_raw.py $O/pmc_seg_sq $O/pmc_seg_insts $O/pmc_seg_insts2 > $O/pmc_segmenter_raw.txt 2>&1; head -30 $O/pmc_segmenter_raw.txt
-rm -rf $O/prof_joint $O/prof_seg $O/prof_bf16     # the sqlite traces are large; the summaries stay
 ls $O
+fi
