@@ -1985,12 +1985,15 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     } else if (lin_any && VECB && wgrad_ring_depth() > 1) {
         // linear pixel walk with DEPTH global-load stages in flight (PNP_WGRAD_DEPTH = 1: conv_wgrad_kernel MODE 3, one stage in flight)
         const int depth = wgrad_ring_depth();
-        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "conv_wgrad_ring_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, depth);
+        static const int env_uni = getenv("PNP_WGRAD_UNI") ? atoi(getenv("PNP_WGRAD_UNI")) : 1;
+        const bool uni = PNP_WGRAD_UNIFORM_ROWS != 0 && BM == 128 && env_uni && depth == 2 && (a.C % BM) == 0;
+        // (the symbol rocprofv3 prints: the scalar-row variant carries 10 + depth as its last template argument)
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), conv_bytes(a), "conv_wgrad_ring_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN,
+                        uni ? 10 + depth : depth);
         if constexpr (VECB) {
             bool done = false;
             if constexpr (PNP_WGRAD_UNIFORM_ROWS != 0 && BM == 128) {          // scalar loader rows where a tile holds one tap
-                static const int env_uni = getenv("PNP_WGRAD_UNI") ? atoi(getenv("PNP_WGRAD_UNI")) : 1;
-                if (env_uni && depth == 2 && (a.C % BM) == 0) {
+                if (uni) {
                     hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 12>), grid, dim3(NTHREADS), 0, st, a);
                     done = true;
                 }

@@ -39,6 +39,8 @@ if [ -z "$SKIP_TESTS" ]; then timeout 1800 python -m pytest tests -m gpu -q -s -
 rm -rf $O/prof_joint $O/prof_seg $O/prof_bf16     # the sqlite traces are large; the summaries stay
 fi
 if [[ $PART == *B* ]]; then
+# (PART B alone starts on a fresh box: the driver's line once more, as the driver itself measures it)
+[[ $PART == *A* ]] || { timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 300 $O/bench_n1.json; }
 # host side of the library under AddressSanitizer (device code uninstrumented): the conv parity tests through libpnp_hip_asan.so
 if [ -f $P/libpnp_hip_asan.so ]; then
   LD_PRELOAD=$(/opt/rocm/bin/hipcc -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 PNP_LIB=$P/libpnp_hip_asan.so \
