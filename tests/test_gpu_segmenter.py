@@ -189,10 +189,12 @@ def test_segmenter_train_step_B16_vs_float32_oracle(dev):
     print("B=16 gradients hip vs cpu-fp32 over %d variables: median %.3e max %.3e, min cosine %.8f (%s)" % (
         len(er), np.median(er), er.max(), min(cs.values()), min(cs, key=cs.get)))
     # fp32 against fp32 through the whole backward chain: both sides carry the slope-flip noise that the B=2 tests measure against
-    # float64, so the pairwise distance is ~sqrt(2) of it and moves with every change of summation order (the same bar as the generator
-    # path of tests/test_gpu_adversarial.py::test_joint_step_B16_vs_float32_oracle, where 0.99988 / 1.1e-2 was measured); the per-kernel
-    # 1e-4 pins at this batch are tests/test_gpu_teacher_forced.py
-    assert min(cs.values()) > 0.9997 and np.median(er) < 2e-2
+    # float64.  The bar follows the MEASUREMENT (profiles/r03_pytest_gpu.log, MI355X round 3): median 4.2e-3, max 3.5e-2 of max|g|, min
+    # cosine 0.999983 — i.e. round 1's original bar (0.9999 / 1e-2) holds at this batch; round 2's last commit had widened it to
+    # 0.9997 / 2e-2 without a run.  The maximum is bounded too: a defect in one B=16-only path (128x128 tiles, 7-way filter-
+    # gradient splits, split data gradients, two-stage BN compaction) would show up in a single variable first.  The per-kernel 1e-4
+    # pins at this batch are tests/test_gpu_teacher_forced.py.
+    assert min(cs.values()) > 0.9999 and np.median(er) < 1e-2 and er.max() < 0.1
     for k, v in V32.items():
         if k.endswith("moving_mean") or k.endswith("moving_variance"):
             assert _rel(after[k], v.detach()) < 1e-4, k
