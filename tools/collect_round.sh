@@ -74,5 +74,8 @@ pmc $O/pmc_seg_sq s GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_W
 pmc $O/pmc_seg_insts i SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES -- $PS
 pmc $O/pmc_seg_insts2 j SQ_INST_CYCLES_VMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA -- $PS
 python tools/pmc_raw.py $O/pmc_seg_sq $O/pmc_seg_insts $O/pmc_seg_insts2 > $O/pmc_segmenter_raw.txt 2>&1; head -30 $O/pmc_segmenter_raw.txt
+# the raw per-dispatch CSVs are tens of MB per pass: gpurun merges at most 64 MiB back (a PART B of round 3 lost everything to that limit)
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_bf16_fetch $O/pmc_bf16_write $O/pmc_bf16_sq $O/pmc_seg_sq $O/pmc_seg_insts $O/pmc_seg_insts2
+du -sh $O
 ls $O
 fi
