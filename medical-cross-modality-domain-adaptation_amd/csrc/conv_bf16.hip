@@ -10,7 +10,9 @@
 //                           unrolled (the layers conv_taps_kernel serves)
 //   conv_wgrad_bf16_kernel  filter gradient, stride 1, zero padding, C % 4 == 0, OW >= 32 (the layers conv_wgrad_kernel<.., 3, ..> serves)
 // Everything else (C in {3,5,16,40}, K <= 16, strided filter gradients, in-kernel SYMMETRIC) stays on the fp32 kernels: those layers
-// are HBM- or launch-bound, not MFMA-bound.
+// are HBM- or launch-bound, not MFMA-bound.  So do the filter gradients of 16 / 32-channel inputs with 32 / 64 filters on maps of >= 8192 pixels
+// (conv_small.hip's 16x16x4 fp32 tiles: 0.064 / 0.113 / 0.053 ms against 0.109 / 0.146 / 0.096 ms on the 128-row bf16 tiles at B = 16).
+// PNP_DTYPE_BF16 in a geometry PERMITS bf16 operands; a layer that stays fp32 is exact, never looser.
 //
 // LDS tiles hold bf16 with the REDUCTION index contiguous for BOTH operands (the 32x32x16 MFMA takes 8 consecutive k per lane from
 // each): rows of 32 k (64 B) + 16 B pad = 80 B, so a ds_read_b128 lane group (16 rows) lands on 16 distinct 16-byte slots

@@ -331,7 +331,10 @@ namespace pnpconv {
 bool n16_geom_ok(const pnp_conv_geom* g) {
     static const int off = getenv("PNP_CONV_NON16") ? 1 : 0;
     if (off || g->K != 16 || (g->C != 16 && g->C != 32 && g->C != 3) || g->R != 3 || g->S != 3 || g->stride != 1 || g->dil != 1) return false;
-    if (g->pad_mode != PNP_PAD_ZERO || g->pad_t > 1 || g->pad_l > 1 || g->dtype != PNP_DTYPE_F32) return false;
+    // dtype: these kernels compute in fp32 whatever the geometry allows — PNP_DTYPE_BF16 PERMITS bf16 operands (conv_bf16.hip's header), and
+    // on 16-channel layers the fp32 16x16x4 tiles are both exact and faster than the 32-wide bf16 tiles (B = 16: 16->16 0.072 vs 0.131 ms)
+    static const int f32only = getenv("PNP_N16_F32ONLY") ? 1 : 0;                                 // A/B: round 2's routing
+    if (g->pad_mode != PNP_PAD_ZERO || g->pad_t > 1 || g->pad_l > 1 || (f32only && g->dtype != PNP_DTYPE_F32)) return false;
     if (g->OH != g->H + 2 * g->pad_t - 2 || g->OW != g->W + 2 * g->pad_l - 2) return false;
     return (long long)g->N * g->OH * g->OW >= 8192 && g->N <= 65535;
 }
@@ -361,7 +364,8 @@ bool n16_wgrad_ok(const pnp_conv_geom* g) {
     static const int off = getenv("PNP_CONV_NON16") ? 1 : 0;
     static const int maxk = getenv("PNP_N16W_MAXK") ? atoi(getenv("PNP_N16W_MAXK")) : 64;       // A/B against the ring kernel's 128x64 tiles
     if (off || g->K > maxk || (g->K != 32 && g->K != 64) || (g->C != 16 && g->C != 32) || g->R != 3 || g->S != 3 || g->stride != 1 || g->dil != 1) return false;
-    if (g->pad_mode != PNP_PAD_ZERO || g->pad_t > 1 || g->pad_l > 1 || g->dtype != PNP_DTYPE_F32) return false;
+    static const int f32only = getenv("PNP_N16_F32ONLY") ? 1 : 0;
+    if (g->pad_mode != PNP_PAD_ZERO || g->pad_t > 1 || g->pad_l > 1 || (f32only && g->dtype != PNP_DTYPE_F32)) return false;
     if (g->OH != g->H + 2 * g->pad_t - 2 || g->OW != g->W + 2 * g->pad_l - 2) return false;
     // 64 filters over >= 2^19 pixels (cls_1's 32 -> 64 at 256^2): the ring kernel's 128x64 tiles win there (measured B = 16: 0.728 ms here,
     // 0.583 ms on conv_wgrad_ring_kernel); on the 64^2 layer of the same shape this kernel wins 0.054 vs 0.106
