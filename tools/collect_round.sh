@@ -1,7 +1,7 @@
 # Regenerates everything under profiles/ for the current round on a GPU box:  bash tools/collect_round.sh   (raw output: gpurun_out/$R/)
 # Every step runs under its own `timeout`; the benchmark lines come FIRST (a box that has just run the 12-minute test suite clocks ~3 % lower),
 # the `rocprofv3 --pmc` passes LAST and guarded: in round 2 one hung pass ate the remaining 26 GPU-minutes of the round.
-# PART=A: smoke, bench lines, kernel traces, per-layer tables, entry-point loops, the whole -m gpu suite.  PART=B: ASAN run, CPU path at
+# PART=A: smoke, bench lines, kernel traces, per-layer tables, entry-point loops, the whole -m gpu suite.  PART=B: UBSan run, CPU path at
 # B=16, PMC passes.  Default: both.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=${R:-r3z}; O=gpurun_out/$R; mkdir -p $O
@@ -41,10 +41,12 @@ fi
 if [[ $PART == *B* ]]; then
 # (PART B alone starts on a fresh box: the driver's line once more, as the driver itself measures it)
 [[ $PART == *A* ]] || { timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 300 $O/bench_n1.json; }
-# host side of the library under AddressSanitizer (device code uninstrumented): the conv parity tests through libpnp_hip_asan.so
-if [ -f $P/libpnp_hip_asan.so ]; then
-  LD_PRELOAD=$(/opt/rocm/bin/hipcc -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 PNP_LIB=$P/libpnp_hip_asan.so \
-    timeout 600 python -m pytest tests/test_abi.py tests/test_gpu_conv.py -q > $O/asan_gpu.log 2>&1; tail -2 $O/asan_gpu.log
+# host side of the library under UBSan + libstdc++ assertions (`make ubsan`; device code uninstrumented).  ASAN cannot run on the GPU box:
+# ROCm's ASAN runtime intercepts hsa_amd_memory_pool_allocate and this image ships no ASAN ROCr (profiles/r03_asan_gpu.log)
+if [ -f $P/libpnp_hip_ubsan.so ]; then
+  PNP_LIB=$P/libpnp_hip_ubsan.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 timeout 900 python -m pytest tests/test_abi.py tests/test_api_errors.py \
+    tests/test_gpu_conv.py tests/test_gpu_elementwise.py tests/test_gpu_loss_optim.py tests/test_gpu_adversarial.py tests/test_gpu_bf16.py -q > $O/ubsan_gpu.log 2>&1
+  echo "rc=$? runtime-error lines: $(grep -c 'runtime error' $O/ubsan_gpu.log)" >> $O/ubsan_gpu.log; tail -3 $O/ubsan_gpu.log
 fi
 # the CPU path at the GPU line's own batch, once (2 steps after 1 warm-up: ~3 min of host time; the default line bounds the sample with B=2)
 [ -z "$FAST" ] && timeout 900 python bench.py --steps 3 --warmup 1 --no-probe --no-sub --cpu-batch 16 --cpu-steps 2 --cpu-warmup 1 > $O/bench_cpu_B16.json 2>/dev/null
