@@ -51,3 +51,20 @@ def test_pmc_summary_shortens_kernel_names_like_the_kernel_tables():
     mod = _load("pmc_summary")
     assert mod.clean("void (anonymous namespace)::conv_taps_kernel<128, 128, 2, 2, 0, 3, 3>(pnpconv::ConvArgs)") == \
         "conv_taps_kernel<128, 128, 2, 2, 0, 3, 3>"
+
+
+def test_shell_tooling_parses_and_sanitizer_targets_exist():
+    """tools/*.sh are only ever executed on a GPU box, minutes into a paid call: a syntax error there costs the call (round 3 lost one
+    collection to a merge limit, not to syntax — keep it that way).  The Makefile's sanitizer targets are named in profiles/README.md."""
+    import glob
+    import subprocess
+    scripts = sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh")) + glob.glob(os.path.join(ROOT, "tools", "experiments", "*.sh")))
+    assert os.path.join(ROOT, "tools", "collect_round.sh") in scripts
+    for s in scripts:
+        r = subprocess.run(["bash", "-n", s], capture_output=True, text=True)
+        assert r.returncode == 0, (s, r.stderr)
+    mk = open(os.path.join(ROOT, "medical-cross-modality-domain-adaptation_amd", "csrc", "Makefile")).read()
+    for target in ("asan:", "ubsan:", "variant:"):
+        assert "\n" + target in mk, target
+    body = open(os.path.join(ROOT, "tools", "collect_round.sh")).read()
+    assert "rm -rf $O/pmc_fetch" in body          # raw PMC CSVs removed before gpurun merges gpurun_out/ back (64 MiB limit)
