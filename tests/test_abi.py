@@ -118,3 +118,20 @@ def test_documents_quote_the_current_abi_size(built):
     for doc in ("README.md", "DESIGN.md", "INTEGRATION.md"):
         text = open(os.path.join(ROOT, doc)).read()
         assert ("%d entry points" % n in text) or ("%d `extern \"C\"` entry points" % n in text) or ("all %d symbols" % n in text), doc
+
+
+def test_every_environment_switch_is_documented():
+    """INTEGRATION.md §E lists every PNP_* variable the library (getenv) and the Python host side (os.environ) read — an experiment switch
+    that silently changes which kernel runs must not exist only in the source."""
+    import glob
+    pk = os.path.join(ROOT, "medical-cross-modality-domain-adaptation_amd")
+    names = set()
+    for f in glob.glob(os.path.join(pk, "csrc", "*.hip")) + glob.glob(os.path.join(pk, "csrc", "*.h")):
+        names |= set(re.findall(r'getenv\("(PNP_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in glob.glob(os.path.join(pk, "*.py")):
+        names |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(PNP_[A-Z0-9_]+)"', open(f).read()))
+    assert len(names) > 25, names
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = doc[doc.index("## E. Environment switches"):]
+    missing = sorted(n for n in names if "`%s`" % n not in section)
+    assert not missing, missing
