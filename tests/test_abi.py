@@ -110,6 +110,13 @@ def test_host_planners_through_the_workspace_queries(built):
     # (the direct vector-ALU filter gradient keeps the other K <= 16 layers: one partial per workgroup, 2048 slabs — `logits` below)
     logits = K.conv_geom((16, 260, 260, 40), (5, 5, 40, 5), 1, 1, "VALID")
     assert wgr(logits) == 2048 * 5 * 5 * 40 * 5 * 4
+    # PNP_DTYPE_BF16 permits bf16 operands; the 16-channel layers keep conv_small.hip's fp32 plan (round 3, run 14), wide layers do not
+    L = built._lib
+    g1b = K.conv_geom((16, 256, 256, 16), (3, 3, 16, 16), 1, 1, "SAME", dtype=L.DTYPE_BF16)
+    assert wgr(g1b) == wgr(g1)
+    g2b = K.conv_geom((16, 128, 128, 32), (3, 3, 32, 32), 1, 1, "SAME", dtype=L.DTYPE_BF16)
+    g2f = geo(16, 128, 32, 32, 3)
+    assert wgr(g2b) == wgr(g2f) and wgr(g2f) % (3 * 3 * 32 * 32 * 4) == 0
     assert lib.pnp_conv2d_dgrad_workspace_bytes(None) == 0 and lib.pnp_conv2d_fwd_workspace_bytes(None) == 0
 
 
