@@ -62,7 +62,11 @@ def main(phase, argv=None):
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--sync-stats", action="store_true", help="data parallel only: all-reduce BN statistics and loss normalisers "
                     "(exactly the single-GPU step on the concatenated batch; ~2 tiny collectives per BN layer per pass)")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="arithmetic of the convolution operands: f32 = the reference's "
+                    "(default); bf16 = BASELINE configs[4]: bf16 MFMA operands, fp32 accumulation / master weights / BN")
     args = ap.parse_args(argv)
+    from .functional import set_conv_dtype
+    set_conv_dtype(args.dtype)
     ck, nc, tc = configure(args.phase)
     num_cls, batch_size = 5, args.batch_size
     output_path = args.output

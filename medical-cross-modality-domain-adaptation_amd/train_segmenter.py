@@ -26,7 +26,11 @@ def main(argv=None):
     ap.add_argument("--sync-stats", action="store_true", help="data parallel only: all-reduce BN statistics and loss normalisers "
                     "(exactly the single-GPU step on the concatenated batch; ~2 tiny collectives per BN layer per pass)")
     ap.add_argument("--restore", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="arithmetic of the convolution operands: f32 = the reference's "
+                    "(default); bf16 = BASELINE configs[4]: bf16 MFMA operands, fp32 accumulation / master weights / BN")
     args = ap.parse_args(argv)
+    from .functional import set_conv_dtype
+    set_conv_dtype(args.dtype)
 
     train_fid, val_fid = "./lists/mr_train_list", "./lists/mr_val_list"
     output_path = args.output

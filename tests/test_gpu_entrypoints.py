@@ -41,3 +41,25 @@ def test_three_phase_chain(dev, tmp_path):
     moved = t3.net.store.state_dict()
     assert not np.array_equal(moved["adapt_1/Variable"], st["adapt_1/Variable"])   # the adaptation module trains in this phase
     assert np.array_equal(moved["group_7/Variable"], st["group_7/Variable"])       # the shared segmenter half never does
+
+
+def test_entry_point_dtype_flag_selects_the_bf16_kernels(dev, tmp_path):
+    """--dtype bf16 (BASELINE configs[4]) at the entry point: the convolution launches of the training loop are observed on the bf16
+    symbols (pnp_prof_*), the run is finite, and a later run without the flag is back on the fp32 kernels (the flag is per main())."""
+    ts, L, K = pkg("train_segmenter"), pkg("_lib"), pkg("kernels")
+    L.prof_summary()
+    L.prof_enable(L.PROF_CONV_FWD)
+    try:
+        tr = ts.main(["--synthetic", "4", "--batch-size", "2", "--iters", "2", "--epochs", "1", "--output", str(tmp_path / "b"), "--dtype", "bf16"])
+        torch.cuda.synchronize()
+        names = [r["name"] for r in L.prof_summary()]
+        assert K.CONV_DTYPE == L.DTYPE_BF16
+        assert any("bf16" in n for n in names), sorted(set(names))[:8]
+        assert np.isfinite(tr.loss_dict["train"][1])
+        ts.main(["--synthetic", "4", "--batch-size", "2", "--iters", "1", "--epochs", "1", "--output", str(tmp_path / "f")])
+        torch.cuda.synchronize()
+        names = [r["name"] for r in L.prof_summary()]
+        assert K.CONV_DTYPE == L.DTYPE_F32 and names and not any("bf16" in n for n in names), sorted(set(names))[:8]
+    finally:
+        L.prof_enable(0)
+        pkg("functional").set_conv_dtype("f32")
