@@ -8,12 +8,16 @@ Headline workload (default, BASELINE.json configs[3]): the JOINT step of `train_
 update on B MR + B CT slices (both critics, RMSProp, weight clip; adversarial.py:839-862) followed by one generator update on the
 B CT slices (adversarial.py:866-882) — B=16 slices of each domain per GPU, fp32, dropout keep 0.75, synthetic N(0,1) slices already
 resident in HBM; B slices are counted per step.  Weak scaling: every rank processes its own 16+16 slices, gradients are
-all-reduced (RCCL).  Rank 0 prints ONE JSON line carrying
+all-reduced (RCCL).  Rank 0 prints, as the LAST line of stdout, ONE compact JSON record (< 2 KB: the driver parses the tail of
+stdout; round 3's 20 KB line arrived unparsed) carrying
   * `roofline`          the kernel symbol with the largest share of the timed region's convolution time, timed live with HIP
                         events recorded by libpnp_hip.so around each of its launches (pnp_prof_*), against the fp32-MFMA peak;
-  * `roofline_kernels`  the same for every MFMA convolution symbol of the step (forward, data gradient, filter gradient);
+  * `roofline_all_mfma_convs`  the aggregate over every MFMA convolution symbol of the step;
   * `segmenter_step`    BASELINE configs[1] (source segmenter fwd + bwd + Adam, source_segmenter.py:484-489) timed the same way;
-  * `cpu_baseline`      the CPU oracle's joint step (oracle/nets_adv.py, torch-CPU fp32) on this host's cores, bounded sample.
+  * `cpu_baseline`      the CPU oracle's joint step (oracle/nets_adv.py, torch-CPU fp32) on this host's cores AT THE GPU LINE'S BATCH
+                        (B = 16: 1 warm-up + 3 timed steps), with the B = 2 figure as a second field.
+The per-symbol table (`roofline_kernels`: forward, data gradient, filter gradient of every convolution symbol) goes to a side file,
+`bench_kernels_<workload>_<dtype>.json` under gpurun_out/ (on a GPU box) or profiles/, and its path is named in the record.
 `--workload segmenter` makes configs[1] the headline line instead (same contract); `--dtype bf16` runs configs[4]'s arithmetic (a
 separate line, never the headline).  The joint workload starts from BN moving statistics calibrated on the synthetic batches (40
 untimed training-mode forwards) — the phase itself starts from a trained baseline checkpoint; with un-calibrated statistics the
@@ -98,12 +102,11 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(workload, Bc=2, timed_steps=5, warm=2):
-    """The CPU oracle (a port: TF-1.4 cannot run here) on this host's cores, same step definition as the GPU line, timed as SURVEY.md
-    §8(d) prescribes — `warm` = 2 warm-up steps, median of `timed_steps` = 5 timed steps.  The default run BOUNDS the sample through the
-    batch: Bc = 2 slices per domain instead of 16 (the smallest batch the reference's PS accepts, ops.py:7), ~2 minutes of host time;
-    seven B = 16 steps would take ~6.  `--cpu-batch 16` runs the CPU path at the GPU line's own batch (the CPU path is more efficient
-    per slice there: oneDNN GEMMs are larger; DESIGN.md §5 quotes that measurement next to this one)."""
+def cpu_baseline(workload, Bc=16, timed_steps=3, warm=1):
+    """The CPU oracle (a port: TF-1.4 cannot run here) on this host's cores, same step definition as the GPU line (SURVEY.md §8(d):
+    "same synthetic batch, same step definition"): Bc slices per domain, `warm` warm-up + `timed_steps` timed steps, median.  The default
+    is the GPU line's own batch, B = 16, 1 + 3 steps (~4.5 min of host time for the joint step); main() adds a B = 2 sample as a second
+    field (the smallest batch the reference's PS accepts, ops.py:7)."""
     # torch's default intra-op thread count honours the cgroup / affinity mask of the box (os.cpu_count() does not:
     # forcing 256 threads onto a restricted mask made this sample 50x slower)
     ncores = torch.get_num_threads()
@@ -127,7 +130,7 @@ def cpu_baseline(workload, Bc=2, timed_steps=5, warm=2):
             t0 = time.time()
             nets.segmenter_train_step(V, opt, x, y, 0.75, seed=1 + i, lr=1e-3, t=1 + i)
             times.append(time.time() - t0)
-        what = "oracle.nets.segmenter_train_step (torch-CPU fp32 restatement of source_segmenter.py:484-489)"
+        what = "oracle.nets.segmenter_train_step (torch-CPU fp32 port of source_segmenter.py:484-489)"
     else:
         from oracle import nets_adv
         adv = importlib.import_module(PKG + ".adversarial")
@@ -143,11 +146,73 @@ def cpu_baseline(workload, Bc=2, timed_steps=5, warm=2):
             t0 = time.time()
             nets_adv.joint_train_step(V, ms_d, ms_g, mr, ct, 0.75, seed=1 + 2 * i)
             times.append(time.time() - t0)
-        what = "oracle.nets_adv.joint_train_step (torch-CPU fp32 restatement of adversarial.py:839-882: 1 dis update + clip + 1 gen update)"
+        what = "oracle.nets_adv.joint_train_step (torch-CPU fp32 port of adversarial.py:839-882)"
     med = float(np.median(times[warm:]))
-    return {"value": Bc / med, "unit": "slices/s", "cores": ncores, "cpu_model": cpu_model(), "kind": "port",
-            "sample": "%s, B=%d per domain (the GPU line runs B=16; default B=2 bounds the sample, DESIGN.md §5), %d warm-up + %d timed steps, "
-                      "median %.2f s/step (all: %s)" % (what, Bc, warm, timed_steps, med, ", ".join("%.2f" % t for t in times))}
+    return {"value": Bc / med, "unit": "slices/s", "cores": ncores, "cpu_model": cpu_model(), "kind": "port", "batch": Bc,
+            "s_per_step": med,
+            "sample": "%s, B=%d per domain, %d warm-up + %d timed steps, median %.2f s/step (all: %s)"
+                      % (what, Bc, warm, timed_steps, med, " ".join("%.1f" % t for t in times))}
+
+
+def _r(v, nd=4):
+    """numbers of the printed record at `nd` significant digits (the full-precision values are in the side file)"""
+    if isinstance(v, float):
+        return float("%.*g" % (nd, v)) if np.isfinite(v) else None
+    if isinstance(v, dict):
+        return {k: _r(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, nd) for x in v]
+    return v
+
+
+MAX_LINE = 1700      # the driver keeps a ~2000-character tail of stdout and parses the last line out of it
+
+
+def compact_record(res):
+    """The ONE line the driver parses: every contract field + `roofline` (dominant kernel) + `roofline_all_mfma_convs` + the secondary
+    workload + `cpu_baseline`, in < MAX_LINE characters whatever the number of kernel symbols (the per-symbol table lives in the side
+    file named by `kernels_file`).  Fields are dropped from the least important end if a record would still be too long."""
+    out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                               "vs_baseline", "dtype", "data") if k in res}
+    cfg = dict(res.get("config", {}))
+    comm = cfg.get("comm")
+    if comm:       # N > 1: what was all-reduced and how much of it the step waited for (launch orders / bucket sizes: side file)
+        c = {k: comm.get(k) for k in ("transport", "rccl_version", "overlap", "buckets", "allreduce_MB_per_step") if k in comm}
+        for ph in ("dis_step", "gen_step"):
+            if ph in comm:
+                c[ph + "_exposed_ms"] = comm[ph].get("exposed_ms")
+        if "exposed_ms" in comm:
+            c["exposed_ms"] = comm["exposed_ms"]
+        cfg["comm"] = c
+    out["config"] = cfg
+    if "roofline" in res:
+        r = res["roofline"]
+        out["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                 "launches", "avg_launch_ms", "share_of_conv_time", "algorithmic_gflop_per_launch",
+                                                 "algorithmic_mbytes_per_launch")}
+    for k in ("roofline_all_mfma_convs", "segmenter_step", "joint_step"):
+        if k in res:
+            out[k] = {a: b for a, b in res[k].items() if a not in ("workload", "unit", "steps", "warmup")}
+    if "cpu_baseline" in res:
+        out["cpu_baseline"] = {k: v for k, v in res["cpu_baseline"].items() if not k.startswith("sample_B")}
+    if "kernels_file" in res:
+        out["kernels_file"] = res["kernels_file"]
+    out = _r(out)
+    for drop in (("cpu_baseline", "cpu_model"), ("roofline", "algorithmic_mbytes_per_launch"), ("roofline", "traffic_source"), ("config", "comm"),
+                 ("kernels_file",), ("cpu_baseline", "sample")):
+        if len(json.dumps(out)) < MAX_LINE:
+            break
+        d = out
+        for k in drop[:-1]:
+            d = d.get(k, {})
+        d.pop(drop[-1], None)
+    return out
+
+
+def side_file_path(workload, dtype, world):
+    """where the per-symbol table goes: gpurun_out/ when it exists (merged back from a GPU box), else profiles/"""
+    d = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.path.join(ROOT, "profiles")
+    return os.path.join(d, "bench_kernels_%s_%s%s.json" % (workload, dtype, "" if world == 1 else "_n%d" % world))
 
 
 PROBE_STEPS = 2      # timed steps whose convolution launches carry HIP events (see timed_loop)
@@ -210,15 +275,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="slices per GPU (of each domain for the joint step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2, help="slices per domain of the cpu_baseline sample (default 2: bounded sample)")
-    ap.add_argument("--cpu-steps", type=int, default=5)
-    ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=16, help="slices per domain of the cpu_baseline sample (default: the GPU line's B = 16)")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-warmup", type=int, default=1)
+    ap.add_argument("--cpu-small-batch", type=int, default=2, help="second, small cpu_baseline sample (0: none)")
     ap.add_argument("--no-probe", action="store_true", help="no per-kernel HIP events (no roofline objects)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="skip the secondary workload's sub-record")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: BASELINE configs[4] arithmetic (bf16 MFMA conv operands, fp32 accumulation / master weights / BN); a separate "
                          "line, never the headline")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --batch slices PER GPU, the job grows with N; strong: --batch is the GLOBAL batch, every rank "
+                         "takes batch / N slices (the reference's B = 16 spread over the node)")
     ap.add_argument("--workload", choices=["joint", "gan", "segmenter"], default="joint",
                     help="joint (= gan): BASELINE configs[3], the headline; segmenter: configs[1]")
     args = ap.parse_args()
@@ -239,6 +308,9 @@ def main():
     if args.dtype == "bf16":
         importlib.import_module(PKG + ".functional").set_conv_dtype("bf16")
     B = args.batch
+    if args.scaling == "strong":
+        assert args.batch % world == 0 and args.batch // world >= 2, "--scaling strong: --batch must split into >= 2 slices per rank (PS, ops.py:7)"
+        B = args.batch // world
     rng = np.random.default_rng(100 + rank)
     x = torch.from_numpy(rng.standard_normal((B, 256, 256, 3)).astype(np.float32)).to(dev)
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
@@ -283,9 +355,9 @@ def main():
         return step
 
     names = {
-        "joint": ("training slices/sec (256x256x3, B=16 per GPU) joint segmenter+GAN step (1 dis update on B MR + B CT, clip, 1 gen update on B CT)",
-                  "BASELINE configs[3]: train_gan.py --phase train-gan joint step, B=%d/GPU of each domain, %s, dropout .75, mask critic on" % (B, args.dtype)),
-        "segmenter": ("training slices/sec (256x256x3, B=16 per GPU) segmenter train step (fwd+bwd+Adam)",
+        "joint": ("training slices/sec (256x256x3, B=16/GPU) joint segmenter+GAN step (1 dis update on B MR + B CT, clip, 1 gen update on B CT)",
+                  "BASELINE configs[3]: train_gan.py --phase train-gan joint step, B=%d/GPU per domain, %s, dropout .75, mask critic on" % (B, args.dtype)),
+        "segmenter": ("training slices/sec (256x256x3, B=16/GPU) segmenter train step (fwd+bwd+Adam)",
                       "BASELINE configs[1]: source segmenter fwd+bwd+Adam, B=%d/GPU, 256x256x3, %s, dropout .75, BN train" % (B, args.dtype)),
     }
     makers = {"joint": make_joint, "segmenter": make_segmenter}
@@ -332,20 +404,22 @@ def main():
         res = {
             "metric": names[args.workload][0],
             "value": world * B * args.steps / el, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": names[args.workload][1], "global_batch": B * world, "parallelism": "dp%d" % world,
+            # (N = 1: no GradReducer is built — the driver's SCALE N=1 run and its BENCH run execute the same code path)
+            "config": {"workload": names[args.workload][1], "global_batch": B * world, "per_gpu_batch": B, "parallelism": "dp%d" % world,
                        "final_loss": lossv, "comm": comm},
         }
         if rows:
             recs = roofline_records(rows, peak)
             if recs:
                 top = dict(recs[0])
-                top["note"] = ("the kernel symbol with the largest share of the timed region's convolution time; `achieved` = sum of "
-                               "algorithmic FLOP (2*N*OH*OW*R*S*C*K) / sum of launch durations, HIP events recorded by libpnp_hip.so on the "
-                               "launch stream around every launch of this symbol in the first %d steps of the timed region; `traffic`" % PROBE_STEPS + " = HBM-side bytes per "
-                               "launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, separate passes), null if absent")
                 res["roofline"] = top
+                res["roofline_note"] = ("roofline = the kernel symbol with the largest share of the timed region's convolution time; `achieved` = sum of "
+                                        "algorithmic FLOP (2*N*OH*OW*R*S*C*K) / sum of launch durations, HIP events recorded by libpnp_hip.so on the "
+                                        "launch stream around every launch of the symbol in the first %d steps of the timed region; `traffic` = HBM-side "
+                                        "bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, separate passes; "
+                                        "`traffic_source` names the file), null if absent" % PROBE_STEPS)
                 res["roofline_kernels"] = recs
                 fl, ms = sum(r["flops"] for r in rows), sum(r["ms"] for r in rows)
                 res["roofline_all_mfma_convs"] = {"achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "frac": fl / (ms * 1e-3) / 1e12 / peak,
@@ -355,8 +429,26 @@ def main():
         if sub is not None:
             res["segmenter_step" if other == "segmenter" else "joint_step"] = sub
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps, args.cpu_warmup)
-        print(json.dumps(res))
+            cb = cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps, args.cpu_warmup)
+            if args.cpu_small_batch and args.cpu_small_batch != args.cpu_batch:
+                small = cpu_baseline(args.workload, args.cpu_small_batch, 2, 1)
+                cb["value_B%d" % args.cpu_small_batch] = small["value"]
+                cb["sample_B%d" % args.cpu_small_batch] = small["sample"]
+            res["cpu_baseline"] = cb
+        # the per-symbol table and the full-precision record: side file (and stderr); the LAST stdout line is the compact record
+        try:
+            path = side_file_path(args.workload, args.dtype, world)
+            with open(path, "w") as f:
+                json.dump(res, f, indent=1)
+            res["kernels_file"] = os.path.relpath(path, ROOT)
+        except OSError:
+            pass
+        sys.stderr.write(json.dumps(res) + "\n")
+        sys.stderr.flush()
+        line = json.dumps(compact_record(res))
+        assert len(line) < MAX_LINE and "\n" not in line, len(line)
+        sys.stdout.flush()
+        print(line, flush=True)
     if world > 1:
         par.shutdown()
 

@@ -75,9 +75,14 @@ def test_bench_two_rank_gan_workload(dev):
     p = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--workload", "gan"],
              {"PNP_DIST_BACKEND": "gloo", "PNP_SAME_DEVICE": "1"})
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    last = p.stdout.rstrip("\n").splitlines()[-1]              # the driver parses the LAST stdout line (out of a ~2000-character tail)
+    assert len(last) < 1700, len(last)
+    r = json.loads(last)
     assert r["n_gpus"] == 2 and "joint" in r["metric"] and r["value"] > 0 and "cpu_baseline" not in r
-    assert r["segmenter_step"]["value"] > 0 and r["roofline"]["launches"] > 0 and len(r["roofline_kernels"]) >= 3
+    assert r["segmenter_step"]["value"] > 0 and r["roofline"]["launches"] > 0 and "roofline_kernels" not in r
+    assert r["config"]["comm"]["buckets"] >= 1 and r["config"]["per_gpu_batch"] == 2
+    full = json.load(open(os.path.join(ROOT, r["kernels_file"])))             # the per-symbol table: side file
+    assert len(full["roofline_kernels"]) >= 3 and full["config"]["comm"]["dis_step"]["launch_order"] is not None
 
 
 def test_train_segmenter_two_ranks(dev, tmp_path):

@@ -68,3 +68,52 @@ def test_shell_tooling_parses_and_sanitizer_targets_exist():
         assert "\n" + target in mk, target
     body = open(os.path.join(ROOT, "tools", "collect_round.sh")).read()
     assert "rm -rf $O/pmc_fetch" in body          # raw PMC CSVs removed before gpurun merges gpurun_out/ back (64 MiB limit)
+
+
+def test_bench_last_line_is_compact_whatever_the_kernel_count():
+    """BENCH_r03.json arrived `parsed: null`: bench.py printed one ~20 KB line (a 42-entry per-symbol table) and the driver keeps only a
+    tail of stdout.  The record the driver parses is now built by bench.compact_record: < 2000 characters for ANY number of kernel
+    symbols, round-trips through json, and carries every contract field plus roofline / cpu_baseline."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rows = [{"name": "conv_taps_kernel<128, %d, 2, 2, %d, 3, 3>" % (32 + i, i % 2), "ms": 30.0 / (1 + i), "launches": 10 + i,
+             "flops": 8.64e10 * (10 + i) / (1 + i), "bytes": 1.08e8 * (10 + i)} for i in range(60)]
+    recs = bench.roofline_records(rows, bench.PEAK_FP32_MFMA_TFLOPS)
+    assert len(recs) == 60
+    long_sample = "oracle.nets_adv.joint_train_step (torch-CPU fp32 port of adversarial.py:839-882: 1 dis + clip + 1 gen), B=16 per domain, " \
+                  "1 warm-up + 3 timed steps, median 65.61 s/step (all: 70.12, 65.61, 65.40, 66.02)"
+    res = {"metric": "training slices/sec (256x256x3, B=16 per GPU) joint segmenter+GAN step (1 dis update on B MR + B CT, clip, 1 gen update on B CT)",
+           "value": 166.66666666, "unit": "slices/s", "n_gpus": 8, "steps": 20, "warmup": 5, "ms_per_step": 95.98765432, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[3]: train_gan.py --phase train-gan joint step, B=16/GPU of each domain, f32, dropout .75, mask critic on",
+                      "global_batch": 128, "per_gpu_batch": 16, "parallelism": "dp8", "final_loss": 0.123456789,
+                      "comm": {"transport": "native-rccl", "rccl_version": 22105, "overlap": True, "buckets": 12,
+                               "bucket_MB": [33.5] * 12, "distinct_bucket_sets": 2, "allreduce_MB_per_step": 315.0,
+                               "dis_step": {"allreduce_MB": 150.0, "launch_order": list(range(12)), "exposed_ms": 0.41},
+                               "gen_step": {"allreduce_MB": 165.0, "launch_order": list(range(12)), "exposed_ms": 0.39}}},
+           "roofline": dict(recs[0]), "roofline_note": "x" * 700, "roofline_kernels": recs,
+           "roofline_all_mfma_convs": {"achieved": 128.6, "peak": 157.3, "frac": 0.8175, "unit": "TFLOP/s", "ms_per_step": 81.2,
+                                       "launches_per_step": 560.0, "probed_steps": 2},
+           "segmenter_step": {"workload": "BASELINE configs[1]: ...", "value": 463.0, "unit": "slices/s", "ms_per_step": 34.5, "steps": 10,
+                              "warmup": 2, "final_loss": 1.5},
+           "cpu_baseline": {"value": 0.2441, "unit": "slices/s", "cores": 128, "cpu_model": "AMD EPYC 9575F 64-Core Processor", "kind": "port",
+                            "batch": 16, "s_per_step": 65.61, "sample": long_sample, "value_B2": 0.1266, "sample_B2": long_sample},
+           "kernels_file": "gpurun_out/bench_kernels_joint_f32_n8.json"}
+    assert len(json.dumps(res)) > 20000                      # what round 3 printed
+    rec = bench.compact_record(res)
+    line = json.dumps(rec)
+    assert len(line) < bench.MAX_LINE <= 1700 and "\n" not in line, len(line)
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["config"]["workload"].startswith("BASELINE configs[3]") and "roofline_kernels" not in back
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
+        assert k in back["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"], k
+    assert "B=16" in back["cpu_baseline"]["sample"] and back["cpu_baseline"]["value_B2"] == 0.1266 and "sample_B2" not in back["cpu_baseline"]
+    assert abs(back["value"] - 166.7) < 0.05 and back["roofline"]["frac"] == float("%.4g" % recs[0]["frac"])
+    assert back["config"]["comm"]["dis_step_exposed_ms"] == 0.41 and "launch_order" not in json.dumps(back)
