@@ -282,6 +282,36 @@ int pnp_wgan_loss(const float* ct_cls, const float* mr_cls, const float* ct_mask
 /* p[0..n) = value  (constant gradient of a mean: coef / B) */
 int pnp_fill(float* p, size_t n, float value, void* stream);
 
+/* ---- bf16-RESIDENT convolutions (BASELINE.json configs[4]: bf16 mixed precision; csrc/conv_bf16r.hip) ------------------------------
+ * The same convolutions as pnp_conv2d_fwd / _dgrad (layers.py:18,24,67,73,86,92) with BOTH MFMA operands stored as bfloat16 in HBM:
+ *   xh / dyh : bf16 copy [N,H,W,C] of an activation / upstream gradient, written by the kernel that produced the tensor (the `yh` /
+ *              `dxh` outputs below, pnp_bn_apply_h, pnp_bn_bwd_apply_h) or by pnp_cast_bf16,
+ *   w_oi     : bf16 shadow [R*S][K][C] of the fp32 master filter [R,S,C,K]  (forward: reduction index C contiguous),
+ *   w_io     : bf16 shadow [R*S][C][K]                                      (data gradient: reduction index K contiguous; the kernel
+ *              walks the taps in reverse — no flip / transpose launch),
+ * both from pnp_filter_bf16 (either pointer nullable).  fp32 accumulation; y / dx are float32 as everywhere else, `yh` / `dxh`
+ * (nullable) receive the same values rounded to bf16 (nearest-even) from the same epilogue.  Arithmetic: exactly "both operands of
+ * every product rounded to bf16, products summed in fp32" — what PNP_DTYPE_BF16 means for the staged-rounding kernels too.
+ * pnp_conv2d_bf16r_served(g, kind) (kind 0 forward, 1 data gradient): 1 when these kernels serve the geometry (zero padding, 3x3 /
+ * forward 5x5, reduction channels % 32 == 0, output channels % 64 == 0, >= 4096 output pixels, stride-1 data gradients); everything
+ * else stays on the fp32-storage entry points above. */
+int pnp_cast_bf16(const float* x, void* y_bf16, size_t n, void* stream);
+int pnp_filter_bf16(const float* w, void* w_io /*nullable*/, void* w_oi /*nullable*/, int32_t R, int32_t S, int32_t C, int32_t K,
+                    void* stream);
+int32_t pnp_conv2d_bf16r_served(const pnp_conv_geom* g, int32_t kind);
+/* number of BN-statistics partial rows the resident forward leaves (its own tiles: not pnp_conv2d_fwd_stats_parts) */
+int32_t pnp_conv2d_fwd_bf16r_stats_parts(const pnp_conv_geom* g);
+/* forward + dropout, optionally (stat_parts != NULL) the BN statistics partials of pnp_conv2d_fwd_stats, optionally (scale != NULL) the
+ * fused inference-mode BN + shortcut + leaky-ReLU of pnp_conv2d_fwd_bn */
+int pnp_conv2d_fwd_bf16r(const void* xh, const void* w_oi, float* y, void* yh /*nullable*/, const pnp_conv_geom* g,
+                         float keep_prob, uint64_t seed, uint32_t stream_id,
+                         const float* stat_shift /*nullable*/, float* stat_parts /*nullable*/, size_t stat_parts_bytes,
+                         const float* scale /*nullable*/, const float* shift, const float* shortcut /*nullable*/, int32_t Cs, float alpha,
+                         void* stream);
+/* dx = data gradient (+ residual, nullable, as pnp_conv2d_dgrad_add) */
+int pnp_conv2d_dgrad_bf16r(const void* dyh, const void* w_io, const float* residual /*nullable*/, float* dx, void* dxh /*nullable*/,
+                           const pnp_conv_geom* g, void* stream);
+
 /* Data-parallel exchange step (new with respect to the single-GPU reference, train_segmenter.py:20 / train_gan.py:18): in-place
  * SUM all-reduce over RCCL (xGMI), one communicator per process / GPU.  librccl.so is resolved at run time: pnp_comm_load(path)
  * names the copy to bind (NULL: the one already mapped in this process, else the default search path); the other calls load it

@@ -22,7 +22,7 @@ PAD_SYMMETRIC = 1
 OPT_CHUNK = 1024
 DTYPE_F32, DTYPE_BF16, DTYPE_F64 = 0, 1, 2
 COMM_ID_BYTES = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvGeom(ctypes.Structure):
@@ -113,6 +113,13 @@ PROTOTYPES = {
     "pnp_confusion_matrix": (c_int, [_F, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "pnp_bn_moments": (c_int, [_F, _F, c_void_p, c_int32, c_void_p]),
     "pnp_bn_from_moments": (c_int, [c_void_p, c_int32, _F, _F, c_int32, c_void_p]),
+    "pnp_cast_bf16": (c_int, [_F, c_void_p, c_size_t, c_void_p]),
+    "pnp_filter_bf16": (c_int, [_F, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "pnp_conv2d_bf16r_served": (c_int32, [_G, c_int32]),
+    "pnp_conv2d_fwd_bf16r_stats_parts": (c_int32, [_G]),
+    "pnp_conv2d_fwd_bf16r": (c_int, [c_void_p, c_void_p, _F, c_void_p, _G, c_float, c_uint64, c_uint32, _F, _F, c_size_t, _F, _F, _F, c_int32,
+                                     c_float, c_void_p]),
+    "pnp_conv2d_dgrad_bf16r": (c_int, [c_void_p, c_void_p, _F, _F, c_void_p, _G, c_void_p]),
     "pnp_comm_load": (c_int, [c_char_p]),
     "pnp_comm_version": (c_int, [POINTER(c_int)]),
     "pnp_comm_unique_id": (c_int, [c_void_p]),

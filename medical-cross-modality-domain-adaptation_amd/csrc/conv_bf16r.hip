@@ -1,0 +1,407 @@
+// conv_bf16r.hip — bf16-RESIDENT MFMA convolutions (BASELINE.json configs[4]; round 4).
+//
+// conv_bf16.hip (round 2/3) rounds fp32 tensors to bf16 WHILE a tile is staged: every operand crosses HBM -> L2 -> L1 -> VGPR as fp32, is
+// packed by the vector ALU and written to LDS by ds_write — measured 0.17 of the bf16 matrix peak, with exactly the fp32 kernel's bytes
+// (profiles/r03_bf16_pmc_counters.json).  Here the operands ARE bf16 in HBM:
+//   * activations / upstream gradients: a bf16 copy [N][H][W][C] written by the PRODUCING kernel (the conv / BN epilogues; pnp_cast_bf16
+//     where a producer has no such output yet),
+//   * filters: two bf16 shadows of the fp32 master filter [R][S][C][K] (pnp_filter_bf16): `w_oi` = [tap][K][C] (reduction index C
+//     contiguous: forward) and `w_io` = [tap][C][K] (reduction index K contiguous: data gradient, taps walked in reverse — no
+//     flip/transpose launch),
+// so that BOTH MFMA operands of a stage are rows of BKC contiguous reduction elements and go global -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no VGPR staging, no v_cvt, no ds_write).  The DMA writes lane-linear (wave-uniform base + 16 B x lane), so
+// the LDS image is [row][BKC] with rows of 128 B (BKC = 64) or 64 B (BKC = 32); the bank swizzle (16-byte chunk c of row r lives at
+// chunk c ^ swz(r)) is applied on the SOURCE side (the lane that fills LDS chunk c' fetches global chunk c' ^ swz(r): the same cache
+// line) and again on the fragment reads: every ds_read_b128 lane group of 16 then covers 16 distinct 16-byte slots of the 256-byte bank
+// row.  Out-of-range rows (TF zero padding, ragged tile edges) carry a voffset past the buffer: the hardware returns zeros, also into LDS.
+//   tiles: 256 x 128 / 8 waves (64 x 64 per wave), 128 x 128 and 128 x 64 / 4 waves; NBUF LDS stages, ONE raw s_barrier per stage,
+//   loads of stage j + NBUF - 1 in flight under the MFMAs of stage j (counted s_waitcnt vmcnt, never a drain inside the loop).
+// fp32 accumulation, fp32 output (+ optional bf16 copy of the output from the same epilogue: the next convolution's operand).
+#include "conv_common.h"
+
+using namespace pnpconv;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// one LDS-DMA piece: 16 bytes per lane, global (buffer descriptor + per-lane voffset + scalar soffset) -> LDS (wave-uniform dst + 16 x lane).
+// The builtin only exists in the device pass (in the host pass clang silently drops the whole kernel's launch stub over it).
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_void* dst, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+#endif
+}
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// 16-byte chunk swizzle of an LDS row (see the file header)
+template <int BKC>
+__device__ __forceinline__ int swz(int row) {
+    return BKC == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+
+template <int BM, int BN, int WM, int WN, int BKC, int KIND, int R, int S, int NBUF>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (NBUF * (BM + BN) * BKC * 2 <= 80 * 1024 ? 2 : 1)))
+    conv_bf16r_kernel(ConvArgs a) {
+    constexpr int NTAP = R * S;
+    static_assert(NTAP <= 32, "one validity bit per tap");
+    static_assert(BKC == 64 || BKC == 32, "rows of 128 or 64 bytes");
+    constexpr int NW = WM * WN;
+    constexpr int ROWB = BKC * 2;              // bytes per LDS row
+    constexpr int LPR = ROWB / 16;             // lanes per row
+    constexpr int RPI = 64 / LPR;              // rows per wave-instruction (1 KiB)
+    constexpr int RPP = NW * RPI;              // rows per pass of the whole workgroup
+    constexpr int NRA = BM / RPP, NRB = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must split into whole passes");
+    constexpr int LPS = NRA + NRB;             // LDS-DMA instructions per wave per stage
+    constexpr int KS = BKC / 16;               // 16-deep MFMA slices per stage
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int STG = (BM + BN) * ROWB;      // bytes per LDS stage
+    static_assert(NBUF >= 2 && (NBUF - 2) * LPS < 64, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(256))) unsigned char lds[NBUF * STG];      // ONE shared object (a second one de-pipelines the DMA)
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nblk = a.nblk_m * a.nblk_n;
+    int bid = blockIdx.x;
+    if (a.xcd_swizzle) bid = xcd_remap(bid, nblk);
+    int mt, nt;
+    tile_coords(bid, a.nblk_m, a.nblk_n, a.gn, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+    // ---- loader rows: A = output pixels (byte offset of the pixel shifted by -pad, one validity bit per tap), B = filters
+    const int lrow = lane / LPR, lchk = lane % LPR;
+    int abase[NRA];
+    unsigned amask[NRA];
+#pragma unroll
+    for (int i = 0; i < NRA; ++i) {
+        const int r = i * RPP + wave * RPI + lrow;
+        int m = m0 + r;
+        const bool ok = m < a.M;
+        if (!ok) m = 0;
+        int n, oh, ow;
+        split_row(a, m, n, oh, ow);
+        const int vh0 = oh * a.stride - a.pad_t, vw0 = ow * a.stride - a.pad_l;
+        abase[i] = (((n * a.H + vh0) * a.W + vw0) * a.C) * 2 + ((lchk ^ swz<BKC>(r)) << 4);
+        unsigned mk = 0;
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int ih = vh0 + (tap / S) * a.dil, iw = vw0 + (tap % S) * a.dil;
+            const bool v = ok & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            mk |= (v ? 1u : 0u) << tap;
+        }
+        amask[i] = mk;
+    }
+    unsigned bvo[NRB];
+#pragma unroll
+    for (int i = 0; i < NRB; ++i) {
+        const int r = i * RPP + wave * RPI + lrow;
+        const int n = n0 + r;
+        bvo[i] = (n < a.K) ? (unsigned)((n * a.C) * 2 + ((lchk ^ swz<BKC>(r)) << 4)) : OOB2;
+    }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
+
+    const int ncc = a.C / BKC;
+    const int nst = ncc * NTAP;
+    int l_cc = 0, l_tap = 0;            // (channel group, tap) of the next stage to fetch: uniform
+    const int tapKC = a.K * a.C * 2;     // bytes per tap of the filter shadow
+    auto issue = [&](int buf) {
+        unsigned char* base = lds + buf * STG + wave * (RPI * ROWB);
+        const int tr = l_tap / S, ts = l_tap - tr * S;
+        const int tshift = ((tr * a.dil * a.W + ts * a.dil) * a.C) * 2;
+        const int sa = l_cc * (BKC * 2);
+        const int teff = (KIND == 1) ? (NTAP - 1 - l_tap) : l_tap;       // data gradient: the filter is walked in reverse (correlation -> convolution)
+        const int sb = teff * tapKC + l_cc * (BKC * 2);
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const unsigned vo = ((amask[i] >> l_tap) & 1u) ? (unsigned)(abase[i] + tshift) : OOB2;
+            dma16(rx, (lds_void*)(base + i * (RPP * ROWB)), vo, sa);
+        }
+#pragma unroll
+        for (int i = 0; i < NRB; ++i)
+            dma16(rw, (lds_void*)(base + BM * ROWB + i * (RPP * ROWB)), bvo[i], sb);
+        // fetches past the last stage re-read the last one (valid addresses, into a buffer nobody reads any more): the stage body has
+        // no conditional load and the vmcnt arithmetic stays uniform
+        const int wrap = (l_tap + 1 == NTAP) ? 1 : 0;
+        l_tap = wrap ? 0 : l_tap + 1;
+        l_cc = min(l_cc + wrap, ncc - 1);
+    };
+
+    // ---- fragment reads: lane (l31, h) reads row l31 of a 32-row block, 16-byte chunk (2 ks + h) ^ swz(row); the swizzle of a row
+    // depends on its low 5 bits only (blocks start at multiples of 32), so ONE set of per-lane offsets serves A and B
+    const int l31 = lane & 31, h = lane >> 5;
+    int foff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = l31 * ROWB + (((2 * ks + h) ^ swz<BKC>(l31)) << 4);
+
+    Acc<TM, TN> acc;
+    acc.zero();
+    auto compute = [&](int buf) {
+        const unsigned char* A = lds + buf * STG + wm0 * ROWB;
+        const unsigned char* B = lds + buf * STG + BM * ROWB + wn0 * ROWB;
+        bf16x8 af[KS][TM], bfr[KS][TN];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[ks][tm] = *reinterpret_cast<const bf16x8*>(A + tm * (32 * ROWB) + foff[ks]);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bfr[ks][tn] = *reinterpret_cast<const bf16x8*>(B + tn * (32 * ROWB) + foff[ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][tm], bfr[ks][tn], acc.v[tm][tn], 0, 0, 0);
+    };
+    // stage j: its DMA was issued NBUF - 1 stages ago.  Own loads landed (counted vmcnt: the NBUF - 2 younger stages stay in flight), own
+    // fragment reads of stage j - 1 retired (lgkmcnt), barrier: now EVERY wave's part of stage j is in LDS and nobody reads buffer
+    // (j - 1) % NBUF any more — refill it with stage j + NBUF - 1, then contract stage j.
+    auto stage = [&](int d) {
+        wait_vm<(NBUF - 2) * LPS>();
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();
+        issue((d + NBUF - 1) % NBUF);
+        compute(d);
+    };
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d) issue(d);
+    const int nmain = (nst / NBUF) * NBUF;
+    for (int j0 = 0; j0 < nmain; j0 += NBUF) {
+#pragma unroll
+        for (int d = 0; d < NBUF; ++d) stage(d);
+    }
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d)
+        if (nst - nmain > d) stage(d);
+    wait_vm<0>();
+    conv_epilogue<TM, TN>(a, acc, a.y, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, true);
+}
+
+// ---------------------------------------- casts -------------------------------------------------
+__global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + i), b = *reinterpret_cast<const f32x4*>(x + i + 4);
+        bf16x8 o;
+        o[0] = (__bf16)a[0]; o[1] = (__bf16)a[1]; o[2] = (__bf16)a[2]; o[3] = (__bf16)a[3];
+        o[4] = (__bf16)b[0]; o[5] = (__bf16)b[1]; o[6] = (__bf16)b[2]; o[7] = (__bf16)b[3];
+        *reinterpret_cast<bf16x8*>(y + i) = o;
+    } else {
+        for (size_t j = i; j < n; ++j) y[j] = (__bf16)x[j];
+    }
+}
+
+// fp32 master filter [tap][C][K] -> bf16 shadows  w_io = [tap][C][K] (plain cast)  and  w_oi = [tap][K][C] (32 x 32 tiles through LDS)
+__global__ void __launch_bounds__(256) filter_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ w_io, __bf16* __restrict__ w_oi,
+                                                          int C, int K) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t tb = (size_t)tap * C * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, k = k0 + tx;
+        float v = 0.f;
+        if (c < C && k < K) {
+            v = w[tb + (size_t)c * K + k];
+            if (w_io) w_io[tb + (size_t)c * K + k] = (__bf16)v;
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+    if (w_oi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ty + 8 * i, c = c0 + tx;
+            if (c < C && k < K) w_oi[tb + (size_t)k * C + c] = (__bf16)tile[tx][ty + 8 * i];
+        }
+    }
+}
+
+// ---------------------------------------- host side ----------------------------------------------
+constexpr bool r_shape(int kind, int R, int S) { return (R == 3 && S == 3) || (kind == 0 && R == 5 && S == 5); }
+
+// tile plan: 0 = 256x128 (8 waves, 3 LDS stages), 1 = 128x128 (4 waves, 2 stages), 2 = 128x64 (4 waves, 3 stages); -1: not served
+int plan_tile(long long M, int K) {
+    static const int force = getenv("PNP_BF16R_TILE") ? atoi(getenv("PNP_BF16R_TILE")) : -1;
+    if (K % 64 != 0) return -1;
+    int tile;
+    if (K % 128 == 0 && pnp_cdiv(M, 256) * (K / 128) >= 256) tile = 0;
+    else if (K % 128 == 0 && pnp_cdiv(M, 128) * (K / 128) >= 256) tile = 1;
+    else tile = 2;
+    if (force >= 0 && !(force <= 1 && K % 128 != 0)) tile = force;
+    return tile;
+}
+
+template <int BM, int BN, int WM, int WN, int BKC, int KIND, int NBUF>
+int launch_tile(ConvArgs& a, hipStream_t st) {
+    a.nblk_m = pnp_cdiv(a.M, BM);
+    a.nblk_n = pnp_cdiv(a.K, BN);
+    a.nsplit = 1;
+    dim3 grid((unsigned)(a.nblk_m * a.nblk_n));
+#define PNP_R(RR, SS)                                                                                                            \
+    if (a.R == RR && a.S == SS) {                                                                                                \
+        PnpProfScope ps(prof_class(KIND), st, conv_flops(a), 0.5 * conv_bytes(a) + 2.0 * (double)a.M * a.K,                      \
+                        "conv_bf16r_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BKC, KIND, RR, SS, NBUF);        \
+        hipLaunchKernelGGL((conv_bf16r_kernel<BM, BN, WM, WN, BKC, KIND, RR, SS, NBUF>), grid, dim3(64 * WM * WN), 0, st, a);    \
+        PNP_CHECK_LAUNCH("conv_bf16r_kernel");                                                                                   \
+        return PNP_OK;                                                                                                           \
+    }
+    PNP_R(3, 3)
+    if constexpr (KIND == 0) { PNP_R(5, 5) }
+#undef PNP_R
+    pnp_set_error("conv_bf16r_kernel: no instance for %dx%d", a.R, a.S);
+    return PNP_EINVAL;
+}
+
+template <int KIND>
+int launch_kind(ConvArgs& a, hipStream_t st) {
+    const int tile = plan_tile(a.M, a.K);
+    PNP_REQUIRE(tile >= 0, "conv_bf16r: geometry not served");
+    if (a.C % 64 == 0) {
+        if (tile == 0) return launch_tile<256, 128, 4, 2, 64, KIND, 3>(a, st);
+        if (tile == 1) return launch_tile<128, 128, 2, 2, 64, KIND, 2>(a, st);
+        return launch_tile<128, 64, 2, 2, 64, KIND, 3>(a, st);
+    }
+    if (tile == 0) return launch_tile<256, 128, 4, 2, 32, KIND, 3>(a, st);
+    if (tile == 1) return launch_tile<128, 128, 2, 2, 32, KIND, 2>(a, st);
+    return launch_tile<128, 64, 2, 2, 32, KIND, 3>(a, st);
+}
+
+// what the resident kernels serve: zero padding, instantiated filter shapes, reduction channels in whole 32-groups, output channels in
+// whole 64-groups, tensors < 2 GiB; data gradient: stride 1 only (the strided ones stay on the stride-phase kernels)
+bool served(const pnp_conv_geom* g, int kind) {
+    if (!g || g->pad_mode != PNP_PAD_ZERO) return false;
+    static const int off = getenv("PNP_BF16R_OFF") ? 1 : 0;
+    if (off) return false;
+    const int red = kind == 1 ? g->K : g->C, outc = kind == 1 ? g->C : g->K;
+    if (!r_shape(kind, g->R, g->S) || red % 32 != 0 || outc % 64 != 0) return false;
+    if (kind == 1 && g->stride != 1) return false;
+    if (kind == 1 && (g->dil * (g->R - 1) < g->pad_t || g->dil * (g->S - 1) < g->pad_l)) return false;
+    const long long xin = (long long)g->N * g->H * g->W * g->C, yout = (long long)g->N * g->OH * g->OW * g->K;
+    if (xin >= (1ll << 30) || yout >= (1ll << 30)) return false;
+    const long long M = kind == 1 ? (long long)g->N * g->H * g->W : (long long)g->N * g->OH * g->OW;
+    if (M < 4096) return false;                      // a handful of tiles: the reduction-split fp32-operand paths serve those
+    return plan_tile(M, outc) >= 0;
+}
+
+ConvArgs base_args(const void* x, const void* w, float* y, const pnp_conv_geom* g) {
+    ConvArgs a{};
+    a.x = (const float*)x; a.w = (const float*)w; a.y = y;
+    a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->C; a.K = g->K; a.R = g->R; a.S = g->S;
+    a.OH = g->OH; a.OW = g->OW; a.stride = g->stride; a.dil = g->dil; a.pad_t = g->pad_t; a.pad_l = g->pad_l;
+    a.pad_mode = g->pad_mode;
+    a.dtype = PNP_DTYPE_BF16;
+    a.ups = 1;
+    a.M = g->N * g->OH * g->OW;
+    a.Kred = g->R * g->S * g->C;
+    a.OHW = g->OH * g->OW;
+    a.nsplit = 1;
+    const bool p2 = (a.OW & (a.OW - 1)) == 0 && (a.OHW & (a.OHW - 1)) == 0;
+    a.ow_sh = p2 ? __builtin_ctz((unsigned)a.OW) : -1;
+    a.ohw_sh = p2 ? __builtin_ctz((unsigned)a.OHW) : -1;
+    a.drop_scale = 1.f;
+    static const int env_noswz = getenv("PNP_CONV_NOSWIZZLE") ? 1 : 0;
+    a.xcd_swizzle = env_noswz ? 0 : 1;
+    a.x_bytes = (unsigned)((size_t)g->N * g->H * g->W * g->C * 2);
+    a.w_bytes = (unsigned)((size_t)g->R * g->S * g->C * g->K * 2);
+    static const int env_gn = getenv("PNP_CONV_GN") ? atoi(getenv("PNP_CONV_GN")) : 4;
+    a.gn = env_gn;
+    return a;
+}
+
+int wm_of_tile(int tile) { return tile == 0 ? 4 : 2; }
+int bm_of_tile(int tile) { return tile == 0 ? 256 : 128; }
+
+}  // namespace
+
+extern "C" {
+
+int pnp_cast_bf16(const float* x, void* y, size_t n, void* stream) {
+    PNP_REQUIRE(x && y && n > 0, "pnp_cast_bf16: bad argument");
+    PNP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "pnp_cast_bf16: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)pnp_cdiv((long long)((n + 7) / 8), 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (__bf16*)y, n);
+    PNP_CHECK_LAUNCH("cast_bf16_kernel");
+    return PNP_OK;
+}
+
+int pnp_filter_bf16(const float* w, void* w_io, void* w_oi, int32_t R, int32_t S, int32_t C, int32_t K, void* stream) {
+    PNP_REQUIRE(w && (w_io || w_oi) && R > 0 && S > 0 && C > 0 && K > 0, "pnp_filter_bf16: bad argument");
+    dim3 grid((unsigned)pnp_cdiv(K, 32), (unsigned)pnp_cdiv(C, 32), (unsigned)(R * S));
+    hipLaunchKernelGGL(filter_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w_io, (__bf16*)w_oi, C, K);
+    PNP_CHECK_LAUNCH("filter_bf16_kernel");
+    return PNP_OK;
+}
+
+int32_t pnp_conv2d_bf16r_served(const pnp_conv_geom* g, int32_t kind) { return (kind == 0 || kind == 1) && served(g, kind) ? 1 : 0; }
+
+// batch-norm statistics partial rows the resident forward leaves behind (pixel tiles x wave rows of ITS tile)
+int32_t pnp_conv2d_fwd_bf16r_stats_parts(const pnp_conv_geom* g) {
+    if (!served(g, 0)) return 0;
+    const long long M = (long long)g->N * g->OH * g->OW;
+    const int tile = plan_tile(M, g->K);
+    return pnp_cdiv(M, bm_of_tile(tile)) * wm_of_tile(tile);
+}
+
+int pnp_conv2d_fwd_bf16r(const void* xh, const void* w_oi, float* y, void* yh, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
+                         uint32_t stream_id, const float* stat_shift, float* stat_parts, size_t stat_parts_bytes, const float* scale,
+                         const float* shift, const float* shortcut, int32_t Cs, float alpha, void* stream) {
+    PNP_REQUIRE(served(g, 0), "pnp_conv2d_fwd_bf16r: geometry not served (pnp_conv2d_bf16r_served)");
+    PNP_REQUIRE(xh && w_oi && y, "pnp_conv2d_fwd_bf16r: null pointer");
+    PNP_REQUIRE(keep_prob > 0.f, "pnp_conv2d_fwd_bf16r: keep_prob must be > 0");
+    ConvArgs a = base_args(xh, w_oi, y, g);
+    a.y_h = (unsigned short*)yh;
+    if (keep_prob < 1.f) {
+        a.do_drop = 1;
+        a.drop_scale = 1.f / keep_prob;
+        a.drop_key = pnp_drop_key(seed, stream_id);
+        a.drop_thresh = pnp_drop_thresh(keep_prob);
+    }
+    if (stat_parts) {
+        const size_t need = (size_t)pnp_conv2d_fwd_bf16r_stats_parts(g) * 2 * g->K * sizeof(float);
+        if (stat_parts_bytes < need) {
+            pnp_set_error("pnp_conv2d_fwd_bf16r: parts buffer too small (%zu < %zu)", stat_parts_bytes, need);
+            return PNP_EWORKSPACE;
+        }
+        a.stat_ws = stat_parts;
+        a.stat_shift = stat_shift;
+    }
+    if (scale) {
+        PNP_REQUIRE(shift, "pnp_conv2d_fwd_bf16r: scale without shift");
+        if (shortcut) PNP_REQUIRE(Cs > 0 && Cs <= g->K && ((g->K - Cs) % 2) == 0, "pnp_conv2d_fwd_bf16r: bad shortcut channels");
+        a.ep_scale = scale; a.ep_shift = shift; a.ep_res = shortcut; a.ep_cs = shortcut ? Cs : g->K; a.ep_alpha = alpha;
+    }
+    return launch_kind<0>(a, (hipStream_t)stream);
+}
+
+// dx = data gradient (+ residual): a stride-1 convolution of dy with the filter walked in reverse, operand rows from w_io = [tap][C][K]
+int pnp_conv2d_dgrad_bf16r(const void* dyh, const void* w_io, const float* residual, float* dx, void* dxh, const pnp_conv_geom* g,
+                           void* stream) {
+    PNP_REQUIRE(served(g, 1), "pnp_conv2d_dgrad_bf16r: geometry not served (pnp_conv2d_bf16r_served)");
+    PNP_REQUIRE(dyh && w_io && dx && residual != dx, "pnp_conv2d_dgrad_bf16r: bad pointer");
+    pnp_conv_geom d{};
+    d.N = g->N; d.H = g->OH; d.W = g->OW; d.C = g->K; d.K = g->C; d.R = g->R; d.S = g->S;
+    d.OH = g->H; d.OW = g->W;
+    d.stride = 1; d.dil = g->dil;
+    d.pad_t = g->dil * (g->R - 1) - g->pad_t;
+    d.pad_l = g->dil * (g->S - 1) - g->pad_l;
+    d.pad_mode = PNP_PAD_ZERO;
+    d.dtype = PNP_DTYPE_BF16;
+    ConvArgs a = base_args(dyh, w_io, dx, &d);
+    a.y_h = (unsigned short*)dxh;
+    a.res_add = residual;
+    return launch_kind<1>(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -55,6 +55,8 @@ struct ConvArgs {
     // instead of two integer divisions (~25 VALU each; a 128x64 tile of a 64-channel layer spends ~3 % of its life on them, the
     // scattered epilogue of a stride-phase data gradient far more); -1: divide
     int ow_sh, ohw_sh;
+    // bf16 copy of the output, [M][K] rows (conv_bf16r.hip: the operand of the NEXT convolution, written by the same epilogue); null: none
+    unsigned short* y_h;
 };
 
 // output row m -> (image n, oh, ow)
@@ -270,6 +272,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, T
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) bstore1(ry, (mok & cok[tn]) ? (row + ncol[tn]) * 4u : OOB, o.v[tm][tn][r]);
         }
+    if (a.y_h && !scatter) {                  // the same values rounded to bf16 (round-to-nearest-even): 64 contiguous bytes per 32 lanes
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.y_h, 0, (unsigned)(yelems * 2), 0x00020000);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = PNP_EP_M;
+                const bool mok = m < a.M;
+                const unsigned row = (unsigned)(m * a.K);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const __bf16 hv = (__bf16)o.v[tm][tn][r];
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rh, (mok & cok[tn]) ? (row + ncol[tn]) * 2u : OOB, 0, 0);
+                }
+            }
+    }
 #undef PNP_EP_FOR
 #undef PNP_EP_M
 }

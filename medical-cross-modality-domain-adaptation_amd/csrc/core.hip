@@ -1,6 +1,7 @@
 // core.hip — error channel, ABI version and device query of libpnp_hip.so.
 #include <stdarg.h>
 #include <string.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -25,18 +26,13 @@ struct ProfRec {
 };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof_recs;
-int g_prof_mask = 0;
+std::atomic<int> g_prof_mask{0};      // read on every launch (relaxed): the mutex guards g_prof_recs only
 constexpr size_t kProfCap = 1u << 18;
 }  // namespace
 
 PnpProfScope::PnpProfScope(int cls, hipStream_t st, double flops, double bytes, const char* fmt, ...)
     : on_(false), st_(st), e0_(nullptr), e1_(nullptr), flops_(flops), bytes_(bytes) {
-    int mask;
-    {
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        mask = g_prof_mask;
-    }
-    if (!(mask & cls)) return;
+    if (!(g_prof_mask.load(std::memory_order_relaxed) & cls)) return;
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(name_, sizeof(name_), fmt, ap);
@@ -65,11 +61,10 @@ PnpProfScope::~PnpProfScope() {
 
 extern "C" {
 
-int pnp_abi_version(void) { return 3; }
+int pnp_abi_version(void) { return 4; }
 
 int pnp_prof_enable(int mask) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_mask = mask;
+    g_prof_mask.store(mask, std::memory_order_relaxed);
     return PNP_OK;
 }
 

@@ -28,6 +28,15 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _ph(t):
+    """device pointer of a contiguous bfloat16 tensor (the bf16-resident convolutions' operands)"""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+        raise _lib.PnpError("expected a contiguous CUDA bfloat16 tensor, got %s %s contiguous=%s" % (t.device, t.dtype, t.is_contiguous()))
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def workspace(nbytes, device, slot="main"):
     """Grow-only scratch buffer per (device, slot). All kernels are stream-ordered on the current stream."""
     key = (str(device), slot, torch.cuda.current_stream().cuda_stream)
@@ -138,6 +147,56 @@ def conv2d_fwd_bn(x, w, g, scale_shift, shortcut=None, alpha=0.2, keep_prob=1.0,
     check(lib.pnp_conv2d_fwd_bn(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _p(scale_shift[0]),
                                 _p(scale_shift[1]), _p(shortcut), cs, float(alpha), _stream()), "pnp_conv2d_fwd_bn")
     return y
+
+
+# ---- bf16-resident convolutions (BASELINE configs[4]; csrc/conv_bf16r.hip) ------------------------------------------------------------
+def cast_bf16(x):
+    """bf16 copy (round-to-nearest-even) of a float32 tensor: pnp_cast_bf16 — for tensors whose producer has no bf16 output"""
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().pnp_cast_bf16(_p(x), _ph(y), x.numel(), _stream()), "pnp_cast_bf16")
+    return y
+
+
+def filter_bf16(w, want_io=True, want_oi=True):
+    """bf16 shadows of the fp32 master filter [R,S,C,K]: (w_io [R*S,C,K], w_oi [R*S,K,C])"""
+    R, S, C, Kc = w.shape
+    w_io = torch.empty((R * S, C, Kc), dtype=torch.bfloat16, device=w.device) if want_io else None
+    w_oi = torch.empty((R * S, Kc, C), dtype=torch.bfloat16, device=w.device) if want_oi else None
+    check(_lib.load().pnp_filter_bf16(_p(w), _ph(w_io), _ph(w_oi), R, S, C, Kc, _stream()), "pnp_filter_bf16")
+    return w_io, w_oi
+
+
+def bf16r_served(g, kind):
+    """kind 0 forward / 1 data gradient: do the resident kernels serve this geometry"""
+    return bool(_lib.load().pnp_conv2d_bf16r_served(ctypes.byref(g), int(kind)))
+
+
+def conv2d_fwd_bf16r(xh, w_oi, g, keep_prob=1.0, seed=0, stream_id=0, want_h=False, stat_shift=None, want_stats=False, bn=None):
+    """resident forward.  Returns (y, yh or None, parts or None).  want_stats: BN statistics partials (-> bn_stats_finish);
+    bn = (scale_shift [2,K], shortcut or None, alpha): fused inference-mode BN + shortcut + leaky-ReLU"""
+    lib = _lib.load()
+    y = torch.empty((g.N, g.OH, g.OW, g.K), dtype=torch.float32, device=xh.device)
+    yh = torch.empty((g.N, g.OH, g.OW, g.K), dtype=torch.bfloat16, device=xh.device) if want_h else None
+    parts, nparts, pbytes = None, 0, 0
+    if want_stats:
+        nparts = int(lib.pnp_conv2d_fwd_bf16r_stats_parts(ctypes.byref(g)))
+        parts = workspace(nparts * 2 * g.K * 4, xh.device, slot="stats")
+        pbytes = parts.numel()
+    ss, sc, alpha = (bn[0], bn[1], bn[2]) if bn is not None else (None, None, -1.0)
+    check(lib.pnp_conv2d_fwd_bf16r(_ph(xh), _ph(w_oi), _p(y), _ph(yh), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id),
+                                   _p(stat_shift), ctypes.c_void_p(parts.data_ptr()) if parts is not None else None, pbytes,
+                                   _p(ss[0]) if ss is not None else None, _p(ss[1]) if ss is not None else None, _p(sc),
+                                   sc.shape[-1] if sc is not None else 0, float(alpha), _stream()), "pnp_conv2d_fwd_bf16r")
+    return y, yh, ((parts, nparts) if want_stats else None)
+
+
+def conv2d_dgrad_bf16r(dyh, w_io, g, residual=None, want_h=False):
+    lib = _lib.load()
+    dx = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dyh.device)
+    dxh = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.bfloat16, device=dyh.device) if want_h else None
+    check(lib.pnp_conv2d_dgrad_bf16r(_ph(dyh), _ph(w_io), _p(residual), _p(dx), _ph(dxh), ctypes.byref(g), _stream()),
+          "pnp_conv2d_dgrad_bf16r")
+    return dx, dxh
 
 
 def conv2d_dgrad(dy, w, g, residual=None):

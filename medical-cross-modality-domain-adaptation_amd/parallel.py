@@ -334,8 +334,17 @@ class GradReducer(object):
             self._var_bucket[v.name] = b
         self._remaining.append(len(members))
 
+    def _arm_counts(self):
+        """per-bucket number of gradients this step will deliver: the members that take a gradient NOW (the GAN steps toggle
+        requires_grad per variable group between steps, so a bucket that mixes critic and adapt_* variables is complete when its
+        trainable members have reported — counting every member left such a bucket waiting for allreduce() and, at the head of the
+        active set, held every complete bucket behind it: no overlap)"""
+        self._count = [sum(1 for v in m if v.tensor.requires_grad) for m in self._members]
+        self._armed = True
+
     def reset(self):
         self._count = list(self._remaining)
+        self._armed = False     # counts are re-derived from the requires_grad flags at the first gradient of the next step
         self._launched = [False] * len(self.buckets)
         self._ready = [False] * len(self.buckets)
         self._seen = set()
@@ -374,6 +383,8 @@ class GradReducer(object):
             # come after the variable's last use of the step, the first one counts
             if name in self._seen:
                 return
+            if not self._armed:
+                self._arm_counts()
             self._seen.add(name)
             self._count[b] -= 1
             if self._count[b] == 0:

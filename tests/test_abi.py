@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol(built):
     for s in syms:
         assert hasattr(lib, s), "libpnp_hip.so does not export %s" % s
     assert sorted(built._lib.PROTOTYPES.keys()) == syms          # ctypes prototypes cover the header exactly
-    assert lib.pnp_abi_version() == built._lib.ABI_VERSION == 3
+    assert lib.pnp_abi_version() == built._lib.ABI_VERSION == 4
 
 
 def test_workspace_queries_and_error_channel(built):
