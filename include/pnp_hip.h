@@ -312,6 +312,29 @@ int pnp_conv2d_fwd_bf16r(const void* xh, const void* w_oi, float* y, void* yh /*
 int pnp_conv2d_dgrad_bf16r(const void* dyh, const void* w_io, const float* residual /*nullable*/, float* dx, void* dxh /*nullable*/,
                            const pnp_conv_geom* g, void* stream);
 
+/* The elementwise producers with a bf16 SIDE OUTPUT (`yh` / `dxh`, nullable): the same values as the float32 output rounded to bf16, from
+ * the same launch — what the next resident convolution reads.  Otherwise identical to pnp_bn_apply / pnp_bn_bwd_acc / pnp_bn_bwd_apply /
+ * pnp_dropout (pnp_dropout_h: y may be NULL when only the bf16 copy is wanted). */
+int pnp_bn_apply_h(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                   const float* shortcut /*nullable*/, int32_t Cs, float* y, void* yh, int64_t P, int32_t C, float eps, float alpha,
+                   void* stream);
+int pnp_bn_bwd_acc_h(const float* dout, const float* out, const float* x, const float* mean, const float* var, const float* gamma,
+                     const float* beta, float* dx, void* dxh, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc,
+                     float* dshortcut, int32_t Cs, int64_t P, int32_t C, float eps, float alpha, int32_t training, float keep_prob,
+                     uint64_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream);
+int pnp_bn_bwd_apply_h(const float* dout, const float* out, const float* x, const float* mean, const float* var, const float* gamma,
+                       const float* beta, const float* dgamma, const float* dbeta, float* dx, void* dxh, float* dshortcut, int32_t Cs,
+                       int64_t P, int64_t P_norm, int32_t C, float eps, float alpha, int32_t training, float keep_prob, uint64_t seed,
+                       uint32_t stream_id, void* stream);
+int pnp_dropout_h(const float* x, float* y /*nullable*/, void* yh, size_t n, float keep_prob, uint64_t seed, uint32_t stream_id,
+                  void* stream);
+
+/* filter gradient from bf16 x [N,H,W,C] and bf16 dy [N,OH,OW,K] (pnp_conv2d_bf16r_served(g, 2)): dw [R,S,C,K] float32 is overwritten
+ * (accumulate = 0) or added to (accumulate != 0, as pnp_conv2d_wgrad_acc); workspace: pnp_conv2d_wgrad_bf16r_workspace_bytes(g) */
+size_t pnp_conv2d_wgrad_bf16r_workspace_bytes(const pnp_conv_geom* g);
+int pnp_conv2d_wgrad_bf16r(const void* xh, const void* dyh, float* dw, int32_t accumulate, const pnp_conv_geom* g,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* Data-parallel exchange step (new with respect to the single-GPU reference, train_segmenter.py:20 / train_gan.py:18): in-place
  * SUM all-reduce over RCCL (xGMI), one communicator per process / GPU.  librccl.so is resolved at run time: pnp_comm_load(path)
  * names the copy to bind (NULL: the one already mapped in this process, else the default search path); the other calls load it

@@ -356,6 +356,7 @@ class Full_DRN(object):
         loss.backward(self.store.unit_grad(1))
         self.dis_loss = loss.detach()
         self.ct_logits, self.mr_logits = o["ct_logits"], o["mr_logits"]
+        self.critic_scores = {k: o[k].detach() for k in ("ct_cls", "mr_cls", "ct_mask", "mr_mask") if o.get(k) is not None}
         return self.dis_loss
 
     def gen_loss_and_grads(self, ct, keep_prob, drop_seed=0):
@@ -369,6 +370,7 @@ class Full_DRN(object):
         loss.backward(self.store.unit_grad(1))
         self.ct_gen_loss = loss.detach()
         self.ct_logits = o["ct_logits"]
+        self.critic_scores = {k: o[k].detach() for k in ("ct_cls", "ct_mask") if o.get(k) is not None}
         return self.ct_gen_loss
 
     def evaluate(self, ct, ct_y, mr, mr_y, keep_prob=1.0, detail=False):

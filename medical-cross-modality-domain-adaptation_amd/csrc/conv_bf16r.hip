@@ -187,6 +187,168 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (NBUF * (BM 
     conv_epilogue<TM, TN>(a, acc, a.y, m0, n0, wm0, wn0, lane, mt * WM + wave / WN, true);
 }
 
+// ===================================== filter gradient ============================================
+// dW[m' = (tap, c)][k] = sum_p x[p shifted by tap][c] * dy[p][k]: the reduction index is the PIXEL, and both operands are pixel-major in
+// memory ([p][c], [p][k]).  They are staged exactly as they lie — LDS rows = pixels, BM (BN) channels wide, by the same LDS-DMA — and
+// the transposition the MFMA wants (8 consecutive reduction elements per lane) is done by the LDS read itself: ds_read_b64_tr_b16 hands
+// lane i of a 16-lane group the i-th COLUMN of the 4 x 16 block whose rows the lanes 4e .. 4e+3 point at (profiles/r04_micro_lds_dma_tr16.txt),
+// i.e. 4 consecutive pixels of one channel; two such reads are one MFMA operand.  Bank swizzle: the four rows of a block are 256 (128)
+// bytes apart, so the 16-byte chunk index is XOR-ed with 4 * (row & 3) (4 * ((row >> 1) & 1) for 128-byte rows): the 4 rows x 4 chunks
+// a half-wave reads then cover the 256-byte bank row exactly once.
+// a.x = x (bf16), a.w = dy (bf16, [P][K]); reduction split over workgroups in chunks of 64 pixels (grid.x = tiles * nsplit; partials
+// summed by conv_igemm.hip's splitk_reduce_kernel).  A tile holds ONE tap (C % BM == 0), OW and OH*OW are powers of two.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+#else
+    return s16x4{};
+#endif
+}
+template <int CPR>
+__device__ __forceinline__ int swz_px(int row) {
+    return CPR == 16 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2);
+}
+
+template <int BM, int BN, int WM, int WN, int NBUF>
+__global__ void __launch_bounds__(256, (NBUF * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) conv_wgrad_bf16r_kernel(ConvArgs a) {
+    constexpr int BKP = 64;                      // pixels per stage
+    constexpr int NW = WM * WN;
+    static_assert(NW == 4, "four waves");
+    constexpr int ROWA = BM * 2, ROWB_ = BN * 2;                 // bytes per LDS row
+    constexpr int CPRA = ROWA / 16, CPRB = ROWB_ / 16;           // 16-byte chunks (= lanes) per row
+    static_assert((CPRA == 16 || CPRA == 8) && (CPRB == 16 || CPRB == 8), "rows of 256 or 128 bytes");
+    constexpr int RPIA = 64 / CPRA, RPIB = 64 / CPRB;            // rows per wave-instruction
+    constexpr int NRA = BKP / (NW * RPIA), NRB = BKP / (NW * RPIB);
+    constexpr int LPS = NRA + NRB;
+    constexpr int KS = BKP / 16;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int ASZ = BKP * ROWA, STG = BKP * (ROWA + ROWB_);
+    static_assert(NBUF >= 2 && (NBUF - 2) * LPS < 64, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(256))) unsigned char lds[NBUF * STG];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nblk = a.nblk_m * a.nblk_n;
+    const int lid = a.xcd_swizzle ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int z = lid / nblk;
+    const int bid = lid - z * nblk;
+    int mt, nt;
+    tile_coords(bid, a.nblk_m, a.nblk_n, a.gn, mt, nt);
+    const int mm0 = mt * BM, n0 = nt * BN;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+    const int P = a.M;
+    const int nchunks_total = (P + BKP - 1) / BKP;
+    const int c_begin = z * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    if (c_end > nchunks_total) c_end = nchunks_total;
+    const int nst = c_end - c_begin;
+
+    // the tile's tap (uniform) and first channel
+    const int tap = mm0 / a.C, c0 = mm0 - tap * a.C;
+    const int tr_ = tap / a.S, ts_ = tap - tr_ * a.S;
+    const int dh = tr_ * a.dil - a.pad_t, dw = ts_ * a.dil - a.pad_l;
+    // loader rows: lane (lrow, lchk) of pass i fills LDS row i * NW * RPI + wave * RPI + lrow, chunk lchk, with source chunk lchk ^ swz
+    const int lrowA = lane / CPRA, lchkA = lane % CPRA, lrowB = lane / CPRB, lchkB = lane % CPRB;
+    int arow[NRA], acol[NRA];
+#pragma unroll
+    for (int i = 0; i < NRA; ++i) {
+        arow[i] = i * (NW * RPIA) + wave * RPIA + lrowA;
+        acol[i] = (c0 * 2) + ((lchkA ^ swz_px<CPRA>(arow[i])) << 4);
+    }
+    unsigned bvo[NRB];           // dy rows: [p][K]
+    int brow[NRB];
+#pragma unroll
+    for (int i = 0; i < NRB; ++i) {
+        brow[i] = i * (NW * RPIB) + wave * RPIB + lrowB;
+        bvo[i] = (unsigned)(((c_begin * BKP + brow[i]) * a.K + n0) * 2 + ((lchkB ^ swz_px<CPRB>(brow[i])) << 4));
+    }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, a.w_bytes);
+    int l_chunk = c_begin;
+    auto issue = [&](int buf) {
+        unsigned char* baseA = lds + buf * STG + wave * (RPIA * ROWA);
+        unsigned char* baseB = lds + buf * STG + ASZ + wave * (RPIB * ROWB_);
+        const int p0 = l_chunk * BKP;
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const int p = p0 + arow[i];
+            const int n = p >> a.ohw_sh;
+            const int oh = (p >> a.ow_sh) & (a.OH - 1), ow = p & (a.OW - 1);
+            const int ih = oh * a.stride + dh, iw = ow * a.stride + dw;
+            const bool ok = (p < P) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            const unsigned vo = ok ? (unsigned)((((n * a.H + ih) * a.W + iw) * a.C) * 2 + acol[i]) : OOB2;
+            dma16(rx, (lds_void*)(baseA + i * (NW * RPIA * ROWA)), vo, 0);
+        }
+        const int sb = (l_chunk - c_begin) * (BKP * a.K * 2);
+        // (the hardware's range check covers the per-lane offset only, not the scalar one: rows past the last pixel are masked here)
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) dma16(rw, (lds_void*)(baseB + i * (NW * RPIB * ROWB_)), (p0 + brow[i] < P) ? bvo[i] : OOB2, sb);
+        l_chunk = min(l_chunk + 1, nchunks_total);      // past the end: every row is masked
+    };
+
+    // fragment reads (see the header of this section): lane = (group g, e, q); rows pbase + 4 r + e of a 16-pixel slice, 4 channels
+    const int g16 = lane >> 4, e4 = (lane >> 2) & 3, q4 = lane & 3;
+    int foffA[TM], foffB[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int chunk = ((wm0 + tm * 32) >> 3) + (g16 & 1) * 2 + (q4 >> 1);
+        foffA[tm] = ((g16 >> 1) * 8 + e4) * ROWA + ((chunk ^ swz_px<CPRA>(e4)) << 4) + (q4 & 1) * 8;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int chunk = ((wn0 + tn * 32) >> 3) + (g16 & 1) * 2 + (q4 >> 1);
+        foffB[tn] = ((g16 >> 1) * 8 + e4) * ROWB_ + ((chunk ^ swz_px<CPRB>(e4)) << 4) + (q4 & 1) * 8;
+    }
+    Acc<TM, TN> acc;
+    acc.zero();
+    auto compute = [&](int buf) {
+        const unsigned char* A = lds + buf * STG;
+        const unsigned char* B = lds + buf * STG + ASZ;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const s16x4 lo = lds_tr16(A + (ks * 16) * ROWA + foffA[tm]), hi = lds_tr16(A + (ks * 16 + 4) * ROWA + foffA[tm]);
+                af[tm] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const s16x4 lo = lds_tr16(B + (ks * 16) * ROWB_ + foffB[tn]), hi = lds_tr16(B + (ks * 16 + 4) * ROWB_ + foffB[tn]);
+                bfr[tn] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc.v[tm][tn], 0, 0, 0);
+        }
+    };
+    auto stage = [&](int d) {
+        wait_vm<(NBUF - 2) * LPS>();
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();
+        issue((d + NBUF - 1) % NBUF);
+        compute(d);
+    };
+    if (nst > 0) {
+#pragma unroll
+        for (int d = 0; d < NBUF - 1; ++d) issue(d);
+        const int nmain = (nst / NBUF) * NBUF;
+        for (int j0 = 0; j0 < nmain; j0 += NBUF) {
+#pragma unroll
+            for (int d = 0; d < NBUF; ++d) stage(d);
+        }
+#pragma unroll
+        for (int d = 0; d < NBUF - 1; ++d)
+            if (nst - nmain > d) stage(d);
+        wait_vm<0>();
+    }
+    wgrad_epilogue<TM, TN>(a, acc, a.y + (size_t)z * a.split_stride, mm0, n0, wm0, wn0, lane);
+}
+
 // ---------------------------------------- casts -------------------------------------------------
 __global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, size_t n) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
@@ -325,6 +487,40 @@ int bm_of_tile(int tile) { return tile == 0 ? 256 : 128; }
 
 }  // namespace
 
+namespace pnpconv {
+
+// which tile serves the filter gradient of `g` on the resident kernel (-1: none): zero padding, channels of one tap in whole 64-groups,
+// filters in whole 64-groups, power-of-two output extents (every layer of the model), tensors < 2 GiB, >= 4096 output pixels
+int wgrad_bf16r_tile(const pnp_conv_geom* g) {
+    static const int off = getenv("PNP_BF16R_OFF") ? 1 : 0;
+    if (off || !g || g->pad_mode != PNP_PAD_ZERO || g->C % 64 != 0 || g->K % 64 != 0) return -1;
+    const long long P = (long long)g->N * g->OH * g->OW, ohw = (long long)g->OH * g->OW;
+    if (P < 4096 || (g->OW & (g->OW - 1)) != 0 || (ohw & (ohw - 1)) != 0) return -1;
+    const long long xin = (long long)g->N * g->H * g->W * g->C, yout = P * g->K;
+    if (xin >= (1ll << 30) || yout >= (1ll << 30)) return -1;
+    return (g->C % 128 == 0 ? 0 : 2) + (g->K % 128 == 0 ? 0 : 1);
+}
+
+// tile: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 128, 3 = 64 x 64 (channels of one tap x filters); grid / nsplit / chunks_per_split (in
+// units of wgrad_bf16r_chunk() pixels) planned by the caller (conv_igemm.hip: it owns the split planner and the reduce kernel)
+bool launch_wgrad_bf16r(const ConvArgs& a, int tile, dim3 grid, hipStream_t st) {
+#define PNP_WG(BM_, BN_, NBUF_)                                                                                                   \
+    {                                                                                                                             \
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, conv_flops(a), 0.5 * conv_bytes(a), "conv_wgrad_bf16r_kernel<%d, %d, 2, 2, %d>", BM_, BN_, \
+                        NBUF_);                                                                                                   \
+        hipLaunchKernelGGL((conv_wgrad_bf16r_kernel<BM_, BN_, 2, 2, NBUF_>), grid, dim3(256), 0, st, a);                           \
+        return true;                                                                                                              \
+    }
+    if (tile == 0) PNP_WG(128, 128, 2)
+    if (tile == 1) PNP_WG(128, 64, 3)
+    if (tile == 2) PNP_WG(64, 128, 3)
+    if (tile == 3) PNP_WG(64, 64, 3)
+#undef PNP_WG
+    return false;
+}
+
+}  // namespace pnpconv
+
 extern "C" {
 
 int pnp_cast_bf16(const float* x, void* y, size_t n, void* stream) {
@@ -344,7 +540,10 @@ int pnp_filter_bf16(const float* w, void* w_io, void* w_oi, int32_t R, int32_t S
     return PNP_OK;
 }
 
-int32_t pnp_conv2d_bf16r_served(const pnp_conv_geom* g, int32_t kind) { return (kind == 0 || kind == 1) && served(g, kind) ? 1 : 0; }
+int32_t pnp_conv2d_bf16r_served(const pnp_conv_geom* g, int32_t kind) {
+    if (kind == 2) return wgrad_bf16r_tile(g) >= 0 ? 1 : 0;
+    return (kind == 0 || kind == 1) && served(g, kind) ? 1 : 0;
+}
 
 // batch-norm statistics partial rows the resident forward leaves behind (pixel tiles x wave rows of ITS tile)
 int32_t pnp_conv2d_fwd_bf16r_stats_parts(const pnp_conv_geom* g) {

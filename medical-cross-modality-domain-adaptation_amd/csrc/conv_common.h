@@ -345,6 +345,10 @@ __device__ __forceinline__ f32x4 bload4s(__amdgpu_buffer_rsrc_t r, unsigned voff
 // planned by the caller exactly as for the fp32 kernels.  tile: 0 = 128x128, 1 = 128x64, 2 = 128x32.  Return false: no instance.
 bool launch_taps_bf16(const ConvArgs& a, int tile, int kind, dim3 grid, hipStream_t st);
 bool launch_wgrad_bf16(const ConvArgs& a, int tile, dim3 grid, hipStream_t st);
+// bf16-RESIDENT filter gradient (conv_bf16r.hip): a.x / a.w point at bf16 tensors; reduction chunks of 64 pixels
+constexpr int kWgradBf16rChunk = 64;
+bool launch_wgrad_bf16r(const ConvArgs& a, int tile, dim3 grid, hipStream_t st);
+int wgrad_bf16r_tile(const pnp_conv_geom* g);
 // 3x3 stride-1 convolutions with exactly 16 output channels and 16 / 32 input channels on the 16x16x4 MFMA (conv_small.hip): forward,
 // data gradient (kind 1; honours res_add) and filter gradient (per-workgroup partials [n16_wgrad_blocks][9*C][16] -> splitk_reduce_many)
 bool n16_geom_ok(const pnp_conv_geom* g);

@@ -2531,6 +2531,64 @@ int pnp_conv2d_wgrad_acc(const float* x, const float* dy, float* dw, const pnp_c
     return wgrad_impl(x, dy, dw, g, workspace, workspace_bytes, stream, 1);
 }
 
+// ---- bf16-resident filter gradient (conv_bf16r.hip): x and dy as bf16 tensors; the split planner and the partial-sum kernel are the
+// fp32 path's own
+static int wgrad_bf16r_plan(const pnp_conv_geom* g, int* bm, int* bn) {
+    const int tile = wgrad_bf16r_tile(g);
+    if (tile < 0) return 0;
+    *bm = tile < 2 ? 128 : 64;
+    *bn = (tile & 1) ? 64 : 128;
+    const long long P = (long long)g->N * g->OH * g->OW;
+    const int nblk = (g->R * g->S * g->C / *bm) * (g->K / *bn);
+    return wgrad_plan_split(nblk, pnp_cdiv(P, kWgradBf16rChunk));
+}
+
+size_t pnp_conv2d_wgrad_bf16r_workspace_bytes(const pnp_conv_geom* g) {
+    int bm, bn;
+    const int ns = g ? wgrad_bf16r_plan(g, &bm, &bn) : 0;
+    return ns > 1 ? (size_t)ns * g->R * g->S * g->C * g->K * sizeof(float) : 0;
+}
+
+int pnp_conv2d_wgrad_bf16r(const void* xh, const void* dyh, float* dw, int32_t accumulate, const pnp_conv_geom* g, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (int e = check_geom(g, "pnp_conv2d_wgrad_bf16r")) return e;
+    PNP_REQUIRE(xh && dyh && dw, "pnp_conv2d_wgrad_bf16r: null pointer");
+    int bm, bn;
+    int nsplit = wgrad_bf16r_plan(g, &bm, &bn);
+    PNP_REQUIRE(nsplit >= 1, "pnp_conv2d_wgrad_bf16r: geometry not served (pnp_conv2d_bf16r_served(g, 2))");
+    ConvArgs a = make_args((const float*)xh, (const float*)dyh, dw, g);
+    a.dtype = PNP_DTYPE_BF16;
+    a.x_bytes = (unsigned)((size_t)g->N * g->H * g->W * g->C * 2);
+    a.w_bytes = (unsigned)((size_t)g->N * g->OH * g->OW * g->K * 2);      // a.w is dy [P][K]
+    a.nblk_m = a.Kred / bm;
+    a.nblk_n = a.K / bn;
+    const size_t nout = (size_t)a.Kred * a.K;
+    float* ws = (float*)workspace;
+    if (!ws) workspace_bytes = 0;
+    if (nsplit > 1 && workspace_bytes < nsplit * nout * sizeof(float)) {
+        nsplit = (int)(workspace_bytes / (nout * sizeof(float)));
+        if (nsplit < 2) nsplit = 1;
+    }
+    const int nchunks = pnp_cdiv(a.M, kWgradBf16rChunk);
+    a.chunks_per_split = pnp_cdiv(nchunks, nsplit);
+    nsplit = pnp_cdiv(nchunks, a.chunks_per_split);
+    a.nsplit = nsplit;
+    a.split_stride = (long long)nout;
+    a.y = (nsplit > 1) ? ws : dw;
+    a.accumulate = (nsplit > 1) ? 0 : accumulate;       // un-split: in the kernel's epilogue; split: in the reduce kernel
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(a.nblk_m * a.nblk_n * nsplit));
+    PNP_REQUIRE(launch_wgrad_bf16r(a, wgrad_bf16r_tile(g), grid, st), "conv_wgrad_bf16r_kernel: no instance");
+    PNP_CHECK_LAUNCH("conv_wgrad_bf16r_kernel");
+    if (nsplit > 1) {
+        int nb = pnp_cdiv((long long)nout, 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, dw, nout, nsplit, nout, (int)accumulate);
+        PNP_CHECK_LAUNCH("splitk_reduce_kernel");
+    }
+    return PNP_OK;
+}
+
 int pnp_sympad_fwd(const float* x, float* xp, int32_t N, int32_t H, int32_t W, int32_t C, int32_t p, void* stream) {
     PNP_REQUIRE(x && xp && N > 0 && H > 0 && W > 0 && C > 0 && p >= 0 && p <= H && p <= W, "pnp_sympad_fwd: bad argument");
     const int vec = (C % 4 == 0) ? 1 : 0;

@@ -11,6 +11,13 @@ constexpr int NT = 256;
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// four values rounded to bf16 (nearest-even), one 8-byte store: the bf16 copies the resident convolutions read (conv_bf16r.hip)
+__device__ __forceinline__ void st4h(__bf16* p, f32x4 v) {
+    bf16x4_t h;
+    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    *reinterpret_cast<bf16x4_t*>(p) = h;
+}
 
 inline int grid_for(size_t nvec, int cap = 256 * 8) {
     long long b = (long long)((nvec + NT - 1) / NT);
@@ -315,6 +322,7 @@ struct BnApplyArgs {
     long long P;
     int C, Cs;
     float eps, alpha;
+    __bf16* yh;      // bf16 copy of y (the next convolution's operand on the bf16-resident path); null: none
 };
 
 template <bool VEC>
@@ -346,6 +354,7 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(BnApplyArgs a) {
                 for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.alpha;
             }
             st4(a.y + i * 4, r);
+            if (a.yh) st4h(a.yh + i * 4, r);
         } else {
             const int c = cv;
             float r = fmaf(a.x[i] - a.mean[c], a.gamma[c] * (1.0f / sqrtf(a.var[c] + a.eps)), a.beta[c]);
@@ -355,6 +364,7 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(BnApplyArgs a) {
             }
             if (a.alpha >= 0.f) r = r > 0.f ? r : r * a.alpha;
             a.y[i] = r;
+            if (a.yh) a.yh[i] = (__bf16)r;
         }
     }
 }
@@ -370,6 +380,7 @@ struct BnBwdArgs {
     int do_drop;
     uint32_t drop_key, drop_thresh;
     float drop_scale;
+    __bf16* dxh;     // bf16 copy of dx (operand of the bf16-resident data / filter gradient kernels); null: none
 };
 
 template <bool VEC>
@@ -420,7 +431,8 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(BnBwdArgs a) {
                 for (int e = 0; e < 4; ++e)
                     r[e] = pnp_drop_keep((uint32_t)(i * 4 + e), a.drop_key, a.drop_thresh) ? r[e] * a.drop_scale : 0.f;
             }
-            st4(a.dx + i * 4, r);
+            if (a.dx) st4(a.dx + i * 4, r);       // (null: only the bf16 copy is wanted — dx feeds nothing but resident convolutions)
+            if (a.dxh) st4h(a.dxh + i * 4, r);
         } else {
             const int c = cv;
             float g = a.dout[i];
@@ -441,23 +453,28 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(BnBwdArgs a) {
                 r = a.gamma[c] * rs * g;
             }
             if (a.do_drop) r = pnp_drop_keep((uint32_t)i, a.drop_key, a.drop_thresh) ? r * a.drop_scale : 0.f;
-            a.dx[i] = r;
+            if (a.dx) a.dx[i] = r;
+            if (a.dxh) a.dxh[i] = (__bf16)r;
         }
     }
 }
 
 __global__ void __launch_bounds__(NT) dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
-                                                     uint32_t key, uint32_t thresh, float scale) {
+                                                     uint32_t key, uint32_t thresh, float scale, __bf16* __restrict__ yh) {
     const size_t gs = (size_t)gridDim.x * NT;
     const size_t n4 = n >> 2;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += gs) {
         f32x4 v = ld4(x + i * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = pnp_drop_keep((uint32_t)(i * 4 + e), key, thresh) ? v[e] * scale : 0.f;
-        st4(y + i * 4, v);
+        if (y) st4(y + i * 4, v);
+        if (yh) st4h(yh + i * 4, v);
     }
-    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += gs)
-        y[i] = pnp_drop_keep((uint32_t)i, key, thresh) ? x[i] * scale : 0.f;
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += gs) {
+        const float v = pnp_drop_keep((uint32_t)i, key, thresh) ? x[i] * scale : 0.f;
+        if (y) y[i] = v;
+        if (yh) yh[i] = (__bf16)v;
+    }
 }
 
 __global__ void __launch_bounds__(NT) axpby_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float a,
@@ -771,9 +788,14 @@ int pnp_bn_update_moving(float* moving_mean, float* moving_var, const float* mea
 
 int pnp_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                  const float* shortcut, int32_t Cs, float* y, int64_t P, int32_t C, float eps, float alpha, void* stream) {
+    return pnp_bn_apply_h(x, mean, var, gamma, beta, shortcut, Cs, y, nullptr, P, C, eps, alpha, stream);
+}
+
+int pnp_bn_apply_h(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                   const float* shortcut, int32_t Cs, float* y, void* yh, int64_t P, int32_t C, float eps, float alpha, void* stream) {
     PNP_REQUIRE(x && mean && var && gamma && beta && y && P > 0 && C > 0, "pnp_bn_apply: bad argument");
     if (shortcut) PNP_REQUIRE(Cs > 0 && Cs <= C && ((C - Cs) % 2) == 0, "pnp_bn_apply: bad shortcut channels %d vs %d", Cs, C);
-    BnApplyArgs a{x, mean, var, gamma, beta, shortcut, y, (long long)P, C, shortcut ? Cs : C, eps, alpha};
+    BnApplyArgs a{x, mean, var, gamma, beta, shortcut, y, (long long)P, C, shortcut ? Cs : C, eps, alpha, (__bf16*)yh};
     const bool vec = (C % 4 == 0) && (!shortcut || (Cs % 4 == 0 && ((C - Cs) / 2) % 4 == 0));
     const size_t nvec = (size_t)P * (vec ? C / 4 : C);
     if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(nvec)), dim3(NT), 0, (hipStream_t)stream, a);
@@ -798,7 +820,15 @@ int pnp_bn_bwd_apply(const float* dout, const float* out, const float* x, const 
                      const float* gamma, const float* beta, const float* dgamma, const float* dbeta, float* dx, float* dshortcut, int32_t Cs,
                      int64_t P, int64_t P_norm, int32_t C, float eps, float alpha, int32_t training, float keep_prob,
                      uint64_t seed, uint32_t stream_id, void* stream) {
-    PNP_REQUIRE(dout && x && mean && var && gamma && dx && P > 0 && P_norm >= P && C > 0, "pnp_bn_bwd_apply: bad argument");
+    return pnp_bn_bwd_apply_h(dout, out, x, mean, var, gamma, beta, dgamma, dbeta, dx, nullptr, dshortcut, Cs, P, P_norm, C, eps, alpha,
+                              training, keep_prob, seed, stream_id, stream);
+}
+
+int pnp_bn_bwd_apply_h(const float* dout, const float* out, const float* x, const float* mean, const float* var,
+                       const float* gamma, const float* beta, const float* dgamma, const float* dbeta, float* dx, void* dxh,
+                       float* dshortcut, int32_t Cs, int64_t P, int64_t P_norm, int32_t C, float eps, float alpha, int32_t training,
+                       float keep_prob, uint64_t seed, uint32_t stream_id, void* stream) {
+    PNP_REQUIRE(dout && x && mean && var && gamma && (dx || dxh) && P > 0 && P_norm >= P && C > 0, "pnp_bn_bwd_apply: bad argument");
     PNP_REQUIRE(!training || (dgamma && dbeta), "pnp_bn_bwd_apply: training mode needs the dgamma / dbeta sums");
     PNP_REQUIRE(alpha < 0.f || out || (beta && !dshortcut), "pnp_bn_bwd_apply: a fused activation needs `out`, or beta (and no shortcut) to recompute its sign");
     PNP_REQUIRE((size_t)P * C < (1ull << 32), "pnp_bn_bwd_apply: tensor exceeds 2^32 elements");
@@ -812,6 +842,7 @@ int pnp_bn_bwd_apply(const float* dout, const float* out, const float* x, const 
     a.drop_key = pnp_drop_key(seed, stream_id);
     a.drop_thresh = pnp_drop_thresh(keep_prob);
     a.drop_scale = keep_prob < 1.f ? 1.f / keep_prob : 1.f;
+    a.dxh = (__bf16*)dxh;
     const bool vec = (C % 4 == 0) && (!dshortcut || (Cs % 4 == 0 && ((C - Cs) / 2) % 4 == 0));
     const size_t nvec = (size_t)P * (vec ? C / 4 : C);
     if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(nvec)), dim3(NT), 0, st, a);
@@ -832,6 +863,14 @@ int pnp_bn_bwd_acc(const float* dout, const float* out, const float* x, const fl
                    const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, float* dshortcut,
                    int32_t Cs, int64_t P, int32_t C, float eps, float alpha, int32_t training, float keep_prob, uint64_t seed,
                    uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream) {
+    return pnp_bn_bwd_acc_h(dout, out, x, mean, var, gamma, beta, dx, nullptr, dgamma, dbeta, dgamma_acc, dbeta_acc, dshortcut, Cs, P, C, eps,
+                            alpha, training, keep_prob, seed, stream_id, workspace, workspace_bytes, stream);
+}
+
+int pnp_bn_bwd_acc_h(const float* dout, const float* out, const float* x, const float* mean, const float* var,
+                     const float* gamma, const float* beta, float* dx, void* dxh, float* dgamma, float* dbeta, float* dgamma_acc,
+                     float* dbeta_acc, float* dshortcut, int32_t Cs, int64_t P, int32_t C, float eps, float alpha, int32_t training,
+                     float keep_prob, uint64_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream) {
     PNP_REQUIRE(dout && x && mean && var && dgamma && dbeta && P > 0 && C > 0, "pnp_bn_bwd: bad argument");
     PNP_REQUIRE(alpha < 0.f || out || (gamma && beta && !dshortcut), "pnp_bn_bwd: a fused activation needs `out`, or beta (and no shortcut) to recompute its sign");
     PNP_REQUIRE((size_t)P * C < (1ull << 32), "pnp_bn_bwd: tensor exceeds 2^32 elements");
@@ -842,18 +881,23 @@ int pnp_bn_bwd_acc(const float* dout, const float* out, const float* x, const fl
     if (int e = run_colreduce<1>(ca, dbeta, dgamma, workspace, workspace_bytes, (hipStream_t)stream, "pnp_bn_bwd", nullptr, nullptr, 0.f,
                                  dbeta_acc, dgamma_acc))
         return e;
-    return pnp_bn_bwd_apply(dout, out, x, mean, var, gamma, beta, dgamma, dbeta, dx, dshortcut, Cs, P, P, C, eps, alpha, training, keep_prob,
-                            seed, stream_id, stream);
+    return pnp_bn_bwd_apply_h(dout, out, x, mean, var, gamma, beta, dgamma, dbeta, dx, dxh, dshortcut, Cs, P, P, C, eps, alpha, training,
+                              keep_prob, seed, stream_id, stream);
 }
 
 int pnp_dropout(const float* x, float* y, size_t n, float keep_prob, uint64_t seed, uint32_t stream_id, void* stream) {
-    PNP_REQUIRE(x && y && keep_prob > 0.f, "pnp_dropout: bad argument");
+    PNP_REQUIRE(y, "pnp_dropout: bad argument");
+    return pnp_dropout_h(x, y, nullptr, n, keep_prob, seed, stream_id, stream);
+}
+
+int pnp_dropout_h(const float* x, float* y, void* yh, size_t n, float keep_prob, uint64_t seed, uint32_t stream_id, void* stream) {
+    PNP_REQUIRE(x && (y || yh) && keep_prob > 0.f, "pnp_dropout: bad argument");
     PNP_REQUIRE(n < (1ull << 32), "pnp_dropout: tensor exceeds 2^32 elements");
     if (n == 0) return PNP_OK;
     const float scale = keep_prob < 1.f ? 1.f / keep_prob : 1.f;
     const uint32_t thresh = keep_prob < 1.f ? pnp_drop_thresh(keep_prob) : 0u;
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, (hipStream_t)stream, x, y, n,
-                       pnp_drop_key(seed, stream_id), thresh, scale);
+                       pnp_drop_key(seed, stream_id), thresh, scale, (__bf16*)yh);
     PNP_CHECK_LAUNCH("pnp_dropout");
     return PNP_OK;
 }

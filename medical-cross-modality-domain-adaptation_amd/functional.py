@@ -16,6 +16,7 @@ import os
 import torch
 from torch.autograd import Function
 
+from . import _lib
 from . import gradsink
 from . import kernels as K
 from . import parallel as par
@@ -72,6 +73,8 @@ def _contig(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# bf16 mode: tensors whose only readers are resident convolutions exist only as bf16 (no float32 copy is written)
+BF16_ONLY_H = os.environ.get("PNP_BF16_ONLY_H", "1") != "0"
 # the gradient that reaches a block input through the shortcut is added by the data-gradient kernel of the block's first convolution
 # (pnp_conv2d_dgrad_add) instead of by the autograd engine's elementwise add
 RES_LINK = os.environ.get("PNP_RES_LINK", "1") != "0"
@@ -92,16 +95,45 @@ class ResLink(object):
 
 
 def _wgrad(ctx, x, dy, sink):
-    """filter gradient of a conv call site: into the variable's arena slot when it has one (returns None to the engine)"""
+    """filter gradient of a conv call site: into the variable's arena slot when it has one (returns None to the engine).
+    bf16-resident path (configs[4]): from the bf16 copies of x (kept by the forward) and dy."""
+    g = ctx.geom
+    xh = getattr(ctx, "xh", None)
+    res = xh is not None and K.bf16r(g, 2)
     if sink is not None and sink.grad() is not None:
-        g = ctx.geom
-        K.conv2d_wgrad(x, dy, g, into=sink.grad().view(g.R, g.S, g.C, g.K))
+        into = sink.grad().view(g.R, g.S, g.C, g.K)
+        if res:
+            K.conv2d_wgrad_bf16r(xh, K.bf16_of(dy), g, into=into)
+        else:
+            K.conv2d_wgrad(x, dy, g, into=into)
         gradsink.done(sink)
         return None
-    return K.conv2d_wgrad(x, dy, ctx.geom)
+    return K.conv2d_wgrad_bf16r(xh, K.bf16_of(dy), g) if res else K.conv2d_wgrad(x, dy, g)
 
 
-def _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, keep, seed, sid, beta=None):
+def _dgrad(ctx, dy, w, residual=None):
+    """data gradient of a conv call site (bf16-resident where the geometry is served: filter shadow [tap][C][K], no flip launch)"""
+    g = ctx.geom
+    if K.bf16r(g, 1):
+        return K.conv2d_dgrad_bf16r(K.bf16_of(dy), K.filter_shadows(w)[0], g, residual=residual)[0]
+    return K.conv2d_dgrad(dy, w, g, residual=residual)
+
+
+def _bwd_wants_h(ctx):
+    """does a resident backward kernel of this call site read the bf16 copy of the upstream gradient"""
+    g = ctx.geom
+    return (ctx.needs_input_grad[0] and K.bf16r(g, 1)) or (ctx.needs_input_grad[1] and getattr(ctx, "xh", None) is not None and K.bf16r(g, 2))
+
+
+def _bwd_only_h(ctx):
+    """EVERY consumer of the gradient w.r.t. the conv accumulator is a resident kernel: the BN backward writes only the bf16 copy"""
+    g = ctx.geom
+    dg_ok = (not ctx.needs_input_grad[0]) or K.bf16r(g, 1)
+    wg_ok = (not ctx.needs_input_grad[1]) or (getattr(ctx, "xh", None) is not None and K.bf16r(g, 2))
+    return _bwd_wants_h(ctx) and dg_ok and wg_ok and BF16_ONLY_H
+
+
+def _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, keep, seed, sid, beta=None, want_h=False, only_h=False):
     """backward of BN (+activation, +dropout mask of the conv in front).  With synchronised statistics the per-channel sums are
     all-reduced between the reduction and the apply kernel; the PARAMETER gradients stay local (the GradReducer sums them).
     Returns (dxc, dgamma, dbeta, dsc); dgamma / dbeta are None when they went straight into the variables' gradient slots."""
@@ -113,14 +145,14 @@ def _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, keep, seed, sid, beta
         sums = K.bn_bwd_reduce(dout, out, xc, mean, var, BN_EPS, ctx.alpha, gamma, beta)
         gsums = par.all_sum_(sums.clone())
         dxc, dsc = K.bn_bwd_apply(dout, out, xc, mean, var, gamma, gsums, ctx.P_norm, need_sc, BN_EPS, ctx.alpha, True, keep, seed, sid,
-                                  beta=beta)
+                                  beta=beta, want_h=want_h, only_h=only_h)
         dgamma, dbeta = sums[0], sums[1]
         if slots is not None:                   # (opt-in SyncBN path: two [C]-sized adds)
             K.axpby(dgamma, slots[0], 1.0, 1.0)
             K.axpby(dbeta, slots[1], 1.0, 1.0)
     else:
         dxc, dgamma, dbeta, dsc = K.bn_bwd(dout, out, xc, mean, var, gamma, need_sc, BN_EPS, ctx.alpha, ctx.is_train, keep, seed, sid,
-                                           into=slots, beta=beta)
+                                           into=slots, beta=beta, want_h=want_h, only_h=only_h)
     if slots is not None:
         gradsink.done(sinks[0])
         gradsink.done(sinks[1])
@@ -145,7 +177,14 @@ class Conv2dDropFn(Function):
         """taped: torch.is_grad_enabled() AT THE CALL SITE (gradsink.py: inside forward it is always off)"""
         x = _contig(x)
         w_ = _contig(w)
-        y = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
+        ctx.xh = None
+        if K.bf16r(geom, 0):          # bf16-resident operands (configs[4])
+            xh = K.bf16_of(x)
+            y = K.conv2d_fwd_bf16r(xh, K.filter_shadows(w_)[1], geom, keep_prob, seed, stream_id)[0]
+            if taped and ctx.needs_input_grad[1] and K.bf16r(geom, 2):
+                ctx.xh = xh
+        else:
+            y = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
         ctx.save_for_backward(x, w_)
         ctx.geom, ctx.keep, ctx.seed, ctx.sid = geom, keep_prob, seed, stream_id
         ctx.w_sink = gradsink.use(w_, taped) if ctx.needs_input_grad[1] else None
@@ -156,8 +195,8 @@ class Conv2dDropFn(Function):
         x, w = ctx.saved_tensors
         dy = _contig(dy)
         if ctx.keep < 1.0:
-            dy = K.dropout(dy, ctx.keep, ctx.seed, ctx.sid)
-        dx = K.conv2d_dgrad(dy, w, ctx.geom) if ctx.needs_input_grad[0] else None
+            dy = K.dropout(dy, ctx.keep, ctx.seed, ctx.sid, want_h=_bwd_wants_h(ctx))
+        dx = _dgrad(ctx, dy, w) if ctx.needs_input_grad[0] else None
         dw = _wgrad(ctx, x, dy, ctx.w_sink) if ctx.needs_input_grad[1] else None
         return dx, dw, None, None, None, None, None
 
@@ -179,9 +218,23 @@ class ConvBNActFn(Function):
         _bn_sinks(ctx, gamma, beta, 2, 3, taped)
         # (no tape: no backward pass can follow, whatever the BN parameters' requires_grad says — monitoring forwards of a TRAINABLE net)
         ctx.fused = (not is_train) and FUSE_BN_INFER and (not taped or not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]))
+        # bf16-resident operands (configs[4]): the bf16 copy of x comes from its producer (or one cast), the filter from its shadow
+        res = K.bf16r(geom, 0)
+        ctx.xh = None
+        h_mode = geom.dtype == _lib.DTYPE_BF16          # producers leave a bf16 copy of their output next to the float32 one
+        if res:
+            xh = K.bf16_of(x)
+            w_oi = K.filter_shadows(w_)[1]
+            if taped and ctx.needs_input_grad[1] and K.bf16r(geom, 2):
+                ctx.xh = xh
         if ctx.fused:
             mean, var = _frozen_stats(ctx, moving_mean, moving_var)
-            out = K.conv2d_fwd_bn(x, w_, geom, K.bn_fold(gamma, beta, mean, var, BN_EPS), sc, alpha, keep_prob, seed, stream_id)
+            ss = K.bn_fold(gamma, beta, mean, var, BN_EPS)
+            if res:
+                out, outh, _ = K.conv2d_fwd_bf16r(xh, w_oi, geom, keep_prob, seed, stream_id, want_h=True, bn=(ss, sc, alpha))
+                K.set_bf16(out, outh)
+            else:
+                out = K.conv2d_fwd_bn(x, w_, geom, ss, sc, alpha, keep_prob, seed, stream_id)
             ctx.P_norm = out.numel() // out.shape[-1]
             ctx.save_for_backward(x, w_, out, out, mean, var, gamma)     # the pre-BN tensor is never read in inference mode
             return out
@@ -189,7 +242,10 @@ class ConvBNActFn(Function):
         ctx.P_norm = P
         # training mode on the MFMA kernels: the convolution's epilogue leaves the statistics partials (no second pass over xc)
         parts = None
-        if is_train and FUSE_BN_STATS and K.conv_stats_parts(geom) > 0:
+        if res:
+            xc, _, parts = K.conv2d_fwd_bf16r(xh, w_oi, geom, keep_prob, seed, stream_id, stat_shift=moving_mean,
+                                              want_stats=is_train and FUSE_BN_STATS)
+        elif is_train and FUSE_BN_STATS and K.conv_stats_parts(geom) > 0:
             xc, parts = K.conv2d_fwd_stats(x, w_, geom, moving_mean, keep_prob, seed, stream_id)
         else:
             xc = K.conv2d_fwd(x, w_, geom, keep_prob, seed, stream_id)
@@ -206,9 +262,13 @@ class ConvBNActFn(Function):
             _bump_stat_version(moving_mean, moving_var)
         else:
             mean, var = _frozen_stats(ctx, moving_mean, moving_var)
-        out = K.bn_apply(xc, mean, var, gamma, beta, sc, BN_EPS, alpha)
+        out = K.bn_apply(xc, mean, var, gamma, beta, sc, BN_EPS, alpha, want_h=h_mode)
         # no shortcut: the backward kernels recompute the activation's sign from xc, gamma, beta — `out` is not kept for this unit
         ctx.resign = BN_RECOMPUTE_SIGN and sc is None and alpha >= 0.0
+        # contract of the recomputed sign: gamma / beta / statistics are NOT written between this forward and its backward.  The
+        # optimiser and clip kernels write the arena in place without bumping tensor versions — the weight epoch (bumped by every
+        # weight-writing kernel wrapper) stands in for them and is checked in backward
+        ctx.wepoch = K._WEIGHT_EPOCH[0]
         ctx.save_for_backward(x, w_, xc, beta if ctx.resign else out, mean, var, gamma)
         return out
 
@@ -217,16 +277,22 @@ class ConvBNActFn(Function):
         x, w, xc, out, mean, var, gamma = ctx.saved_tensors
         beta = None
         if getattr(ctx, "resign", False):
+            if ctx.wepoch != K._WEIGHT_EPOCH[0]:
+                raise RuntimeError("parameters were updated (optimiser / clip / load) between a forward pass and its backward pass: the "
+                                   "BN backward recomputes the activation's sign from gamma / beta and would use the NEW values "
+                                   "(set PNP_BN_RECOMPUTE_SIGN=0 for flows that step between forward and backward)")
             out, beta = None, out
         _check_frozen_stats(ctx, mean, var)
         dout = _contig(dout)
         need_sc = ctx.sc_channels if ctx.needs_input_grad[6] else 0
+        want_h = _bwd_wants_h(ctx)          # a resident backward kernel reads dxc as bf16: written by the same BN-backward launch
+        only_h = _bwd_only_h(ctx)           # ... and nobody reads it as float32
         if ctx.fused:
             dxc, dsc = K.bn_bwd_apply(dout, out, out, mean, var, gamma, None, ctx.P_norm, need_sc, BN_EPS, ctx.alpha, False, ctx.keep,
-                                      ctx.seed, ctx.sid)
+                                      ctx.seed, ctx.sid, want_h=want_h, only_h=only_h)
             dgamma = dbeta = None
         else:
-            dxc, dgamma, dbeta, dsc = _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, ctx.keep, ctx.seed, ctx.sid, beta)
+            dxc, dgamma, dbeta, dsc = _bn_bwd(ctx, dout, out, xc, mean, var, gamma, need_sc, ctx.keep, ctx.seed, ctx.sid, beta, want_h, only_h)
         res = None
         if ctx.link is not None:
             if ctx.sc_channels:             # tail of a block: the head's data-gradient kernel adds the shortcut gradient
@@ -234,7 +300,7 @@ class ConvBNActFn(Function):
             else:                           # head of a block
                 res = ctx.link.take()
         if ctx.needs_input_grad[0]:
-            dx = K.conv2d_dgrad(dxc, w, ctx.geom, residual=res)
+            dx = _dgrad(ctx, dxc, w, residual=res)
         else:
             dx = None
         dw = _wgrad(ctx, x, dxc, ctx.w_sink) if ctx.needs_input_grad[1] else None
@@ -363,6 +429,9 @@ class FanOutFn(Function):
 
     @staticmethod
     def forward(ctx, x):
+        # an edge nobody differentiates through hands None to backward (default: a full-size zero fill by the engine plus a pnp_add —
+        # create_first_half always fans out conv4_2, also when no critic consumes it)
+        ctx.set_materialize_grads(False)
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
@@ -376,7 +445,12 @@ def fan_out(x):
     """(x, x) as two autograd edges whose gradients are summed by pnp_add; plain (x, x) where no tape is recorded / on meta tensors"""
     if x.is_meta or not (torch.is_grad_enabled() and x.requires_grad):
         return x, x
-    return FanOutFn.apply(x)
+    a, b = FanOutFn.apply(x)
+    h = getattr(x, "_pnp_h", None)
+    if h is not None and h[1] == x._version:          # the views are the same values: they inherit the bf16 copy
+        K.set_bf16(a, h[0])
+        K.set_bf16(b, h[0])
+    return a, b
 
 
 class WganLossFn(Function):
@@ -415,5 +489,4 @@ def set_conv_dtype(name):
     if name not in ("f32", "bf16"):
         raise ValueError("conv dtype must be 'f32' or 'bf16', got %r" % (name,))
     CONV_DTYPE = name
-    from . import _lib
     K.CONV_DTYPE = _lib.DTYPE_BF16 if name == "bf16" else _lib.DTYPE_F32

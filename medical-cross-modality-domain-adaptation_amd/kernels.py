@@ -166,6 +166,82 @@ def filter_bf16(w, want_io=True, want_oi=True):
     return w_io, w_oi
 
 
+# bf16 copies ("shadows") of tensors the resident convolutions read.  An activation's shadow is written by its producer (yh / dxh side
+# outputs) and travels as an attribute of the tensor OBJECT; a tensor that arrives without one (re-wrapped by a view, produced by a
+# kernel without a bf16 output) is cast on demand.  Filter shadows are cached per filter and weight epoch: every kernel that writes
+# weights (optimisers, clip) and every host-side load bumps the epoch.
+_WEIGHT_EPOCH = [0]
+_filter_cache = {}
+CAST_COUNT = [0]          # on-demand casts since the last reset (tests / profiling: how many producers still lack a bf16 output)
+
+
+def weights_changed():
+    _WEIGHT_EPOCH[0] += 1
+    if len(_filter_cache) > 1024:          # shadows of filters of stores that no longer exist (test suites): start over
+        _filter_cache.clear()
+
+
+class HalfOnly(object):
+    """A tensor that exists ONLY as its bf16 copy (the gradient w.r.t. a convolution's accumulator when both of its consumers — data
+    and filter gradient — are resident kernels: the float32 copy would be written and never read)."""
+    __slots__ = ("h",)
+
+    def __init__(self, h):
+        self.h = h
+
+    @property
+    def shape(self):
+        return self.h.shape
+
+
+def bf16_of(t):
+    if isinstance(t, HalfOnly):
+        return t.h
+    h = getattr(t, "_pnp_h", None)
+    if h is not None and h[1] == t._version and h[0].shape == t.shape:
+        return h[0]
+    CAST_COUNT[0] += 1
+    hh = cast_bf16(t)
+    set_bf16(t, hh)
+    return hh
+
+
+def set_bf16(t, h):
+    if h is not None:
+        t._pnp_h = (h, t._version)
+    return t
+
+
+def filter_shadows(w):
+    """(w_io, w_oi) of an fp32 filter [R,S,C,K], refreshed when the weight epoch has moved"""
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _filter_cache.get(key)
+    if ent is None or ent[0] != _WEIGHT_EPOCH[0]:
+        if ent is None:
+            w_io, w_oi = filter_bf16(w)
+        else:                   # refresh in place: same buffers, no allocation in the steady state
+            w_io, w_oi = ent[1], ent[2]
+            R, S, C, Kc = w.shape
+            check(_lib.load().pnp_filter_bf16(_p(w), _ph(w_io), _ph(w_oi), R, S, C, Kc, _stream()), "pnp_filter_bf16")
+        ent = (_WEIGHT_EPOCH[0], w_io, w_oi)
+        _filter_cache[key] = ent
+    return ent[1], ent[2]
+
+
+_served_cache = {}
+
+
+def bf16r(g, kind):
+    """does the bf16-RESIDENT kernel family serve (geometry, kind) — only asked for geometries whose dtype is PNP_DTYPE_BF16"""
+    if g.dtype != _lib.DTYPE_BF16:
+        return False
+    key = (g.key(), kind)
+    v = _served_cache.get(key)
+    if v is None:
+        v = _served_cache[key] = bf16r_served(g, kind)
+    return v
+
+
 def bf16r_served(g, kind):
     """kind 0 forward / 1 data gradient: do the resident kernels serve this geometry"""
     return bool(_lib.load().pnp_conv2d_bf16r_served(ctypes.byref(g), int(kind)))
@@ -197,6 +273,19 @@ def conv2d_dgrad_bf16r(dyh, w_io, g, residual=None, want_h=False):
     check(lib.pnp_conv2d_dgrad_bf16r(_ph(dyh), _ph(w_io), _p(residual), _p(dx), _ph(dxh), ctypes.byref(g), _stream()),
           "pnp_conv2d_dgrad_bf16r")
     return dx, dxh
+
+
+def conv2d_wgrad_bf16r(xh, dyh, g, into=None):
+    """filter gradient from the bf16 copies of x and dy; `into`: dw is ADDED to it (a slot of the gradient arena)"""
+    lib = _lib.load()
+    nbytes = lib.pnp_conv2d_wgrad_bf16r_workspace_bytes(ctypes.byref(g))
+    ws = workspace(nbytes, xh.device)
+    dw = into if into is not None else torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=xh.device)
+    if tuple(dw.shape) != (g.R, g.S, g.C, g.K):
+        raise ValueError("conv2d_wgrad_bf16r: `into` %s is not the filter shape %s" % (tuple(dw.shape), (g.R, g.S, g.C, g.K)))
+    check(lib.pnp_conv2d_wgrad_bf16r(_ph(xh), _ph(dyh), _p(dw), 1 if into is not None else 0, ctypes.byref(g),
+                                     ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_conv2d_wgrad_bf16r")
+    return dw
 
 
 def conv2d_dgrad(dy, w, g, residual=None):
@@ -234,11 +323,13 @@ def conv2d_wgrad(x, dy, g, into=None):
     return dw
 
 
-def dropout(x, keep_prob, seed, stream_id):
+def dropout(x, keep_prob, seed, stream_id, want_h=False):
+    """want_h: also the bf16 copy of the result (attached as its shadow)"""
     lib = _lib.load()
     y = torch.empty_like(x)
-    check(lib.pnp_dropout(_p(x), _p(y), x.numel(), float(keep_prob), int(seed), int(stream_id), _stream()), "pnp_dropout")
-    return y
+    yh = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_h else None
+    check(lib.pnp_dropout_h(_p(x), _p(y), _ph(yh), x.numel(), float(keep_prob), int(seed), int(stream_id), _stream()), "pnp_dropout")
+    return set_bf16(y, yh)
 
 
 def bn_stats(x2d_like):
@@ -273,41 +364,39 @@ def bn_update_moving(mm, mv, mean, var, P, decay=0.9):
           "pnp_bn_update_moving")
 
 
-def bn_apply(x, mean, var, gamma, beta, shortcut=None, eps=1e-3, alpha=0.2):
+def bn_apply(x, mean, var, gamma, beta, shortcut=None, eps=1e-3, alpha=0.2, want_h=False):
     lib = _lib.load()
     C = x.shape[-1]
     P = x.numel() // C
     y = torch.empty_like(x)
+    yh = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_h else None
     Cs = shortcut.shape[-1] if shortcut is not None else 0
-    check(lib.pnp_bn_apply(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(shortcut), Cs, _p(y), P, C, float(eps),
-                           float(alpha), _stream()), "pnp_bn_apply")
-    return y
+    check(lib.pnp_bn_apply_h(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(shortcut), Cs, _p(y), _ph(yh), P, C, float(eps),
+                             float(alpha), _stream()), "pnp_bn_apply")
+    return set_bf16(y, yh)
 
 
 def bn_bwd(dout, out, x, mean, var, gamma, shortcut_channels=0, eps=1e-3, alpha=0.2, training=True, keep_prob=1.0, seed=0,
-           stream_id=0, into=None, beta=None):
+           stream_id=0, into=None, beta=None, want_h=False, only_h=False):
     """`into` = (dgamma_slot, dbeta_slot): the parameter gradients are also ADDED to these [C] buffers (pnp_bn_bwd_acc).
     out=None (with `beta`, units without a shortcut): the kernels recompute the activation's sign from x instead of reading `out`"""
     lib = _lib.load()
     C = x.shape[-1]
     P = x.numel() // C
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(x) if not only_h else None
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     dsc = None
     if shortcut_channels:
         dsc = torch.empty(x.shape[:-1] + (shortcut_channels,), dtype=torch.float32, device=x.device)
     ws = workspace(lib.pnp_bn_workspace_bytes(P, C), x.device)
-    if into is not None:
-        check(lib.pnp_bn_bwd_acc(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta), _p(into[0]),
-                                 _p(into[1]), _p(dsc), shortcut_channels, P, C, float(eps), float(alpha), 1 if training else 0,
-                                 float(keep_prob), int(seed), int(stream_id), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
-              "pnp_bn_bwd_acc")
-        return dx, dgamma, dbeta, dsc
-    check(lib.pnp_bn_bwd(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta), _p(dsc),
-                         shortcut_channels, P, C, float(eps), float(alpha), 1 if training else 0, float(keep_prob), int(seed),
-                         int(stream_id), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "pnp_bn_bwd")
-    return dx, dgamma, dbeta, dsc
+    dxh = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (want_h or only_h) else None
+    a0, a1 = (into[0], into[1]) if into is not None else (None, None)
+    check(lib.pnp_bn_bwd_acc_h(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(dx), _ph(dxh), _p(dgamma), _p(dbeta), _p(a0),
+                               _p(a1), _p(dsc), shortcut_channels, P, C, float(eps), float(alpha), 1 if training else 0,
+                               float(keep_prob), int(seed), int(stream_id), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+          "pnp_bn_bwd_acc" if into is not None else "pnp_bn_bwd")
+    return (HalfOnly(dxh) if only_h else set_bf16(dx, dxh)), dgamma, dbeta, dsc
 
 
 def bn_bwd_reduce(dout, out, x, mean, var, eps=1e-3, alpha=0.2, gamma=None, beta=None):
@@ -323,20 +412,21 @@ def bn_bwd_reduce(dout, out, x, mean, var, eps=1e-3, alpha=0.2, gamma=None, beta
 
 
 def bn_bwd_apply(dout, out, x, mean, var, gamma, sums, P_norm, shortcut_channels=0, eps=1e-3, alpha=0.2, training=True, keep_prob=1.0,
-                 seed=0, stream_id=0, beta=None):
+                 seed=0, stream_id=0, beta=None, want_h=False, only_h=False):
     """second half of bn_bwd with the (possibly all-reduced) sums and the row count behind them"""
     lib = _lib.load()
     C = x.shape[-1]
     P = x.numel() // C
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(x) if not only_h else None
     dsc = None
     if shortcut_channels:
         dsc = torch.empty(x.shape[:-1] + (shortcut_channels,), dtype=torch.float32, device=x.device)
     dg, db = (sums[0], sums[1]) if sums is not None else (None, None)      # not read in inference mode
-    check(lib.pnp_bn_bwd_apply(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(dg), _p(db), _p(dx), _p(dsc),
-                               shortcut_channels, P, int(P_norm), C, float(eps), float(alpha), 1 if training else 0, float(keep_prob),
-                               int(seed), int(stream_id), _stream()), "pnp_bn_bwd_apply")
-    return dx, dsc
+    dxh = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (want_h or only_h) else None
+    check(lib.pnp_bn_bwd_apply_h(_p(dout), _p(out), _p(x), _p(mean), _p(var), _p(gamma), _p(beta), _p(dg), _p(db), _p(dx), _ph(dxh), _p(dsc),
+                                 shortcut_channels, P, int(P_norm), C, float(eps), float(alpha), 1 if training else 0, float(keep_prob),
+                                 int(seed), int(stream_id), _stream()), "pnp_bn_bwd_apply")
+    return (HalfOnly(dxh) if only_h else set_bf16(dx, dxh)), dsc
 
 
 def maxpool2_fwd(x):
@@ -479,25 +569,38 @@ def bn_from_moments(mom, world):
     return mean, var
 
 
+def _bumps_weights(fn):
+    """a kernel that writes the weight arena: the filters' bf16 shadows are stale afterwards"""
+    def wrapped(*a, **k):
+        weights_changed()
+        return fn(*a, **k)
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
+
+
 def _u8p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+@_bumps_weights
 def adam_step(w, g, m, v, chunk_l2, chunk_mask, lr, beta1, beta2, eps, t):
     check(_lib.load().pnp_adam_step(_p(w), _p(g), _p(m), _p(v), w.numel(), _p(chunk_l2), _u8p(chunk_mask), float(lr), float(beta1),
                                     float(beta2), float(eps), int(t), _stream()), "pnp_adam_step")
 
 
+@_bumps_weights
 def rmsprop_step(w, g, ms, chunk_l2, chunk_mask, lr, decay=0.9, eps=1e-10):
     check(_lib.load().pnp_rmsprop_step(_p(w), _p(g), _p(ms), w.numel(), _p(chunk_l2), _u8p(chunk_mask), float(lr), float(decay),
                                        float(eps), _stream()), "pnp_rmsprop_step")
 
 
+@_bumps_weights
 def momentum_step(w, g, acc, chunk_l2, chunk_mask, lr, momentum):
     check(_lib.load().pnp_momentum_step(_p(w), _p(g), _p(acc), w.numel(), _p(chunk_l2), _u8p(chunk_mask), float(lr),
                                         float(momentum), _stream()), "pnp_momentum_step")
 
 
+@_bumps_weights
 def clip(w, chunk_mask, lo, hi):
     check(_lib.load().pnp_clip(_p(w), w.numel(), _u8p(chunk_mask), float(lo), float(hi), _stream()), "pnp_clip")
 

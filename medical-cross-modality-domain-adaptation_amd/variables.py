@@ -142,6 +142,9 @@ class VariableStore(object):
         else:
             host = np.full(shape, float(init), dtype=np.float32)
         v.tensor = torch.from_numpy(np.ascontiguousarray(host)).to(self.device)
+        if self.device.type == "cuda" and kind == "weight":
+            from . import kernels as K
+            K.weights_changed()      # a new filter may land on the address of a freed one whose bf16 shadow is still cached
         self.vars[name] = v
         return v
 
@@ -171,6 +174,9 @@ class VariableStore(object):
 
         self.arena = pack(tr)
         self.state_arena = pack(st)
+        if self.device.type == "cuda":
+            from . import kernels as K
+            K.weights_changed()      # every filter moved: bf16 shadows cached under the old addresses must not be hit by a later allocation
         self.grad_arena = torch.zeros_like(self.arena)
         for v in tr:
             t = v.tensor.detach()
@@ -245,6 +251,9 @@ class VariableStore(object):
         return OrderedDict((k, v.tensor.detach().cpu().numpy().copy()) for k, v in self.vars.items())
 
     def load_state_dict(self, sd, strict=True):
+        if self.device.type == "cuda":
+            from . import kernels as K
+            K.weights_changed()                # the filters' bf16 shadows (bf16-resident convolutions) are stale after a load
         for k, arr in sd.items():
             if k not in self.vars:
                 if strict:

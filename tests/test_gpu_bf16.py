@@ -191,21 +191,23 @@ def test_joint_step_bf16_within_budget(dev):
             L.prof_summary()
             L.prof_enable(L.PROF_CONV_FWD | L.PROF_CONV_DGRAD | L.PROF_CONV_WGRAD)
             dl = float(net.dis_loss_and_grads(mr, ct, 0.75, drop_seed=11))
+            sc_d = net.miu_dis * sum(float(v.abs().mean()) * (net.lambda_mask_loss if "mask" in k else 1.0) for k, v in net.critic_scores.items())
             g_dis = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if "cls" in v.name}
             lg = net.ct_logits.cpu().clone()
             net.store.load_state_dict(sd)
             gl = float(net.gen_loss_and_grads(ct, 0.75, drop_seed=12))
+            sc_g = net.miu_gen * sum(float(v.abs().mean()) * (net.lambda_mask_loss if "mask" in k else 1.0) for k, v in net.critic_scores.items())
             g_gen = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if v.name.startswith("adapt_")}
             torch.cuda.synchronize()
             L.prof_enable(0)
             names = [r_["name"] for r_ in L.prof_summary() for _ in range(r_["launches"])]
             assert net.store.arena.dtype == torch.float32
-            return dl, gl, lg, g_dis, g_gen, names
+            return dl, gl, lg, g_dis, g_gen, names, sc_d, sc_g
         finally:
             L.prof_enable(0)
             F.set_conv_dtype("f32")
-    d16, g16, lg16, gd16, gg16, names16 = run("bf16")
-    d32, g32, lg32, gd32, gg32, names32 = run("f32")
+    d16, g16, lg16, gd16, gg16, names16, _, _ = run("bf16")
+    d32, g32, lg32, gd32, gg32, names32, sc_d, sc_g = run("f32")
     share = sum("bf16" in n for n in names16) / float(len(names16))
     assert not any("bf16" in n for n in names32) and share > 0.5, share
 
@@ -215,13 +217,17 @@ def test_joint_step_bf16_within_budget(dev):
     c_dis = np.array([cos(gd16[k], gd32[k]) for k in gd32 if float(gd32[k].abs().max()) > 0])
     c_gen = np.array([cos(gg16[k], gg32[k]) for k in gg32 if float(gg32[k].abs().max()) > 0])
     e_lg = _rel(lg16, lg32)
-    print("joint step bf16 vs fp32 (B=2): dis loss %.6e vs %.6e, gen loss %.6e vs %.6e, CT logits %.3e; gradient cosine dis median %.5f "
-          "min %.5f, gen median %.5f min %.5f; %.0f %% of %d conv launches on bf16 kernels" % (
-              d16, d32, g16, g32, e_lg, np.median(c_dis), c_dis.min(), np.median(c_gen), c_gen.min(), 100 * share, len(names16)))
+    print("joint step bf16 vs fp32 (B=2): dis loss %.6e vs %.6e (scale of its terms %.2e), gen loss %.6e vs %.6e (scale %.2e), CT logits %.3e; "
+          "gradient cosine dis median %.5f min %.5f, gen median %.5f min %.5f; %.0f %% of %d conv launches on bf16 kernels" % (
+              d16, d32, sc_d, g16, g32, sc_g, e_lg, np.median(c_dis), c_dis.min(), np.median(c_gen), c_gen.min(), 100 * share, len(names16)))
     assert np.isfinite([d16, g16]).all()
     # bars = ~3x the deviations MEASURED on the GPU (round 3, gpurun_out/r3f): CT logits 6.6e-3, losses 0.55 % / 0.37 %, gradient cosine
     # dis median 0.979 (min 0.950), gen median 0.952 (min 0.905) — operand rounding (2^-9 per operand) through ~50 layers of leaky-ReLU /
     # dropout kinks turns the gradient by a few degrees; it does not change what it points at
     assert 1e-4 < e_lg < 2e-2                                     # the segmenter's budget (tests/test_bf16_budget.py: 1.1e-2 typical)
-    assert abs(d16 - d32) < 0.02 * abs(d32) + 1e-6 and abs(g16 - g32) < 0.02 * abs(g32) + 1e-6
+    # the WGAN losses are DIFFERENCES of mean critic scores (adversarial.py:455-459) over B = 2 samples: a cancelling quantity, so the bar
+    # is taken against the size of the terms, not of their difference — each mean score within 3 % (the critic scores of two correct
+    # bf16 evaluations that differ only in float32 summation order already sit 1-2 % apart at the end of the 50-layer graph: round 4,
+    # tools/experiments/dbg_critic.py)
+    assert abs(d16 - d32) < 0.03 * sc_d + 1e-6 and abs(g16 - g32) < 0.03 * sc_g + 1e-6, (d16, d32, sc_d, g16, g32, sc_g)
     assert np.median(c_dis) > 0.94 and c_dis.min() > 0.85 and np.median(c_gen) > 0.86 and c_gen.min() > 0.75

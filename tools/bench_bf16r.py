@@ -21,9 +21,9 @@ def main():
     dev = torch.device("cuda:0")
     only = os.environ.get("ONLY")
     check = os.environ.get("CHECK", "1") != "0"
-    print("%-18s %8s | %8s %7s %8s %9s | %8s %7s %8s %9s" % ("layer", "GFLOP", "fwd ms", "TF/s", "old ms", "max err", "dgrad ms", "TF/s",
-                                                             "old ms", "max err"))
-    tot = {"f": 0.0, "d": 0.0, "fo": 0.0, "do": 0.0}
+    print("%-18s %8s | %8s %7s %8s %9s | %8s %7s %8s %9s | %8s %7s %8s %9s" % ("layer", "GFLOP", "fwd ms", "TF/s", "old ms", "max err", "dgrad ms",
+                                                                             "TF/s", "old ms", "max err", "wgrad ms", "TF/s", "old ms", "max err"))
+    tot = {"f": 0.0, "d": 0.0, "w": 0.0, "fo": 0.0, "do": 0.0, "wo": 0.0}
     totflop = 0.0
     for name, H, C, Kc, R, dil, padding, cnt, *rest in LAYERS:
         stride = rest[0] if rest else 1
@@ -42,7 +42,7 @@ def main():
         xh, dyh = K.cast_bf16(x), K.cast_bf16(dy)
         w_io, w_oi = K.filter_bf16(w)
         xr, wr, dyr = xh.float(), w.bfloat16().float(), dyh.float()      # the rounded operands as fp32 tensors (test tool: torch casts)
-        for kind in (0, 1):
+        for kind in (0, 1, 2):
             if not K.bf16r_served(g, kind):
                 line += " %8s %7s %8s %9s |" % ("-", "-", "-", "-")
                 continue
@@ -50,29 +50,39 @@ def main():
                 fn = lambda: K.conv2d_fwd_bf16r(xh, w_oi, g, want_h=True)
                 old = lambda: K.conv2d_fwd(x, w, g)
                 ref = lambda: K.conv2d_fwd(xr, wr, gf)
-            else:
+            elif kind == 1:
                 fn = lambda: K.conv2d_dgrad_bf16r(dyh, w_io, g, want_h=True)
                 old = lambda: K.conv2d_dgrad(dy, w, g)
                 ref = lambda: K.conv2d_dgrad(dyr, wr, gf)
+            else:
+                fn = lambda: (K.conv2d_wgrad_bf16r(xh, dyh, g), None)
+                old = lambda: K.conv2d_wgrad(x, dy, g)
+                ref = lambda: K.conv2d_wgrad(xr, dyr, gf)
             err = float("nan")
             if check:
                 out = fn()
                 r = ref()
                 err = float((out[0] - r).abs().max() / r.abs().max())
-                errh = float((out[1].float() - r).abs().max() / r.abs().max())
                 assert err < 2e-5, (name, kind, err)
-                assert errh < 6e-3, (name, kind, errh)       # bf16 copy: 2^-8 relative of the largest value
+                if out[1] is not None:
+                    errh = float((out[1].float() - r).abs().max() / r.abs().max())
+                    assert errh < 6e-3, (name, kind, errh)       # bf16 copy: 2^-8 relative of the largest value
+                if kind == 2:                                    # "add into": twice the gradient
+                    acc = r.clone()
+                    K.conv2d_wgrad_bf16r(xh, dyh, g, into=acc)
+                    assert float((acc - 2 * r).abs().max() / r.abs().max()) < 4e-5, name
             t = timeit(fn, 10)
             to = timeit(old, 5)
             line += " %8.3f %7.1f %8.3f %9.2e |" % (t, flop / t / 1e9, to, err)
-            tot["f" if kind == 0 else "d"] += t * cnt
-            tot["fo" if kind == 0 else "do"] += to * cnt
+            tot["fdw"[kind]] += t * cnt
+            tot["fdw"[kind] + "o"] += to * cnt
         if cnt and K.bf16r_served(g, 0):
             totflop += flop * cnt
         print(line, flush=True)
     if tot["f"] > 0:
-        print("segmenter layers served by the resident kernels: fwd %.2f ms (staged-rounding kernels %.2f), dgrad %.2f (%.2f); fwd %.1f TF/s = "
-              "%.1f%% of %.0f" % (tot["f"], tot["fo"], tot["d"], tot["do"], totflop / tot["f"] / 1e9, 100 * totflop / tot["f"] / 1e9 / PEAK, PEAK))
+        print("segmenter layers served by the resident kernels: fwd %.2f ms (staged-rounding kernels %.2f), dgrad %.2f (%.2f), wgrad %.2f (%.2f); fwd "
+              "%.1f TF/s = %.1f%% of %.0f" % (tot["f"], tot["fo"], tot["d"], tot["do"], tot["w"], tot["wo"], totflop / tot["f"] / 1e9,
+                                              100 * totflop / tot["f"] / 1e9 / PEAK, PEAK))
 
 
 if __name__ == "__main__":
