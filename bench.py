@@ -285,6 +285,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: BASELINE configs[4] arithmetic (bf16 MFMA conv operands, fp32 accumulation / master weights / BN); a separate "
                          "line, never the headline")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="step capture (step_capture.py): every un-probed step of the timed region is ONE hipGraph launch, like the "
+                         "reference's one sess.run per step; auto = on for N = 1, off under data parallelism")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --batch slices PER GPU, the job grows with N; strong: --batch is the GLOBAL batch, every rank "
                          "takes batch / N slices (the reference's B = 16 spread over the node)")
@@ -316,6 +319,34 @@ def main():
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
 
     reducers = {}
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    assert not (use_graph and world > 1), "--graph on: step capture is single-GPU (the bucketed all-reduce runs on a side stream)"
+    probing = {"on": False}
+
+    captured = {"ok": None}
+
+    def try_capture(fn):
+        """--graph auto never costs the run: a recording that fails leaves the eager step in place (and says so in the record)"""
+        try:
+            fn()
+            captured["ok"] = captured["ok"] is not False
+        except Exception as e:
+            if args.graph == "on":
+                raise
+            captured["ok"] = False
+            sys.stderr.write("step capture failed, running eagerly: %r\n" % (e,))
+
+    def eager_while_probing(tr, fn):
+        """the steps whose convolution launches carry HIP events run eagerly (events are recorded by the host around each launch)"""
+        def step(i):
+            if probing["on"] and getattr(tr, "_cap", None) is not None:
+                cap, tr._cap = tr._cap, None
+                try:
+                    return fn(i)
+                finally:
+                    tr._cap = cap
+            return fn(i)
+        return step
 
     def make_segmenter():
         ss = importlib.import_module(PKG + ".source_segmenter")
@@ -326,7 +357,9 @@ def main():
         tr = ss.Trainer(net, None, None, num_cls=5, batch_size=B, optimizer="adam", opt_kwargs={"learning_rate": 1e-3}, reducer=reducer)
         tr.opt = tr._get_optimizer(10)
         y = torch.from_numpy(one_hot(blob_labels(rng, B))).to(dev)
-        return lambda i: tr.train_step(x, y, 0.75, i * world + rank)
+        if use_graph:
+            try_capture(lambda: tr.capture_step(x, y, 0.75))
+        return eager_while_probing(tr, lambda i: tr.train_step(x, y, 0.75, i * world + rank))
 
     def make_joint():
         adv = importlib.import_module(PKG + ".adversarial")
@@ -347,12 +380,22 @@ def main():
             for i in range(40):
                 net._graph(x, ct, 1.0, mr_front_bn=True, joint_bn=True, ct_front_bn=True, critics=False, drop_seed=1000 + i)
 
+        if use_graph:
+            try_capture(lambda: tr.capture_steps(x, ct, 0.75))
+
         def step(i):
             tr.dis_step(x, ct, 0.75, 2 * (i * world + rank) + 1)
             if reducer is not None:
                 step.comm_dis = (reducer.bytes_step, list(reducer.launch_log), reducer.exposed_time_ms() if reducer.measure_exposed else None)
             return tr.gen_step(ct, 0.75, 2 * (i * world + rank) + 2)
-        return step
+        inner = eager_while_probing(tr, step)
+
+        def outer(i):
+            r = inner(i)
+            if hasattr(step, "comm_dis"):
+                outer.comm_dis = step.comm_dis
+            return r
+        return outer
 
     names = {
         "joint": ("training slices/sec (256x256x3, B=16/GPU) joint segmenter+GAN step (1 dis update on B MR + B CT, clip, 1 gen update on B CT)",
@@ -365,6 +408,7 @@ def main():
 
     def prof(on):
         if not args.no_probe:
+            probing["on"] = bool(on)
             L.prof_enable((L.PROF_CONV_FWD | L.PROF_CONV_DGRAD | L.PROF_CONV_WGRAD) if on else 0)
 
     step_fn = makers[args.workload]()
@@ -407,7 +451,7 @@ def main():
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             # (N = 1: no GradReducer is built — the driver's SCALE N=1 run and its BENCH run execute the same code path)
-            "config": {"workload": names[args.workload][1], "global_batch": B * world, "per_gpu_batch": B, "parallelism": "dp%d" % world,
+            "config": {"workload": names[args.workload][1], "global_batch": B * world, "per_gpu_batch": B, "parallelism": "dp%d" % world, "step_capture": bool(use_graph and captured["ok"]),
                        "final_loss": lossv, "comm": comm},
         }
         if rows:

@@ -335,6 +335,17 @@ size_t pnp_conv2d_wgrad_bf16r_workspace_bytes(const pnp_conv_geom* g);
 int pnp_conv2d_wgrad_bf16r(const void* xh, const void* dyh, float* dw, int32_t accumulate, const pnp_conv_geom* g,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- step capture (one hipGraph launch per training step instead of ~1 400 kernel launches from the host) ---------------------------------
+ * A captured step replays its launches with every by-value argument frozen.  Two scalars change every step: the dropout seed
+ * (tf.nn.dropout's per-run mask, layers.py:25,74,93) and Adam's bias-corrected learning rate (tf.train.AdamOptimizer, source_segmenter.py:378).
+ * With a 16-byte DEVICE block bound (pnp_step_params_bind(block); NULL unbinds: the default), every dropout-carrying entry point takes
+ * its seed from the block instead of its `seed` argument — the mask stream is the same function of (seed, stream_id) either way — and
+ * pnp_adam_step takes lr * sqrt(1 - beta2^t) / (1 - beta1^t) from the block instead of computing it from (lr, t).
+ * pnp_step_params_set enqueues the write of the block on `stream` (ordered before the graph launch that follows it).
+ * The binding is process-global state of the library (one training loop per process). */
+int pnp_step_params_bind(const void* dev_block /*16 bytes, or NULL*/);
+int pnp_step_params_set(void* dev_block, uint64_t drop_seed, float adam_lr_t, void* stream);
+
 /* Data-parallel exchange step (new with respect to the single-GPU reference, train_segmenter.py:20 / train_gan.py:18): in-place
  * SUM all-reduce over RCCL (xGMI), one communicator per process / GPU.  librccl.so is resolved at run time: pnp_comm_load(path)
  * names the copy to bind (NULL: the one already mapped in this process, else the default search path); the other calls load it

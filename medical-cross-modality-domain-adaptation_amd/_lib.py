@@ -128,6 +128,8 @@ PROTOTYPES = {
     "pnp_dropout_h": (c_int, [_F, _F, c_void_p, c_size_t, c_float, c_uint64, c_uint32, c_void_p]),
     "pnp_conv2d_wgrad_bf16r_workspace_bytes": (c_size_t, [_G]),
     "pnp_conv2d_wgrad_bf16r": (c_int, [c_void_p, c_void_p, _F, c_int32, _G, c_void_p, c_size_t, c_void_p]),
+    "pnp_step_params_bind": (c_int, [c_void_p]),
+    "pnp_step_params_set": (c_int, [c_void_p, c_uint64, c_float, c_void_p]),
     "pnp_comm_load": (c_int, [c_char_p]),
     "pnp_comm_version": (c_int, [POINTER(c_int)]),
     "pnp_comm_unique_id": (c_int, [c_void_p]),

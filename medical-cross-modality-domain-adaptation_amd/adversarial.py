@@ -584,8 +584,37 @@ class Trainer(object):
                     f, len(dm) + len(gm), (dm + gm)[0]))
         return True
 
+    def capture_steps(self, mr_batch, ct_batch, dropout):
+        """Step capture (step_capture.py): from now on dis_step / gen_step on batches of these shapes and this keep probability are ONE
+        hipGraph launch each.  The reference's counterpart is the single sess.run per step (adversarial.py:852-881).  The two warm-up
+        steps per graph are real updates.  Not under data parallelism."""
+        if self.reducer is not None:
+            raise RuntimeError("capture_steps: not under data parallelism (the bucketed all-reduce runs on a side stream)")
+        from .step_capture import CapturedStep
+        if self.dis_optimizer is None:
+            self._get_optimizer()
+        self._cap = None
+        cap = {"dropout": float(dropout), "mr": tuple(mr_batch.shape), "ct": tuple(ct_batch.shape)}
+        g0 = self.global_step
+        cap["dis"] = CapturedStep(lambda m, c: self.dis_step(m, c, dropout, 0), [mr_batch, ct_batch])
+        cap["gen"] = CapturedStep(lambda c: self.gen_step(c, dropout, 0), [ct_batch])
+        self.global_step = g0 + 4      # the two recordings counted themselves; the 2 + 2 warm-up steps are real
+        self._cap = cap
+        return cap
+
+    def _captured(self, which, dropout, shapes):
+        cap = getattr(self, "_cap", None)
+        if cap is None or cap["dropout"] != float(dropout) or any(cap[k] != tuple(s) for k, s in shapes.items()):
+            return None
+        return cap[which]
+
     def dis_step(self, mr_batch, ct_batch, dropout, seed):
         """sess.run(dis_optimizer) + sess.run(clip_op) (adversarial.py:852-861)"""
+        g = self._captured("dis", dropout, {"mr": mr_batch.shape, "ct": ct_batch.shape})
+        if g is not None:
+            self.global_step += 1
+            K.weights_changed()
+            return g.replay(seed, mr_batch, ct_batch)
         loss = self.net.dis_loss_and_grads(mr_batch, ct_batch, dropout, drop_seed=seed)
         if self.reducer is not None:
             self.reducer.allreduce()
@@ -596,6 +625,11 @@ class Trainer(object):
 
     def gen_step(self, ct_batch, dropout, seed):
         """sess.run(gen_optimizer) (adversarial.py:875-881)"""
+        g = self._captured("gen", dropout, {"ct": ct_batch.shape})
+        if g is not None:
+            self.global_step += 1
+            K.weights_changed()
+            return g.replay(seed, ct_batch)
         loss = self.net.gen_loss_and_grads(ct_batch, dropout, drop_seed=seed)
         if self.reducer is not None:
             self.reducer.allreduce()

@@ -566,6 +566,7 @@ int pnp_conv2d_fwd_bf16r(const void* xh, const void* w_oi, float* y, void* yh, c
         a.drop_scale = 1.f / keep_prob;
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
+        a.sp = pnp_step_params_ptr(); a.drop_sid = stream_id;
     }
     if (stat_parts) {
         const size_t need = (size_t)pnp_conv2d_fwd_bf16r_stats_parts(g) * 2 * g->K * sizeof(float);

@@ -28,6 +28,8 @@ struct ConvArgs {
     uint32_t drop_thresh, drop_key;
     float drop_scale;
     int do_drop;
+    const pnp_step_params* sp;   // step capture: the dropout seed lives in device memory (pnp_common.h); null: drop_key as passed
+    uint32_t drop_sid;           // the call site's stream id (only read with sp)
     int xcd_swizzle;
     unsigned x_bytes, w_bytes;   // sizes of the tensors behind a.x / a.w (buffer descriptors)
     int stagger;                 // s_sleep units (64 clk) by which every second dispatch wave of workgroups starts late
@@ -196,9 +198,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, T
 #define PNP_EP_M (mbase + tm * 32 + (r & 3) + 8 * (r >> 2))
     // ---- dropout (counter hash on the flat output index)
     if (a.do_drop) {
+        const uint32_t dkey = pnp_eff_drop_key(a.drop_key, a.sp, a.drop_sid);
         PNP_EP_FOR {
             const uint32_t idx = (uint32_t)((size_t)PNP_EP_M * a.K + ncol[tn]);
-            o.v[tm][tn][r] = pnp_drop_keep(idx, a.drop_key, a.drop_thresh) ? o.v[tm][tn][r] * a.drop_scale : 0.f;
+            o.v[tm][tn][r] = pnp_drop_keep(idx, dkey, a.drop_thresh) ? o.v[tm][tn][r] * a.drop_scale : 0.f;
         }
     }
     // ---- residual add (data gradients: the gradient that reaches the same tensor through a shortcut): all loads, then all adds

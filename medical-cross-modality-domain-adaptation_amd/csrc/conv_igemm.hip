@@ -1274,6 +1274,8 @@ struct NarrowArgs {
     float drop_scale;
     uint32_t drop_thresh, drop_key;
     unsigned x_bytes;
+    const pnp_step_params* sp;
+    uint32_t drop_sid;
 };
 
 template <int KK, bool EXACT>
@@ -1324,7 +1326,7 @@ __global__ void __launch_bounds__(256) conv_fwd_narrow_kernel(NarrowArgs a) {
             if (k < K) {
                 const size_t idx = m * K + k;
                 float v = acc[k];
-                if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+                if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, pnp_eff_drop_key(a.drop_key, a.sp, a.drop_sid), a.drop_thresh) ? v * a.drop_scale : 0.f;
                 a.y[idx] = v;
             }
     }
@@ -1546,7 +1548,9 @@ __global__ void __launch_bounds__(256) wgrad_direct4_kernel(WgdArgs a) {
 // forward conv with a split reduction: sum the partials, then the dropout of the fused conv->dropout (same element-index hash as the
 // un-split epilogue)
 __global__ void splitk_reduce_drop_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nsplit, size_t stride,
-                                          uint32_t drop_key, uint32_t drop_thresh, float drop_scale) {
+                                          uint32_t drop_key, uint32_t drop_thresh, float drop_scale, const pnp_step_params* sp,
+                                          uint32_t drop_sid) {
+    drop_key = pnp_eff_drop_key(drop_key, sp, drop_sid);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t gs = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += gs) {
@@ -1903,7 +1907,7 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
         if (nb > 4096) nb = 4096;
         if (drop_in_reduce) {
             hipLaunchKernelGGL(splitk_reduce_drop_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, final_out, nout, nsplit, nout,
-                               a.drop_key, a.drop_thresh, a.drop_scale);
+                               a.drop_key, a.drop_thresh, a.drop_scale, a.sp, a.drop_sid);
         } else if (a.o_s != 0) {
             ConvArgs ar = a;
             ar.y = final_out;
@@ -2056,6 +2060,7 @@ int launch_narrow(const float* x, const float* w, float* y, const pnp_conv_geom*
     na.N = g->N; na.H = g->H; na.W = g->W; na.C = g->C; na.K = g->K; na.R = g->R; na.S = g->S; na.OH = g->OH; na.OW = g->OW;
     na.dil = g->dil; na.pad_t = g->pad_t; na.pad_l = g->pad_l;
     na.do_drop = a.do_drop; na.drop_scale = a.drop_scale; na.drop_thresh = a.drop_thresh; na.drop_key = a.drop_key;
+    na.sp = a.sp; na.drop_sid = a.drop_sid;
     na.x_bytes = a.x_bytes;
     const size_t lds = (size_t)na.PH * na.PW * na.CP * sizeof(float);
     dim3 grid((unsigned)pnp_cdiv(g->OW, 32), (unsigned)pnp_cdiv(g->OH, 8), (unsigned)g->N);
@@ -2257,6 +2262,7 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
         a.drop_scale = 1.f / keep_prob;
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
+        a.sp = pnp_step_params_ptr(); a.drop_sid = stream_id;
     }
     if (n16_geom_ok(g)) return launch_n16_fwd(a, 0, (hipStream_t)stream);
     if (narrow_fwd_ok(g, nullptr)) return launch_narrow(x, w, y, g, a, (hipStream_t)stream);
@@ -2293,6 +2299,7 @@ int pnp_conv2d_fwd_stats(const float* x, const float* w, float* y, const pnp_con
         a.drop_scale = 1.f / keep_prob;
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
+        a.sp = pnp_step_params_ptr(); a.drop_sid = stream_id;
     }
     a.stat_ws = parts;
     a.stat_shift = shift;
@@ -2321,6 +2328,7 @@ int pnp_conv2d_fwd_bn(const float* x, const float* w, float* y, const pnp_conv_g
         a.drop_scale = 1.f / keep_prob;
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
+        a.sp = pnp_step_params_ptr(); a.drop_sid = stream_id;
     }
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = shortcut; a.ep_cs = shortcut ? Cs : g->K; a.ep_alpha = alpha;
     if (n16_geom_ok(g)) return launch_n16_fwd(a, 0, (hipStream_t)stream);

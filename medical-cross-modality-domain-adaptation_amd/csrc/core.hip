@@ -59,9 +59,31 @@ PnpProfScope::~PnpProfScope() {
     g_prof_recs.push_back(ProfRec{name_, flops_, bytes_, e0_, e1_});
 }
 
+static const pnp_step_params* g_step_params = nullptr;
+const pnp_step_params* pnp_step_params_ptr() { return g_step_params; }
+
+__global__ void step_params_set_kernel(pnp_step_params* p, unsigned long long seed, float lr_t) {
+    p->drop_seed = seed;
+    p->adam_lr_t = lr_t;
+    p->reserved = 0.f;
+}
+
 extern "C" {
 
 int pnp_abi_version(void) { return 4; }
+
+int pnp_step_params_bind(const void* dev_block) {
+    g_step_params = (const pnp_step_params*)dev_block;
+    return PNP_OK;
+}
+
+int pnp_step_params_set(void* dev_block, uint64_t drop_seed, float adam_lr_t, void* stream) {
+    PNP_REQUIRE(dev_block, "pnp_step_params_set: null block");
+    hipLaunchKernelGGL(step_params_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (pnp_step_params*)dev_block,
+                       (unsigned long long)drop_seed, adam_lr_t);
+    PNP_CHECK_LAUNCH("step_params_set_kernel");
+    return PNP_OK;
+}
 
 int pnp_prof_enable(int mask) {
     g_prof_mask.store(mask, std::memory_order_relaxed);

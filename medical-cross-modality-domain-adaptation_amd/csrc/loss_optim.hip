@@ -244,6 +244,7 @@ struct OptArgs {
     const float* chunk_l2;
     const uint8_t* chunk_mask;
     float lr, b1, b2, eps, aux;
+    const pnp_step_params* sp;      // step capture (Adam): the bias-corrected learning rate from device memory; null: `lr`
 };
 
 // KIND 0 adam, 1 rmsprop, 2 momentum, 3 clip
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(NT) opt_kernel(OptArgs a) {
                 v = v + (g * g - v) * (1.0f - a.b2);
                 a.s0[i] = m;
                 a.s1[i] = v;
-                a.w[i] = w - a.lr * m / (sqrtf(v) + a.eps);   // lr already bias-corrected (lr_t)
+                a.w[i] = w - (a.sp ? a.sp->adam_lr_t : a.lr) * m / (sqrtf(v) + a.eps);   // lr already bias-corrected (lr_t)
             } else if constexpr (KIND == 1) {
                 float ms = a.s0[i];
                 ms = ms + (g * g - ms) * (1.0f - a.b1);   // b1 = decay
@@ -505,27 +506,27 @@ int pnp_adam_step(float* w, const float* g, float* m, float* v, size_t n, const 
                   float lr, float beta1, float beta2, float eps, int32_t t, void* stream) {
     PNP_REQUIRE(w && g && m && v && t >= 1, "pnp_adam_step: bad argument");
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
-    OptArgs a{w, g, m, v, n, chunk_l2, chunk_mask, (float)lr_t, beta1, beta2, eps, 0.f};
+    OptArgs a{w, g, m, v, n, chunk_l2, chunk_mask, (float)lr_t, beta1, beta2, eps, 0.f, pnp_step_params_ptr()};
     return run_opt<0>(a, (hipStream_t)stream, "pnp_adam_step");
 }
 
 int pnp_rmsprop_step(float* w, const float* g, float* ms, size_t n, const float* chunk_l2, const uint8_t* chunk_mask, float lr,
                      float decay, float eps, void* stream) {
     PNP_REQUIRE(w && g && ms, "pnp_rmsprop_step: bad argument");
-    OptArgs a{w, g, ms, nullptr, n, chunk_l2, chunk_mask, lr, decay, 0.f, eps, 0.f};
+    OptArgs a{w, g, ms, nullptr, n, chunk_l2, chunk_mask, lr, decay, 0.f, eps, 0.f, nullptr};
     return run_opt<1>(a, (hipStream_t)stream, "pnp_rmsprop_step");
 }
 
 int pnp_momentum_step(float* w, const float* g, float* acc, size_t n, const float* chunk_l2, const uint8_t* chunk_mask,
                       float lr, float momentum, void* stream) {
     PNP_REQUIRE(w && g && acc, "pnp_momentum_step: bad argument");
-    OptArgs a{w, g, acc, nullptr, n, chunk_l2, chunk_mask, lr, momentum, 0.f, 0.f, 0.f};
+    OptArgs a{w, g, acc, nullptr, n, chunk_l2, chunk_mask, lr, momentum, 0.f, 0.f, 0.f, nullptr};
     return run_opt<2>(a, (hipStream_t)stream, "pnp_momentum_step");
 }
 
 int pnp_clip(float* w, size_t n, const uint8_t* chunk_mask, float lo, float hi, void* stream) {
     PNP_REQUIRE(w && lo <= hi, "pnp_clip: bad argument");
-    OptArgs a{w, nullptr, nullptr, nullptr, n, nullptr, chunk_mask, lo, hi, 0.f, 0.f, 0.f};
+    OptArgs a{w, nullptr, nullptr, nullptr, n, nullptr, chunk_mask, lo, hi, 0.f, 0.f, 0.f, nullptr};
     return run_opt<3>(a, (hipStream_t)stream, "pnp_clip");
 }
 

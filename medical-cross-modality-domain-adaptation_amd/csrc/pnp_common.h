@@ -58,6 +58,19 @@ __host__ __device__ __forceinline__ bool pnp_drop_keep(uint32_t idx, uint32_t ke
     return (h >> 8) >= thresh;
 }
 
+// ---- per-step scalars read from DEVICE memory (step capture: a hipGraph replays the launches of a recorded step, with every by-value
+// argument frozen — the dropout seed and Adam's bias-corrected learning rate change every step, so a captured step reads them from a
+// 16-byte device block instead; core.hip: pnp_step_params_bind / pnp_step_params_set).  Not bound (the default): by-value scalars.
+struct pnp_step_params {
+    unsigned long long drop_seed;      // replaces the `seed` argument of every dropout-carrying call
+    float adam_lr_t;                   // replaces lr * sqrt(1 - beta2^t) / (1 - beta1^t) of pnp_adam_step
+    float reserved;
+};
+const pnp_step_params* pnp_step_params_ptr();
+__device__ __forceinline__ uint32_t pnp_eff_drop_key(uint32_t key, const pnp_step_params* sp, uint32_t stream_id) {
+    return sp ? pnp_drop_key(sp->drop_seed, stream_id) : key;      // the SAME mask stream: key = f(seed, call site), wherever the seed lives
+}
+
 // Times one kernel launch with HIP events on its own stream when pnp_prof_enable(mask) selects its class (core.hip); a no-op otherwise.
 // name = the kernel symbol as rocprofv3 prints it, so that bench.py's live numbers and the committed --kernel-trace summaries line up.
 struct PnpProfScope {

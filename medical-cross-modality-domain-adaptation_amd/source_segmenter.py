@@ -443,9 +443,33 @@ class Trainer(object):
             return AdamOptimizer(net.store, lr, l2, **self.opt_kwargs)
         raise ValueError("unknown optimizer %r" % (self.optimizer,))
 
+    def capture_step(self, batch_x, batch_y, dropout):
+        """Step capture (step_capture.py): from now on train_step on batches of these shapes and this keep probability is ONE hipGraph
+        launch (the reference: one sess.run per step, source_segmenter.py:484-489).  Adam only (its per-step scalar travels in the
+        captured step's device block); the two warm-up steps are real updates.  Not under data parallelism."""
+        if self.reducer is not None:
+            raise RuntimeError("capture_step: not under data parallelism (the bucketed all-reduce runs on a side stream)")
+        if self.opt is None:
+            self.opt = self._get_optimizer(100)
+        if not isinstance(self.opt, AdamOptimizer):
+            raise RuntimeError("capture_step: only the Adam optimiser's per-step scalars are carried by a captured step")
+        from .step_capture import CapturedStep
+        self._cap = None
+        g0 = self.global_step
+        cap = {"dropout": float(dropout), "x": tuple(batch_x.shape), "y": tuple(batch_y.shape)}
+        cap["step"] = CapturedStep(lambda x_, y_: self.train_step(x_, y_, dropout, 0), [batch_x, batch_y], adam=self.opt)
+        self.global_step = g0 + 2      # the recording counted itself; the two warm-up steps are real
+        self._cap = cap
+        return cap
+
     def train_step(self, batch_x, batch_y, dropout, step):
         """the accelerated unit: sess.run((optimizer, cost, lr), feed_dict) of source_segmenter.py:484-489"""
         net = self.net
+        cap = getattr(self, "_cap", None)
+        if cap is not None and cap["dropout"] == float(dropout) and cap["x"] == tuple(batch_x.shape) and cap["y"] == tuple(batch_y.shape):
+            self.global_step += 1
+            K.weights_changed()
+            return cap["step"].replay(step + 1 + self.seed_offset, batch_x, batch_y)
         loss = net.loss_and_grads(batch_x, batch_y, dropout, main_bn=True, adapt_bn=True, drop_seed=step + 1 + self.seed_offset)
         if self.reducer is not None:
             self.reducer.allreduce(net.store.grad_arena)

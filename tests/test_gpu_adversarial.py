@@ -209,7 +209,10 @@ def test_joint_step_B16_vs_float32_oracle(dev):
         # max 3e-2 of max|g| for either side — sign flips at the leaky-ReLU / max-pool / dropout kinks, amplified through 30+ layers), so
         # the pairwise distance is ~sqrt(2) of it and moves with any change of summation order (e.g. BN statistics from the convolution
         # epilogue: measured 0.99988 / 1.1e-2 on the generator path).  The per-kernel 1e-4 pins are tests/test_gpu_teacher_forced.py.
-        lim_cos, lim_med = (0.9999, 1e-2) if tag == "dis" else (0.9997, 3e-2)
+        # The generator path is adjudicated in float64 by tests/test_gpu_teacher_forced_adv.py (B = 16: HIP 5.6e-3 median of max|g| from
+        # float64, the float32 CPU oracle 6.0e-3; HIP <= 1.5 x the oracle's distance, cosine >= 0.9999 asserted there); the pairwise
+        # distance here is at most the sum of the two (measured 1.35e-2 / 0.99984): bars = that sum with 50 % head-room, no looser.
+        lim_cos, lim_med = (0.9999, 1e-2) if tag == "dis" else (0.9998, 2e-2)
         assert min(cs.values()) > lim_cos and np.median(er) < lim_med
     # which variables moved: critics in the dis step (clipped to +-0.03), adapt_* in the gen step, nothing else ever
     for k in sd:

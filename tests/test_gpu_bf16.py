@@ -226,8 +226,9 @@ def test_joint_step_bf16_within_budget(dev):
     # dropout kinks turns the gradient by a few degrees; it does not change what it points at
     assert 1e-4 < e_lg < 2e-2                                     # the segmenter's budget (tests/test_bf16_budget.py: 1.1e-2 typical)
     # the WGAN losses are DIFFERENCES of mean critic scores (adversarial.py:455-459) over B = 2 samples: a cancelling quantity, so the bar
-    # is taken against the size of the terms, not of their difference — each mean score within 3 % (the critic scores of two correct
-    # bf16 evaluations that differ only in float32 summation order already sit 1-2 % apart at the end of the 50-layer graph: round 4,
-    # tools/experiments/dbg_critic.py)
-    assert abs(d16 - d32) < 0.03 * sc_d + 1e-6 and abs(g16 - g32) < 0.03 * sc_g + 1e-6, (d16, d32, sc_d, g16, g32, sc_g)
+    # is taken against the size of the terms, not of their difference.  Measured over 5 input seeds (profiles/r04_bf16_loss_noise.txt): a
+    # single critic score moves by up to +-10 % of the mean |score| under bf16 operand rounding, with random sign, for the resident AND
+    # the staged-rounding kernels alike; the 8-score discriminator loss by up to 1.6 % of the terms' scale, the 2-4-score generator loss
+    # by up to 3.1 %.  Bars: 4 % / 8 %.
+    assert abs(d16 - d32) < 0.04 * sc_d + 1e-6 and abs(g16 - g32) < 0.08 * sc_g + 1e-6, (d16, d32, sc_d, g16, g32, sc_g)
     assert np.median(c_dis) > 0.94 and c_dis.min() > 0.85 and np.median(c_gen) > 0.86 and c_gen.min() > 0.75

@@ -131,6 +131,9 @@ def test_every_kernel_of_every_adaptation_unit_teacher_forced_B16(dev):
     assert abs(float(loss) - float(gen64)) < max(3.0 * abs(float(gen32) - float(gen64)), 1e-4 * abs(float(gen64))) + 1e-8
     # "same error class as another float32 evaluation of the graph": the product may not be further from float64 than a small multiple of
     # what the float32 CPU oracle is (its own distance is pure evaluation-order noise amplified by leaky-ReLU / max-pool / dropout kinks)
-    assert np.median(eh) < 5.0 * np.median(ec) + 1e-4
-    assert eh.max() < max(3.0 * ec.max(), 1e-3)
-    assert min(r[3] for r in rows) > min(0.9999, 1.0 - 3.0 * (1.0 - min(r[4] for r in rows)))
+    # (round 3 measured, MI355X: hip median 5.6e-3 / max 1.5e-2 / min cosine 0.999976; cpu-fp32 6.0e-3 / 1.2e-2 / 0.999959.)  This is THE
+    # whole-step statement for the generator path: the float32-vs-float32 band of test_joint_step_B16_vs_float32_oracle is two such
+    # distances added.
+    assert np.median(eh) < 1.5 * np.median(ec) + 1e-4
+    assert eh.max() < max(2.0 * ec.max(), 1e-3)
+    assert min(r[3] for r in rows) > 0.9999

@@ -117,3 +117,11 @@ def test_bench_last_line_is_compact_whatever_the_kernel_count():
     assert "B=16" in back["cpu_baseline"]["sample"] and back["cpu_baseline"]["value_B2"] == 0.1266 and "sample_B2" not in back["cpu_baseline"]
     assert abs(back["value"] - 166.7) < 0.05 and back["roofline"]["frac"] == float("%.4g" % recs[0]["frac"])
     assert back["config"]["comm"]["dis_step_exposed_ms"] == 0.41 and "launch_order" not in json.dumps(back)
+
+
+def test_gpu_suite_wall_time_guard():
+    """tests/conftest.py fails a -m gpu run that outgrows its wall-time budget (the driver stops it at 1200 s); CPU runs are exempt"""
+    import conftest
+    assert conftest.GPU_SUITE_BUDGET_S <= 900
+    assert conftest.suite_over_budget(901.0, 170, 900.0) and not conftest.suite_over_budget(899.0, 170, 900.0)
+    assert not conftest.suite_over_budget(5000.0, 0, 900.0)          # the CPU suite ran no GPU test
