@@ -352,10 +352,6 @@ bool launch_wgrad_bf16(const ConvArgs& a, int tile, dim3 grid, hipStream_t st);
 constexpr int kWgradBf16rChunk = 64;
 bool launch_wgrad_bf16r(const ConvArgs& a, int tile, dim3 grid, hipStream_t st);
 int wgrad_bf16r_tile(const pnp_conv_geom* g);
-// fp32 filter gradient with LDS-DMA staging (conv_wgrad_dma.hip): same planning (tiles of bm x bn, reduction chunks of BK pixels) as the
-// ring kernel it replaces where the geometry is served
-bool wgrad_dma_ok(const ConvArgs& a, int bm, int bn);
-bool launch_wgrad_dma(const ConvArgs& a, int bm, int bn, dim3 grid, hipStream_t st);
 // 3x3 stride-1 convolutions with exactly 16 output channels and 16 / 32 input channels on the 16x16x4 MFMA (conv_small.hip): forward,
 // data gradient (kind 1; honours res_add) and filter gradient (per-workgroup partials [n16_wgrad_blocks][9*C][16] -> splitk_reduce_many)
 bool n16_geom_ok(const pnp_conv_geom* g);

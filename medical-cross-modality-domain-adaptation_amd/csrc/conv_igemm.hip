@@ -1986,9 +1986,6 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
     if (lin && VECB && a.dtype == PNP_DTYPE_BF16) {
         const bool launched = launch_wgrad_bf16(a, BN == 128 ? 0 : (BN == 64 ? 1 : 2), grid, st);
         PNP_REQUIRE(launched, "conv_wgrad_bf16_kernel: no instance for a %dx%d tile", BM, BN);
-    } else if (VECB && BM == 128 && BN >= 64 && wgrad_dma_ok(a, BM, BN)) {
-        // LDS-DMA staging (conv_wgrad_dma.hip): the LDS image of a stage is the memory image of its 32 pixels
-        PNP_REQUIRE(launch_wgrad_dma(a, BM, BN, grid, st), "conv_wgrad_dma_kernel: no instance for a %dx%d tile", BM, BN);
     } else if (lin_any && VECB && wgrad_ring_depth() > 1) {
         // linear pixel walk with DEPTH global-load stages in flight (PNP_WGRAD_DEPTH = 1: conv_wgrad_kernel MODE 3, one stage in flight)
         const int depth = wgrad_ring_depth();
