@@ -287,7 +287,8 @@ def main():
                          "line, never the headline")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="step capture (step_capture.py): every un-probed step of the timed region is ONE hipGraph launch, like the "
-                         "reference's one sess.run per step; auto = on for N = 1, off under data parallelism")
+                         "reference's one sess.run per step; auto = on for N = 1 with a per-GPU batch <= 4 (where the eager host side is the bound), "
+                         "off otherwise")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --batch slices PER GPU, the job grows with N; strong: --batch is the GLOBAL batch, every rank "
                          "takes batch / N slices (the reference's B = 16 spread over the node)")
@@ -319,7 +320,9 @@ def main():
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
 
     reducers = {}
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    # auto: capture only where the eager host side is the bound (small per-GPU batches; profiles/r04_batch_sweep.json) — at B = 16 a
+    # captured step is no faster and loses the side-stream overlap of the filter gradients (hipGraph replay serialised the branch)
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and args.batch <= 4)
     assert not (use_graph and world > 1), "--graph on: step capture is single-GPU (the bucketed all-reduce runs on a side stream)"
     probing = {"on": False}
 
@@ -406,9 +409,15 @@ def main():
     makers = {"joint": make_joint, "segmenter": make_segmenter}
     other = "segmenter" if args.workload == "joint" else "joint"
 
+    Fn = importlib.import_module(PKG + ".functional")
+    overlap_default = Fn.WGRAD_STREAM
+
     def prof(on):
         if not args.no_probe:
             probing["on"] = bool(on)
+            # a probed step times each convolution launch on its own: no filter gradient next to a data gradient on another stream
+            # (two kernels sharing the chip would each be charged the other's time)
+            Fn.WGRAD_STREAM = overlap_default and not on
             L.prof_enable((L.PROF_CONV_FWD | L.PROF_CONV_DGRAD | L.PROF_CONV_WGRAD) if on else 0)
 
     step_fn = makers[args.workload]()

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
-from .functional import Conv2dDropFn, CriticInputFn, WganLossFn, fan_out
+from .functional import Conv2dDropFn, CriticInputFn, WganLossFn, fan_out, wgrad_overlap
 from .layers import (DR_block, conv2d, conv_bn_relu2d, max_pool2d, residual_block, sharable_weight_variable, weight_variable)
 from .lib import _dice_eval, _label_decomp
 from .ops import PS
@@ -353,7 +353,8 @@ class Full_DRN(object):
         use_mask = lam != 0.0
         loss = WganLossFn.apply(o["ct_cls"], o["mr_cls"], o["ct_mask"] if use_mask else None, o["mr_mask"] if use_mask else None,
                                 (mu, -mu, lam * mu, -lam * mu), 1.0 / self.world_size)
-        loss.backward(self.store.unit_grad(1))
+        with wgrad_overlap():
+            loss.backward(self.store.unit_grad(1))
         self.dis_loss = loss.detach()
         self.ct_logits, self.mr_logits = o["ct_logits"], o["mr_logits"]
         self.critic_scores = {k: o[k].detach() for k in ("ct_cls", "mr_cls", "ct_mask", "mr_mask") if o.get(k) is not None}
@@ -367,7 +368,8 @@ class Full_DRN(object):
         lam, mu = self.lambda_mask_loss, self.miu_gen
         use_mask = lam != 0.0
         loss = WganLossFn.apply(o["ct_cls"], None, o["ct_mask"] if use_mask else None, None, (-mu, 0.0, -lam * mu, 0.0), 1.0 / self.world_size)
-        loss.backward(self.store.unit_grad(1))
+        with wgrad_overlap():
+            loss.backward(self.store.unit_grad(1))
         self.ct_gen_loss = loss.detach()
         self.ct_logits = o["ct_logits"]
         self.critic_scores = {k: o[k].detach() for k in ("ct_cls", "ct_mask") if o.get(k) is not None}

@@ -54,6 +54,11 @@ class Sink(object):
 _SINKS = {}     # data_ptr of the parameter -> Sink
 
 
+def has_ready_hooks():
+    """does any sink announce completed gradients to a data-parallel reducer (then gradients must complete on the compute stream)"""
+    return any(s.ready is not None for s in _SINKS.values())
+
+
 def register(param):
     """param: a leaf tensor whose .grad is (a view of) the buffer the kernels may add into"""
     s = Sink(param)

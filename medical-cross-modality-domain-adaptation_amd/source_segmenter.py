@@ -17,7 +17,7 @@ import torch
 
 from . import kernels as K
 from . import lib
-from .functional import SegLossFn, sync_now
+from .functional import SegLossFn, sync_now, wgrad_overlap
 from .layers import (DR_block, conv2d, conv_bn_relu2d, max_pool2d, pixel_wise_softmax_2, residual_block, weight_variable)
 from .lib import _dice_eval, _indicator_eval, _label_decomp
 from .ops import PS
@@ -257,7 +257,8 @@ class Full_DRN(object):
         self.store.zero_grad()
         logits = self.forward(x, keep_prob, main_bn, adapt_bn, drop_seed)
         lv = self._get_cost(logits, y)
-        lv.backward(self.store.unit_grad(3))      # SegLossFn: element 0 is the root (cost); the upstream gradient is taken to be 1
+        with wgrad_overlap():
+            lv.backward(self.store.unit_grad(3))      # SegLossFn: element 0 is the root (cost); the upstream gradient is taken to be 1
         self.cost, self.weighted_loss, self.dice_loss = lv[0].detach(), lv[1].detach(), lv[2].detach()
         return self.cost
 
