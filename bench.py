@@ -401,9 +401,9 @@ def main():
         return outer
 
     names = {
-        "joint": ("training slices/sec (256x256x3, B=16/GPU) joint segmenter+GAN step (1 dis update on B MR + B CT, clip, 1 gen update on B CT)",
+        "joint": ("training slices/sec (256x256x3, B=%d/GPU) joint segmenter+GAN step (1 dis update on B MR + B CT, clip, 1 gen update on B CT)" % B,
                   "BASELINE configs[3]: train_gan.py --phase train-gan joint step, B=%d/GPU per domain, %s, dropout .75, mask critic on" % (B, args.dtype)),
-        "segmenter": ("training slices/sec (256x256x3, B=16/GPU) segmenter train step (fwd+bwd+Adam)",
+        "segmenter": ("training slices/sec (256x256x3, B=%d/GPU) segmenter train step (fwd+bwd+Adam)" % B,
                       "BASELINE configs[1]: source segmenter fwd+bwd+Adam, B=%d/GPU, 256x256x3, %s, dropout .75, BN train" % (B, args.dtype)),
     }
     makers = {"joint": make_joint, "segmenter": make_segmenter}
