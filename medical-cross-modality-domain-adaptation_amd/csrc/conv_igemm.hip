@@ -1831,8 +1831,20 @@ template <int BM, int BN, int WM, int WN, int KIND>
 bool launch_taps(const ConvArgs& a, dim3 grid, hipStream_t st) {
     // three-stage kernel (conv_taps3_kernel) for the narrow tiles: its channel-group loop runs in pairs for odd tap counts
     static const int env_t3 = getenv("PNP_CONV_TAPS3") ? atoi(getenv("PNP_CONV_TAPS3")) : PNP_TAPS3_DEFAULT;
+    // conv_taps3_kernel contracts channel groups in PAIRS when the tap count is odd (CCU = 2): every reduction split must then hold an
+    // even number of groups — nothing on the device checks it (a clamped, duplicated stage would be contracted past cc_end), so the
+    // condition is stated here per split, not inferred from the planner (round-3 advisor finding)
     const int cc_per = a.chunks_per_split / (a.R * a.S);
-    const bool t3 = env_t3 && BN <= 64 && ((a.R * a.S) % 2 == 0 || (cc_per % 2 == 0 && (a.nsplit == 1 || (a.C / BK) % cc_per == 0)));
+    bool pairs_ok = (a.R * a.S) % 2 == 0;
+    if (!pairs_ok && cc_per > 0) {
+        pairs_ok = true;
+        const int ncc = a.C / BK;
+        for (int z = 0; z < a.nsplit; ++z) {
+            const int n = (ncc - z * cc_per) < cc_per ? (ncc - z * cc_per) : cc_per;
+            if (n <= 0 || (n & 1)) pairs_ok = false;
+        }
+    }
+    const bool t3 = env_t3 && BN <= 64 && pairs_ok;
 #define PNP_TAPS(RR, SS)                                                                                                   \
     if (a.R == RR && a.S == SS) {                                                                                          \
         if constexpr (BN <= 64 && RR * SS <= 9) {     /* 5x5: 50 unrolled stages per trip and spills — stays on the two-stage kernel */ \

@@ -48,6 +48,13 @@ def sync_now():
 _STAT_VERSION = {}
 
 
+def forget_stat_versions(lo, hi):
+    """a new VariableStore packed its BN statistics into [lo, hi): counters left behind by a dead store whose arena sat at the same
+    addresses must not be inherited (called by VariableStore.finalize — nothing of the new store has a backward pass pending)"""
+    for k in [k for k in _STAT_VERSION if lo <= k < hi]:
+        del _STAT_VERSION[k]
+
+
 def _stat_version(t):
     return _STAT_VERSION.get(t.data_ptr(), 0)
 

@@ -174,6 +174,8 @@ class VariableStore(object):
 
         self.arena = pack(tr)
         self.state_arena = pack(st)
+        from . import functional as F_
+        F_.forget_stat_versions(self.state_arena.data_ptr(), self.state_arena.data_ptr() + self.state_arena.numel() * 4)
         if self.device.type == "cuda":
             from . import kernels as K
             K.weights_changed()      # every filter moved: bf16 shadows cached under the old addresses must not be hit by a later allocation

@@ -106,6 +106,27 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert _rel(slot, slot0 + 2 * dw) < 4e-6
 
 
+def test_odd_channel_group_count_keeps_the_two_stage_kernel(dev):
+    """conv_taps3_kernel walks channel groups in pairs for odd tap counts: a layer with an ODD number of 32-channel groups (C = 96)
+    must stay on conv_taps_kernel (host predicate in launch_taps; nothing on the device would catch a wrong routing) — observed through
+    the profiler's symbol names, and held to the oracle like every other shape"""
+    K, L = pkg("kernels"), pkg("_lib")
+    rng = np.random.default_rng(4)
+    for C, want in ((96, "conv_taps_kernel<"), (64, "conv_taps3_kernel<")):
+        x = rng.standard_normal((16, 32, 32, C)).astype(np.float32)          # 16 384 pixels: no reduction split (a split would pair groups per split)
+        w = (rng.standard_normal((3, 3, C, 64)) * 0.05).astype(np.float32)
+        g = K.conv_geom(x.shape, w.shape, 1, 1, "SAME")
+        xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+        L.prof_summary()
+        L.prof_enable(L.PROF_CONV_FWD)
+        y = K.conv2d_fwd(xd, wd, g)
+        torch.cuda.synchronize()
+        L.prof_enable(0)
+        names = [r["name"] for r in L.prof_summary()]
+        assert names and all(n.startswith(want) for n in names), (C, names)
+        assert _rel(y, T.conv2d(torch.from_numpy(x), torch.from_numpy(w), 1, 1, "SAME")) < TOL
+
+
 def test_conv_transpose_detecting(dev):
     """A = identity-like input with ASYMMETRIC weights: catches row/col swaps in the MFMA C/D mapping"""
     K = pkg("kernels")

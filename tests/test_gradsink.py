@@ -132,3 +132,26 @@ def test_high_low_float_pairs_carry_a_double_sum():
         hb = np.float32(big)
         lb = np.float32(0.0) if not np.isfinite(hb) else np.float32(big - np.float64(hb))      # the kernel's guard
     assert np.isinf(hb) and np.float64(hb) + np.float64(lb) == np.inf
+
+
+def test_bn_statistics_versions_are_forgotten_when_a_new_store_takes_the_addresses():
+    """functional._STAT_VERSION is keyed by the address of a moving-statistics buffer; a store that dies leaves its counters behind and
+    the next store's arena may land on the same addresses (round-3 review): finalize() drops every counter inside the new arena."""
+    F = pkg("functional")
+    F._STAT_VERSION.clear()
+    F._STAT_VERSION.update({1000: 3, 1016: 1, 5000: 7})
+    F.forget_stat_versions(1000, 1020)
+    assert F._STAT_VERSION == {5000: 7}
+    variables = pkg("variables")
+    st = variables.VariableStore("cpu", seed=0)
+    mm = st.get("bn/moving_mean", (8,), 0.0, False, "bn_stat")
+    st.get("w", (3, 3, 4, 8), 0.5, True, "weight")
+    st.finalize()
+    base = st.state_arena.data_ptr()
+    assert st.vars["bn/moving_mean"].tensor.data_ptr() == base
+    F._STAT_VERSION[base] = 9                       # as if a dead store had bumped a buffer at this address
+    st2 = variables.VariableStore("cpu", seed=0)
+    st2.get("bn/moving_mean", (8,), 0.0, False, "bn_stat")
+    st2.finalize()
+    assert st2.state_arena.data_ptr() not in F._STAT_VERSION
+    F._STAT_VERSION.clear()

@@ -15,7 +15,7 @@ timeout 600 python bench.py --workload segmenter --no-sub > $O/bench_segmenter_n
 timeout 600 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16_n1.json 2>/dev/null
 [ -z "$FAST" ] && timeout 600 python bench.py --dtype bf16 --batch 32 --no-cpu-baseline --no-sub > $O/bench_bf16_B32_n1.json 2>/dev/null
 # kernel traces (rocprofv3 --kernel-trace --stats), same command lines as the bench
-B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub"
+B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub --graph off"
 timeout 420 rocprofv3 --kernel-trace --stats -d $O/prof_joint -o joint -- $B > $O/bench_prof_joint.json 2>/dev/null
 timeout 420 rocprofv3 --kernel-trace --stats -d $O/prof_seg -o seg -- $B --workload segmenter > $O/bench_prof_seg.json 2>/dev/null
 [ -z "$FAST" ] && timeout 420 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o bf16 -- $B --dtype bf16 > $O/bench_prof_bf16.json 2>/dev/null
@@ -30,6 +30,7 @@ head -12 $O/joint_kernel_stats.txt | cut -c1-170
 # per-layer tables
 timeout 300 python tools/bench_conv.py > $O/conv_layers_f32.txt 2>/dev/null
 DTYPE=bf16 timeout 300 python tools/bench_conv.py > $O/conv_layers_bf16.txt 2>/dev/null
+timeout 400 python tools/bench_bf16r.py > $O/conv_layers_bf16r.txt 2>/dev/null       # the bf16-RESIDENT kernels next to the staged-rounding ones
 if [ -z "$FAST" ]; then
 python tools/e2e_segmenter.py 2>&1 | grep "E2E" > $O/e2e.txt; cat $O/e2e.txt
 timeout 400 python tools/e2e_gan.py 2>&1 | grep "E2E" > $O/e2e_gan.txt; cat $O/e2e_gan.txt
@@ -58,19 +59,20 @@ pmc() {   # pmc <outdir> <prefix> <counters...> -- <command...>
   timeout -k 10 240 rocprofv3 --pmc "${ctr[@]}" --kernel-trace --output-format csv -d $d -o $o -- "$@" > /dev/null 2>&1
   local rc=$?; if [ $rc -ge 124 ]; then echo "PMC pass $d timed out (rc $rc): skipping the remaining passes"; PMC_OK=0; fi
 }
-P1="python bench.py --steps 2 --warmup 1 --no-probe --no-cpu-baseline --no-sub"
+P1="python bench.py --steps 2 --warmup 1 --no-probe --no-cpu-baseline --no-sub --graph off"
 pmc $O/pmc_fetch f FETCH_SIZE -- $P1
 pmc $O/pmc_write w WRITE_SIZE -- $P1
 pmc $O/pmc_sq s GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES -- $P1
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_counters.json > /dev/null 2>$O/pmc_summary.err; tail -2 $O/pmc_summary.err
-# bf16 symbols (configs[4]): HBM traffic + matrix-pipe utilisation
-PB="$P1 --dtype bf16"
+# bf16 symbols (configs[4]): HBM traffic + matrix-pipe utilisation (B=32: the configs[4] per-GPU batch — at B=16 the 256x128 tiles of
+# the 32^2 layers are exactly one dispatch round)
+PB="$P1 --dtype bf16 --graph off"
 pmc $O/pmc_bf16_fetch f FETCH_SIZE -- $PB
 pmc $O/pmc_bf16_write w WRITE_SIZE -- $PB
 pmc $O/pmc_bf16_sq s GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES -- $PB
 python tools/pmc_summary.py $O/pmc_bf16_fetch $O/pmc_bf16_write $O/pmc_bf16_sq $O/bf16_pmc_counters.json > /dev/null 2>>$O/pmc_summary.err
 # instruction mix (segmenter workload): a pass with an unknown counter name just fails
-PS="python bench.py --workload segmenter --steps 2 --warmup 1 --no-probe --no-cpu-baseline --no-sub"
+PS="python bench.py --workload segmenter --steps 2 --warmup 1 --no-probe --no-cpu-baseline --no-sub --graph off"
 pmc $O/pmc_seg_sq s GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES -- $PS
 pmc $O/pmc_seg_insts i SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES -- $PS
 pmc $O/pmc_seg_insts2 j SQ_INST_CYCLES_VMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA -- $PS
