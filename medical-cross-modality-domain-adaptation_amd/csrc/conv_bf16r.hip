@@ -45,7 +45,7 @@ __device__ __forceinline__ int swz(int row) {
     return BKC == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
 }
 
-template <int BM, int BN, int WM, int WN, int BKC, int KIND, int R, int S, int NBUF>
+template <int BM, int BN, int WM, int WN, int BKC, int KIND, int R, int S, int NBUF, int ILV = 1>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (NBUF * (BM + BN) * BKC * 2 <= 80 * 1024 ? 2 : 1)))
     conv_bf16r_kernel(ConvArgs a) {
     constexpr int NTAP = R * S;
@@ -166,12 +166,77 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (NBUF * (BM 
     // stage j: its DMA was issued NBUF - 1 stages ago.  Own loads landed (counted vmcnt: the NBUF - 2 younger stages stay in flight), own
     // fragment reads of stage j - 1 retired (lgkmcnt), barrier: now EVERY wave's part of stage j is in LDS and nobody reads buffer
     // (j - 1) % NBUF any more — refill it with stage j + NBUF - 1, then contract stage j.
-    auto stage = [&](int d) {
+    // ILV = 1 (the default; ILV = 0 is the first version, kept for A/B builds): the DMA pieces of the stage being fetched are issued
+    // BETWEEN the MFMAs of the stage being contracted (one piece costs the wave 60-150 issue cycles — MI355X_MICROARCH.md — and with all
+    // pieces in front of the MFMAs both waves of a SIMD, released by the same barrier, issue pieces at the same time and leave the matrix
+    // pipe idle), and the fragments of slice ks + 1 are read under the MFMAs of slice ks.  sched_group_barrier pins the order; the
+    // address arithmetic of the pieces floats.  Within-run A/B x2 at B = 16: 512->512 998 -> 1063-1073 TF/s, g10 data gradient 691 -> 787,
+    // cls2 128->128@128^2 795 -> 852, cls3 256->256@64^2 930 -> 998.
+    auto stage_ilv = [&](int d) {
         wait_vm<(NBUF - 2) * LPS>();
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();
-        issue((d + NBUF - 1) % NBUF);
-        compute(d);
+        const int nb = (d + NBUF - 1) % NBUF;
+        unsigned char* base = lds + nb * STG + wave * (RPI * ROWB);
+        const int tr = l_tap / S, ts = l_tap - tr * S;
+        const int tshift = ((tr * a.dil * a.W + ts * a.dil) * a.C) * 2;
+        const int sa = l_cc * (BKC * 2);
+        const int teff = (KIND == 1) ? (NTAP - 1 - l_tap) : l_tap;
+        const int sb = teff * tapKC + l_cc * (BKC * 2);
+        auto piece = [&](int i) {
+            if (i < NRA) {
+                const unsigned vo = ((amask[i] >> l_tap) & 1u) ? (unsigned)(abase[i] + tshift) : OOB2;
+                dma16(rx, (lds_void*)(base + i * (RPP * ROWB)), vo, sa);
+            } else {
+                dma16(rw, (lds_void*)(base + BM * ROWB + (i - NRA) * (RPP * ROWB)), bvo[i - NRA], sb);
+            }
+        };
+        const unsigned char* A = lds + d * STG + wm0 * ROWB;
+        const unsigned char* B = lds + d * STG + BM * ROWB + wn0 * ROWB;
+        bf16x8 af[2][TM], bfr[2][TN];
+        auto rd = [&](int s_, int ks) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[s_][tm] = *reinterpret_cast<const bf16x8*>(A + tm * (32 * ROWB) + foff[ks]);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bfr[s_][tn] = *reinterpret_cast<const bf16x8*>(B + tn * (32 * ROWB) + foff[ks]);
+        };
+        rd(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) rd((ks + 1) & 1, ks + 1);
+            const int p0 = (ks * LPS) / KS, p1 = ((ks + 1) * LPS) / KS;        // pieces issued under this slice
+            int mi = 0;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][tm], bfr[ks & 1][tn], acc.v[tm][tn], 0, 0, 0);
+                    const int pi = p0 + mi;
+                    if (pi < p1) piece(pi);
+                    ++mi;
+                }
+            if (ks + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+            for (int m = 0; m < TM * TN; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (p0 + m < p1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        const int wrap = (l_tap + 1 == NTAP) ? 1 : 0;
+        l_tap = wrap ? 0 : l_tap + 1;
+        l_cc = min(l_cc + wrap, ncc - 1);
+    };
+    auto stage = [&](int d) {
+        if constexpr (ILV != 0) {
+            stage_ilv(d);
+        } else {
+            wait_vm<(NBUF - 2) * LPS>();
+            wait_lgkm0();
+            __builtin_amdgcn_s_barrier();
+            issue((d + NBUF - 1) % NBUF);
+            compute(d);
+        }
     };
 #pragma unroll
     for (int d = 0; d < NBUF - 1; ++d) issue(d);
@@ -205,6 +270,18 @@ __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
     return s16x4{};
 #endif
 }
+__device__ __forceinline__ s16x4 lds_tr16_asm(unsigned lds_byte_addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_byte_addr));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
 template <int CPR>
 __device__ __forceinline__ int swz_px(int row) {
     return CPR == 16 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2);
@@ -225,6 +302,7 @@ __global__ void __launch_bounds__(256, (NBUF * (BM + BN) * 128 <= 80 * 1024 ? 2 
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int ASZ = BKP * ROWA, STG = BKP * (ROWA + ROWB_);
     static_assert(NBUF >= 2 && (NBUF - 2) * LPS < 64, "vmcnt is a 6-bit counter");
+    static_assert(2 * (TM + TN) < 16, "lgkmcnt is a 4-bit counter");
     __shared__ __attribute__((aligned(256))) unsigned char lds[NBUF * STG];
 
     const int t = threadIdx.x;
@@ -304,34 +382,85 @@ __global__ void __launch_bounds__(256, (NBUF * (BM + BN) * 128 <= 80 * 1024 ? 2 
     }
     Acc<TM, TN> acc;
     acc.zero();
-    auto compute = [&](int buf) {
-        const unsigned char* A = lds + buf * STG;
-        const unsigned char* B = lds + buf * STG + ASZ;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 af[TM], bfr[TN];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const s16x4 lo = lds_tr16(A + (ks * 16) * ROWA + foffA[tm]), hi = lds_tr16(A + (ks * 16 + 4) * ROWA + foffA[tm]);
-                af[tm] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const s16x4 lo = lds_tr16(B + (ks * 16) * ROWB_ + foffB[tn]), hi = lds_tr16(B + (ks * 16 + 4) * ROWB_ + foffB[tn]);
-                bfr[tn] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc.v[tm][tn], 0, 0, 0);
-        }
-    };
+    // the DMA pieces of the stage being fetched go BETWEEN the MFMAs of the stage being contracted, fragments one slice ahead (see
+    // conv_bf16r_kernel's stage_ilv)
     auto stage = [&](int d) {
         wait_vm<(NBUF - 2) * LPS>();
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();
-        issue((d + NBUF - 1) % NBUF);
-        compute(d);
+        const int nb = (d + NBUF - 1) % NBUF;
+        unsigned char* baseA = lds + nb * STG + wave * (RPIA * ROWA);
+        unsigned char* baseB = lds + nb * STG + ASZ + wave * (RPIB * ROWB_);
+        const int p0_ = l_chunk * BKP;
+        const int sb = (l_chunk - c_begin) * (BKP * a.K * 2);
+        auto piece = [&](int i) {
+            if (i < NRA) {
+                const int p = p0_ + arow[i];
+                const int n = p >> a.ohw_sh;
+                const int oh = (p >> a.ow_sh) & (a.OH - 1), ow = p & (a.OW - 1);
+                const int ih = oh * a.stride + dh, iw = ow * a.stride + dw;
+                const bool ok = (p < P) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+                const unsigned vo = ok ? (unsigned)((((n * a.H + ih) * a.W + iw) * a.C) * 2 + acol[i]) : OOB2;
+                dma16(rx, (lds_void*)(baseA + i * (NW * RPIA * ROWA)), vo, 0);
+            } else {
+                const int j = i - NRA;
+                dma16(rw, (lds_void*)(baseB + j * (NW * RPIB * ROWB_)), (p0_ + brow[j] < P) ? bvo[j] : OOB2, sb);
+            }
+        };
+        // Fragment reads are INLINE ASM: behind an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr builtin
+        // (it does not for plain LDS loads) — the first version of this kernel therefore waited for the stage it had just requested
+        // before contracting the current one.  An asm read is invisible to the waitcnt pass, so the waits are counted by hand: the
+        // 2 (TM + TN) reads of slice ks + 1 may be outstanding when slice ks is contracted (LDS returns in order), and a full scheduling
+        // barrier behind each wait keeps the MFMAs from being hoisted above it.
+        const unsigned abase_ = lds_addr(lds) + d * STG, bbase_ = lds_addr(lds) + d * STG + ASZ;
+        s16x4 alo[2][TM], ahi[2][TM], blo[2][TN], bhi[2][TN];
+        auto rd = [&](int s_, int ks) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                alo[s_][tm] = lds_tr16_asm(abase_ + foffA[tm] + (ks * 16) * ROWA);
+                ahi[s_][tm] = lds_tr16_asm(abase_ + foffA[tm] + (ks * 16 + 4) * ROWA);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                blo[s_][tn] = lds_tr16_asm(bbase_ + foffB[tn] + (ks * 16) * ROWB_);
+                bhi[s_][tn] = lds_tr16_asm(bbase_ + foffB[tn] + (ks * 16 + 4) * ROWB_);
+            }
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+                rd((ks + 1) & 1, ks + 1);
+                wait_lgkm<2 * (TM + TN)>();
+            } else {
+                wait_lgkm<0>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int q0 = (ks * LPS) / KS, q1 = ((ks + 1) * LPS) / KS;        // pieces issued under this slice
+            int mi = 0;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo[ks & 1][tm], ahi[ks & 1][tm], 0, 1, 2, 3, 4, 5, 6, 7));
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo[ks & 1][tn], bhi[ks & 1][tn], 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc.v[tm][tn], 0, 0, 0);
+                    // piece j of this slice's n goes behind MFMA floor(j * m / n) of its m (8 pieces per 16 MFMAs on the 128 x 128 tile)
+#pragma unroll
+                    for (int j = 0; j < q1 - q0; ++j)
+                        if ((j * TM * TN) / (q1 - q0) == mi) piece(q0 + j);
+                    ++mi;
+                }
+#pragma unroll
+            for (int m = 0; m < TM * TN; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                for (int j = 0; j < q1 - q0; ++j)
+                    if ((j * TM * TN) / (q1 - q0) == m) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        l_chunk = min(l_chunk + 1, nchunks_total);
     };
     if (nst > 0) {
 #pragma unroll
