@@ -113,13 +113,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (NBUF * (BM 
     const int nst = ncc * NTAP;
     int l_cc = 0, l_tap = 0;            // (channel group, tap) of the next stage to fetch: uniform
     const int tapKC = a.K * a.C * 2;     // bytes per tap of the filter shadow
+    // which tap of the filter SHADOW stage tap (tr, ts) reads: forward the same one; data gradient the filter walked in reverse
+    // (correlation -> convolution); a stride phase its sub-filter's tap inside the full filter (ConvArgs::ph_*)
+    auto tap_eff = [&](int tap, int tr, int ts) {
+        if (KIND == 1 && a.ph_st) return (a.ph_pa + a.ph_st * (R - 1 - tr)) * a.ph_S + a.ph_pb + a.ph_st * (S - 1 - ts);
+        return (KIND == 1) ? (NTAP - 1 - tap) : tap;
+    };
     auto issue = [&](int buf) {
         unsigned char* base = lds + buf * STG + wave * (RPI * ROWB);
         const int tr = l_tap / S, ts = l_tap - tr * S;
         const int tshift = ((tr * a.dil * a.W + ts * a.dil) * a.C) * 2;
         const int sa = l_cc * (BKC * 2);
-        const int teff = (KIND == 1) ? (NTAP - 1 - l_tap) : l_tap;       // data gradient: the filter is walked in reverse (correlation -> convolution)
-        const int sb = teff * tapKC + l_cc * (BKC * 2);
+        const int sb = tap_eff(l_tap, tr, ts) * tapKC + l_cc * (BKC * 2);
 #pragma unroll
         for (int i = 0; i < NRA; ++i) {
             const unsigned vo = ((amask[i] >> l_tap) & 1u) ? (unsigned)(abase[i] + tshift) : OOB2;
@@ -181,8 +186,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (NBUF * (BM 
         const int tr = l_tap / S, ts = l_tap - tr * S;
         const int tshift = ((tr * a.dil * a.W + ts * a.dil) * a.C) * 2;
         const int sa = l_cc * (BKC * 2);
-        const int teff = (KIND == 1) ? (NTAP - 1 - l_tap) : l_tap;
-        const int sb = teff * tapKC + l_cc * (BKC * 2);
+        const int sb = tap_eff(l_tap, tr, ts) * tapKC + l_cc * (BKC * 2);
         auto piece = [&](int i) {
             if (i < NRA) {
                 const unsigned vo = ((amask[i] >> l_tap) & 1u) ? (unsigned)(abase[i] + tshift) : OOB2;
@@ -520,7 +524,8 @@ __global__ void __launch_bounds__(256) filter_bf16_kernel(const float* __restric
 }
 
 // ---------------------------------------- host side ----------------------------------------------
-constexpr bool r_shape(int kind, int R, int S) { return (R == 3 && S == 3) || (kind == 0 && R == 5 && S == 5); }
+constexpr bool r_shape(int kind, int R, int S) { return (R == 3 && S == 3) || (R == 5 && S == 5 && kind == 0); }
+bool strided_dgrad_served(const pnp_conv_geom* g);
 
 // tile plan: 0 = 256x128 (8 waves, 3 LDS stages), 1 = 128x128 (4 waves, 2 stages), 2 = 128x64 (4 waves, 3 stages); -1: not served
 int plan_tile(long long M, int K) {
@@ -550,6 +555,9 @@ int launch_tile(ConvArgs& a, hipStream_t st) {
     }
     PNP_R(3, 3)
     if constexpr (KIND == 0) { PNP_R(5, 5) }
+    if constexpr (KIND == 1 && BKC == 64) {       // stride-phase sub-filters of the k3 / k5 strided layers
+        PNP_R(1, 1) PNP_R(1, 2) PNP_R(2, 1) PNP_R(2, 2) PNP_R(2, 3) PNP_R(3, 2)
+    }
 #undef PNP_R
     pnp_set_error("conv_bf16r_kernel: no instance for %dx%d", a.R, a.S);
     return PNP_EINVAL;
@@ -569,15 +577,32 @@ int launch_kind(ConvArgs& a, hipStream_t st) {
     return launch_tile<128, 64, 2, 2, 32, KIND, 3>(a, st);
 }
 
+// strided data gradient: one launch per stride phase (conv_igemm.hip's plan_phases), every phase a stride-1 resident convolution over dy
+// with its sub-filter taken out of the full filter shadow.  Served when the phases exist, their sub-filters are instantiated shapes,
+// K (the reduction channels) comes in whole 64-groups and every non-empty phase has >= 4096 pixels.
+bool strided_dgrad_served(const pnp_conv_geom* g) {
+    if (g->K % 64 != 0 || g->C % 64 != 0) return false;
+    DgradPhase ph[16];
+    const int nph = plan_phases(g, ph);
+    if (nph <= 0) return false;
+    for (int i = 0; i < nph; ++i) {
+        if (ph[i].I == 0 || ph[i].J == 0) continue;
+        if (ph[i].T > 3 || ph[i].U > 3 || (ph[i].T == 3 && ph[i].U == 1) || (ph[i].T == 1 && ph[i].U == 3)) return false;
+        if ((long long)g->N * ph[i].I * ph[i].J < 4096) return false;
+    }
+    const long long xin = (long long)g->N * g->H * g->W * g->C, yout = (long long)g->N * g->OH * g->OW * g->K;
+    return xin < (1ll << 30) && yout < (1ll << 30);
+}
+
 // what the resident kernels serve: zero padding, instantiated filter shapes, reduction channels in whole 32-groups, output channels in
 // whole 64-groups, tensors < 2 GiB; data gradient: stride 1 only (the strided ones stay on the stride-phase kernels)
 bool served(const pnp_conv_geom* g, int kind) {
     if (!g || g->pad_mode != PNP_PAD_ZERO) return false;
     static const int off = getenv("PNP_BF16R_OFF") ? 1 : 0;
     if (off) return false;
+    if (kind == 1 && g->stride != 1) return strided_dgrad_served(g);
     const int red = kind == 1 ? g->K : g->C, outc = kind == 1 ? g->C : g->K;
     if (!r_shape(kind, g->R, g->S) || red % 32 != 0 || outc % 64 != 0) return false;
-    if (kind == 1 && g->stride != 1) return false;
     if (kind == 1 && (g->dil * (g->R - 1) < g->pad_t || g->dil * (g->S - 1) < g->pad_l)) return false;
     const long long xin = (long long)g->N * g->H * g->W * g->C, yout = (long long)g->N * g->OH * g->OW * g->K;
     if (xin >= (1ll << 30) || yout >= (1ll << 30)) return false;
@@ -719,6 +744,22 @@ int pnp_conv2d_dgrad_bf16r(const void* dyh, const void* w_io, const float* resid
                            void* stream) {
     PNP_REQUIRE(served(g, 1), "pnp_conv2d_dgrad_bf16r: geometry not served (pnp_conv2d_bf16r_served)");
     PNP_REQUIRE(dyh && w_io && dx && residual != dx, "pnp_conv2d_dgrad_bf16r: bad pointer");
+    if (g->stride != 1) {                   // one resident launch per stride phase, rows scattered with pixel stride `stride`
+        PNP_REQUIRE(!residual && !dxh, "pnp_conv2d_dgrad_bf16r: strided geometry takes neither a residual nor a bf16 output");
+        DgradPhase ph[16];
+        const int nph = plan_phases(g, ph);
+        for (int i = 0; i < nph; ++i) {
+            const DgradPhase& p = ph[i];
+            if (p.I == 0 || p.J == 0) continue;
+            const pnp_conv_geom d = phase_geom(g, p);
+            ConvArgs a = base_args(dyh, w_io, dx, &d);
+            a.w_bytes = (unsigned)((size_t)g->R * g->S * g->C * g->K * 2);      // the FULL filter shadow
+            a.o_s = g->stride; a.o_H = g->H; a.o_W = g->W; a.o_h0 = p.h0; a.o_w0 = p.w0;
+            a.ph_st = g->stride; a.ph_pa = p.pa; a.ph_pb = p.pb; a.ph_S = g->S;
+            if (int e = launch_kind<1>(a, (hipStream_t)stream)) return e;
+        }
+        return PNP_OK;
+    }
     pnp_conv_geom d{};
     d.N = g->N; d.H = g->OH; d.W = g->OW; d.C = g->K; d.K = g->C; d.R = g->R; d.S = g->S;
     d.OH = g->H; d.OW = g->W;

@@ -57,6 +57,10 @@ struct ConvArgs {
     // instead of two integer divisions (~25 VALU each; a 128x64 tile of a 64-channel layer spends ~3 % of its life on them, the
     // scattered epilogue of a stride-phase data gradient far more); -1: divide
     int ow_sh, ohw_sh;
+    // bf16-resident data gradient of ONE stride phase (conv_bf16r.hip): the kernel's R x S taps are the phase's sub-filter, read out of
+    // the FULL filter shadow [tap][C][K]: kernel tap (tr, ts) is full-filter tap (ph_pa + ph_st (R-1-tr), ph_pb + ph_st (S-1-ts)) of a
+    // filter ph_S taps wide.  ph_st = 0: not a phase.
+    int ph_st, ph_pa, ph_pb, ph_S;
     // bf16 copy of the output, [M][K] rows (conv_bf16r.hip: the operand of the NEXT convolution, written by the same epilogue); null: none
     unsigned short* y_h;
 };
@@ -352,6 +356,14 @@ bool launch_wgrad_bf16(const ConvArgs& a, int tile, dim3 grid, hipStream_t st);
 constexpr int kWgradBf16rChunk = 64;
 bool launch_wgrad_bf16r(const ConvArgs& a, int tile, dim3 grid, hipStream_t st);
 int wgrad_bf16r_tile(const pnp_conv_geom* g);
+// stride-phase decomposition of a strided data gradient (conv_igemm.hip): dx[h] only receives taps r = h + pad (mod stride), so each
+// residue class is a stride-1 convolution of dy with a sub-filter, its rows scattered with pixel stride `stride`
+struct DgradPhase {
+    int pa, pb, T, U, h0, w0, I, J, pad_t, pad_l;
+    size_t wt_off;      // float offset of this phase's flipped filter [T][U][K][C] in the workspace (fp32 path)
+};
+int plan_phases(const pnp_conv_geom* g, DgradPhase* ph);
+pnp_conv_geom phase_geom(const pnp_conv_geom* g, const DgradPhase& p);
 // 3x3 stride-1 convolutions with exactly 16 output channels and 16 / 32 input channels on the 16x16x4 MFMA (conv_small.hip): forward,
 // data gradient (kind 1; honours res_add) and filter gradient (per-workgroup partials [n16_wgrad_blocks][9*C][16] -> splitk_reduce_many)
 bool n16_geom_ok(const pnp_conv_geom* g);

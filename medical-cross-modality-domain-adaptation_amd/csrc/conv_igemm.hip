@@ -2140,10 +2140,10 @@ size_t wgrad_ws(const pnp_conv_geom* g) {
 //     dx[h0 + stride*i] = sum_t dy[i + q - t] * W[a + stride*t],   q = (h0 + pad - a) / stride
 // i.e. T = ceil((R-a)/stride) taps, zero padding T-1-q, output scattered with pixel stride `stride`.  The stride^2 phases together
 // perform exactly the useful multiply-adds; the zero-upsampled formulation (KIND 2) multiplies stride^2 - 1 zeros for every product.
-struct DgradPhase {
-    int pa, pb, T, U, h0, w0, I, J, pad_t, pad_l;
-    size_t wt_off;      // float offset of this phase's flipped filter [T][U][K][C] in the workspace
-};
+
+}  // namespace
+
+namespace pnpconv {
 
 // -> number of phases (0: decomposition not applicable, use the zero-upsampled kernel)
 int plan_phases(const pnp_conv_geom* g, DgradPhase* ph) {
@@ -2186,6 +2186,10 @@ pnp_conv_geom phase_geom(const pnp_conv_geom* g, const DgradPhase& p) {
     d.dtype = g->dtype;
     return d;
 }
+
+}  // namespace pnpconv
+
+namespace {
 
 // All phases in one launch (conv_dgrad_phases_kernel) when no single phase fills the chip: the phases' pixel tiles x 64-wide channel
 // tiles together stay under one dispatch round (512 slots).  Needs the general kernel's fast mode (K % 32 == 0 channels of dy) and

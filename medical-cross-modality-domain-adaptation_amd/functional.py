@@ -172,8 +172,10 @@ def _wgrad(ctx, x, dy, sink):
 def _dgrad(ctx, dy, w, residual=None):
     """data gradient of a conv call site (bf16-resident where the geometry is served: filter shadow [tap][C][K], no flip launch)"""
     g = ctx.geom
-    if K.bf16r(g, 1):
+    if K.bf16r(g, 1) and (g.stride == 1 or residual is None):       # (strided: one resident launch per stride phase, no residual input)
         return K.conv2d_dgrad_bf16r(K.bf16_of(dy), K.filter_shadows(w)[0], g, residual=residual)[0]
+    if isinstance(dy, K.HalfOnly):
+        raise RuntimeError("data gradient off the resident kernels got a bf16-only upstream gradient")
     return K.conv2d_dgrad(dy, w, g, residual=residual)
 
 
@@ -186,7 +188,7 @@ def _bwd_wants_h(ctx):
 def _bwd_only_h(ctx):
     """EVERY consumer of the gradient w.r.t. the conv accumulator is a resident kernel: the BN backward writes only the bf16 copy"""
     g = ctx.geom
-    dg_ok = (not ctx.needs_input_grad[0]) or K.bf16r(g, 1)
+    dg_ok = (not ctx.needs_input_grad[0]) or (K.bf16r(g, 1) and (g.stride == 1 or getattr(ctx, "link", None) is None))
     wg_ok = (not ctx.needs_input_grad[1]) or (getattr(ctx, "xh", None) is not None and K.bf16r(g, 2))
     return _bwd_wants_h(ctx) and dg_ok and wg_ok and BF16_ONLY_H
 

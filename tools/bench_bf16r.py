@@ -51,7 +51,7 @@ def main():
                 old = lambda: K.conv2d_fwd(x, w, g)
                 ref = lambda: K.conv2d_fwd(xr, wr, gf)
             elif kind == 1:
-                fn = lambda: K.conv2d_dgrad_bf16r(dyh, w_io, g, want_h=True)
+                fn = lambda: K.conv2d_dgrad_bf16r(dyh, w_io, g, want_h=stride == 1)
                 old = lambda: K.conv2d_dgrad(dy, w, g)
                 ref = lambda: K.conv2d_dgrad(dyr, wr, gf)
             else:
