@@ -531,9 +531,12 @@ bool strided_dgrad_served(const pnp_conv_geom* g);
 int plan_tile(long long M, int K) {
     static const int force = getenv("PNP_BF16R_TILE") ? atoi(getenv("PNP_BF16R_TILE")) : -1;
     if (K % 64 != 0) return -1;
+    // 256 x 128 needs one tile per CU (one workgroup of 8 waves fits), 128 x 128 two per CU, else 128 x 64 — measured with the
+    // interleaved schedule (round 4 tile sweep): 256->256@32^2 630 (128x128, one tile per CU) vs 663 TF/s (128x64), 256->512 data
+    // gradient 674 vs 772, 512->512@16^2 388 / 363 vs 662; whole bf16 joint step, same box x2: 455.5 -> 460.8 slices/s
     int tile;
     if (K % 128 == 0 && pnp_cdiv(M, 256) * (K / 128) >= 256) tile = 0;
-    else if (K % 128 == 0 && pnp_cdiv(M, 128) * (K / 128) >= 256) tile = 1;
+    else if (K % 128 == 0 && pnp_cdiv(M, 128) * (K / 128) >= 512) tile = 1;
     else tile = 2;
     if (force >= 0 && !(force <= 1 && K % 128 != 0)) tile = force;
     return tile;

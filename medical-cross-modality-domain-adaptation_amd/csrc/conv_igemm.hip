@@ -2564,7 +2564,26 @@ static int wgrad_bf16r_plan(const pnp_conv_geom* g, int* bm, int* bn) {
     *bn = (tile & 1) ? 64 : 128;
     const long long P = (long long)g->N * g->OH * g->OW;
     const int nblk = (g->R * g->S * g->C / *bm) * (g->K / *bn);
-    return wgrad_plan_split(nblk, pnp_cdiv(P, kWgradBf16rChunk));
+    static const int force = getenv("PNP_BF16R_WSPLIT") ? atoi(getenv("PNP_BF16R_WSPLIT")) : 0;      // experiments: force the split count
+    if (force > 0) return force;
+    const int nchunks = pnp_cdiv(P, kWgradBf16rChunk);
+    // The resident kernel is ~3x faster than the fp32 ring kernel while a split partial costs the same bytes, so the fp32 planner's
+    // "fill >= one dispatch round of 512" over-splits here (256->256@32^2: 15 splits 0.052 ms, 7 splits 0.048 ms; round 4 sweep,
+    // tools/experiments/README.md).  Cost model, microseconds: dispatch rounds x (stages per workgroup x 0.7 x tile/128^2 + 6 fixed)
+    // + partials written and read back at 4 TB/s; the split with the lowest estimate wins (ties: fewer splits).  Against the fp32
+    // planner on every layer at B = 16: better or equal everywhere (64->64@64^2 0.044 -> 0.030 ms, 256->256@32^2 0.053 -> 0.041,
+    // cls1 64->64@256^2 0.188 -> 0.165, 512->512 equal); bf16 joint step, same box x2: 457.0 -> 460.8 slices/s.
+    const double t_stage = 0.7 * ((double)*bm * *bn) / (128.0 * 128.0);
+    const double nout_mb = (double)g->R * g->S * g->C * g->K * 4.0 / 1e6;
+    int best = 1;
+    double best_t = 1e30;
+    const int max_split = nchunks / 4 < 1 ? 1 : (nchunks / 4 > 64 ? 64 : nchunks / 4);
+    for (int ns = 1; ns <= max_split; ++ns) {
+        const double rounds = ceil((double)nblk * ns / 512.0);
+        const double t = rounds * (ceil((double)nchunks / ns) * t_stage + 6.0) + (ns > 1 ? 2.0 * ns * nout_mb / 4.0 + 3.0 : 0.0);
+        if (t < best_t - 1e-9) { best_t = t; best = ns; }
+    }
+    return best;
 }
 
 size_t pnp_conv2d_wgrad_bf16r_workspace_bytes(const pnp_conv_geom* g) {
