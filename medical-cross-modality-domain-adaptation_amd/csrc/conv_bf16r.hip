@@ -267,13 +267,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (NBUF * (BM 
 // a.x = x (bf16), a.w = dy (bf16, [P][K]); reduction split over workgroups in chunks of 64 pixels (grid.x = tiles * nsplit; partials
 // summed by conv_igemm.hip's splitk_reduce_kernel).  A tile holds ONE tap (C % BM == 0), OW and OH*OW are powers of two.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-#else
-    return s16x4{};
-#endif
-}
+// (inline asm, not __builtin_amdgcn_ds_read_tr16_b64_v4i16: behind an LDS-DMA in flight hipcc fences the builtin with s_waitcnt vmcnt(0))
 __device__ __forceinline__ s16x4 lds_tr16_asm(unsigned lds_byte_addr) {
     s16x4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_byte_addr));

@@ -142,3 +142,35 @@ def test_every_environment_switch_is_documented():
     section = doc[doc.index("## E. Environment switches"):]
     missing = sorted(n for n in names if "`%s`" % n not in section)
     assert not missing, missing
+
+
+def test_resident_bf16_planners_on_the_host(built):
+    import ctypes
+    """which geometries the bf16-resident kernels serve, their statistics-partials count and the filter gradient's workspace are host
+    functions of the C-ABI (pnp_conv2d_bf16r_served / _fwd_bf16r_stats_parts / _wgrad_bf16r_workspace_bytes): pinned here without a GPU"""
+    K, L = built.kernels, built._lib
+    lib = L.load()
+    geo = lambda N, H, C, Kf, k, stride=1, pad="SAME", dt=L.DTYPE_BF16: K.conv_geom((N, H, H, C), (k, k, C, Kf), stride, 1, pad, dtype=dt)
+    srv = lambda g: tuple(int(lib.pnp_conv2d_bf16r_served(ctypes.byref(g), k)) for k in (0, 1, 2))
+    assert srv(geo(16, 32, 512, 512, 3)) == (1, 1, 1)                       # group_7..9
+    assert srv(geo(16, 34, 512, 2560, 3, pad="VALID")) == (1, 1, 1)         # group_10 after the mirror pre-pad
+    assert srv(geo(16, 256, 32, 64, 3)) == (1, 0, 0)                        # C = 32: forward only (64-byte rows); K = 32 outputs / C % 64
+    assert srv(geo(16, 256, 64, 64, 3, stride=2)) == (1, 1, 1)              # critic k3 s2: stride-phase data gradient, strided filter gradient
+    assert srv(geo(16, 128, 128, 128, 5, stride=2)) == (1, 1, 1)            # k5 s2: phases (3,3) (3,2) (2,3) (2,2)
+    assert srv(geo(16, 16, 512, 512, 5, stride=4)) == (0, 0, 0)             # 4x4 output maps: a handful of tiles, stays on the split kernels
+    assert srv(geo(2, 32, 512, 512, 3)) == (0, 0, 0)                        # 2 048 pixels: below the 4 096-pixel floor
+    assert srv(geo(16, 256, 40, 5, 5, pad="VALID")) == (0, 0, 0)            # the logits convolution
+    assert srv(geo(16, 256, 16, 16, 3)) == (0, 0, 0)                        # 16-channel layers: conv_small.hip's fp32 tiles
+    assert srv(geo(3, 37, 96, 128, 3)) [2] == 0                             # non-power-of-two map: no resident filter gradient
+    # statistics partials: pixel tiles x wave rows of the tile the planner picks (256 x 128: 4 wave rows; 128-row tiles: 2)
+    parts = lambda g: int(lib.pnp_conv2d_fwd_bf16r_stats_parts(ctypes.byref(g)))
+    assert parts(geo(16, 32, 512, 512, 3)) == (16 * 32 * 32 // 256) * 4          # 256 tiles of 256 x 128
+    assert parts(geo(16, 32, 256, 256, 3)) == (16 * 32 * 32 // 128) * 2          # 256 tiles of 128 x 128 would be one per CU: 128 x 64
+    assert parts(geo(16, 256, 16, 16, 3)) == 0
+    # filter gradient workspace = split count x |dW| x 4, with the split from the cost model (1 <= split <= 64; 0 bytes when un-split)
+    ws = lambda g: int(lib.pnp_conv2d_wgrad_bf16r_workspace_bytes(ctypes.byref(g)))
+    for g in (geo(16, 32, 512, 512, 3), geo(16, 256, 64, 64, 3), geo(16, 32, 256, 256, 3)):
+        nout = g.R * g.S * g.C * g.K * 4
+        assert ws(g) % nout == 0 and 0 <= ws(g) // nout <= 64
+    assert ws(geo(16, 256, 64, 64, 3)) // (9 * 64 * 64 * 4) >= 16                # 9 tiles over 16 384 chunks: split deep
+    assert ws(geo(16, 256, 16, 16, 3)) == 0 and lib.pnp_conv2d_wgrad_bf16r_workspace_bytes(None) == 0
