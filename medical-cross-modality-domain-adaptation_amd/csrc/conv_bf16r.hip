@@ -545,7 +545,7 @@ int launch_tile(ConvArgs& a, hipStream_t st) {
 #define PNP_R(RR, SS)                                                                                                            \
     if (a.R == RR && a.S == SS) {                                                                                                \
         PnpProfScope ps(prof_class(KIND), st, conv_flops(a), 0.5 * conv_bytes(a) + 2.0 * (double)a.M * a.K,                      \
-                        "conv_bf16r_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BKC, KIND, RR, SS, NBUF);        \
+                        "conv_bf16r_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, 1>", BM, BN, WM, WN, BKC, KIND, RR, SS, NBUF);     \
         hipLaunchKernelGGL((conv_bf16r_kernel<BM, BN, WM, WN, BKC, KIND, RR, SS, NBUF>), grid, dim3(64 * WM * WN), 0, st, a);    \
         PNP_CHECK_LAUNCH("conv_bf16r_kernel");                                                                                   \
         return PNP_OK;                                                                                                           \
