@@ -104,6 +104,20 @@ int32_t pnp_conv2d_fwd_stats_parts(const pnp_conv_geom* g);
 int pnp_conv2d_fwd_stats(const float* x, const float* w, float* y, const pnp_conv_geom* g,
                          float keep_prob, uint64_t seed, uint32_t stream_id,
                          const float* shift /*nullable*/, float* parts, size_t parts_bytes, void* stream);
+/* The same with a workspace of pnp_conv2d_fwd_workspace_bytes(g) bytes.  Wide stride-1 3x3 layers (the segmenter's 256- / 512-channel
+ * groups, source_segmenter.py:140-200) may be given to the Winograd F(2x2, 3x3) route (csrc/conv_wino.hip: 2.25x fewer multiplications,
+ * transformed tensors through the workspace; same result up to fp32 rounding, ~1e-6 relative); its partial rows are the tile slabs of its
+ * output transform, so the count comes from pnp_conv2d_fwd_stats_ws_parts(g).  Every other layer: identical to pnp_conv2d_fwd_stats.
+ * pnp_conv2d_wino_chosen(g, kind) tells which route a layer takes (kind 0: forward; 1: data gradient, g = the FORWARD geometry);
+ * environment PNP_WINOGRAD = 0 never / 1 where the cost model says it pays / 2 wherever the geometry allows. */
+int32_t pnp_conv2d_fwd_stats_ws_parts(const pnp_conv_geom* g);
+int pnp_conv2d_fwd_stats_ws(const float* x, const float* w, float* y, const pnp_conv_geom* g,
+                            float keep_prob, uint64_t seed, uint32_t stream_id,
+                            const float* shift /*nullable*/, float* parts, size_t parts_bytes,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int32_t pnp_conv2d_wino_chosen(const pnp_conv_geom* g, int32_t kind);
+/* sets the route policy at run time (0 / 1 / 2 as PNP_WINOGRAD; < 0: read only) and returns the previous one */
+int32_t pnp_conv2d_wino_mode(int32_t mode);
 
 /* Inference-mode conv -> dropout -> batch norm -> (+ shortcut) -> leaky-ReLU in ONE kernel (the monitoring forwards of
  * source_segmenter.py:525-570 / adversarial.py:948-991, every frozen-BN forward of the GAN steps, Trainer.test_eval):
@@ -115,6 +129,12 @@ int pnp_conv2d_fwd_bn(const float* x, const float* w, float* y, const pnp_conv_g
                       float keep_prob, uint64_t seed, uint32_t stream_id,
                       const float* scale, const float* shift, const float* shortcut /*nullable*/, int32_t Cs, float alpha,
                       void* stream);
+/* the same with a workspace of pnp_conv2d_fwd_workspace_bytes(g) bytes (nullable / too small: == pnp_conv2d_fwd_bn): the layers the
+ * planner gives to the Winograd route take it, epilogue included */
+int pnp_conv2d_fwd_bn_ws(const float* x, const float* w, float* y, const pnp_conv_geom* g,
+                         float keep_prob, uint64_t seed, uint32_t stream_id,
+                         const float* scale, const float* shift, const float* shortcut /*nullable*/, int32_t Cs, float alpha,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* gradient w.r.t. the conv input (TF autodiff of the ops above; Conv2DBackpropInput).
  * dy is the gradient w.r.t. the conv accumulator (i.e. AFTER the dropout mask has been applied by the caller).

@@ -371,6 +371,15 @@ bool n16_wgrad_ok(const pnp_conv_geom* g);       // superset: filter gradients o
 int launch_n16_fwd(const ConvArgs& a, int kind, hipStream_t st);
 int n16_wgrad_blocks(const pnp_conv_geom* g);
 int launch_n16_wgrad(const ConvArgs& a, float* part, hipStream_t st);
+// Winograd F(2x2, 3x3) route of the wide stride-1 3x3 convolutions, forward and data gradient (conv_wino.hip).  eligible: the geometry can
+// run it; chosen: eligible and the policy takes it (PNP_WINOGRAD = 0 never / 1 where the cost model says it pays / 2 wherever eligible).
+// launch_wino honours the whole epilogue of ConvArgs (dropout, residual add, statistics partials, fused inference BN); its statistics
+// partial rows are the tile slabs of the output transform (wino_stats_parts), not the direct kernel's wave rows.
+bool wino_eligible(const pnp_conv_geom* g);
+bool wino_chosen(const pnp_conv_geom* g);
+size_t wino_workspace_bytes(const pnp_conv_geom* g);
+int wino_stats_parts(const pnp_conv_geom* g);
+int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size_t ws_bytes, hipStream_t st);
 inline double conv_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.K * a.Kred; }
 inline double conv_bytes(const ConvArgs& a) {
     return 4.0 * ((double)a.N * a.H * a.W * a.C + (double)a.M * a.K + (double)a.Kred * a.K);

@@ -33,6 +33,7 @@
 //   B tile       [32][BN+4]   row = k, n contiguous; fragment = ds_read_b32, lanes 0-31 consecutive => conflict-free.
 //   wgrad A tile [32][BM+4]   row = pixel (reduction index), m' contiguous; ds_read_b32 like B.
 #include "conv_common.h"
+#include "conv_mma.h"
 
 using namespace pnpconv;
 
@@ -318,42 +319,6 @@ struct WgradALoader {
     }
 };
 
-// ---- register-pipelined fragments: one 8-k slice (kq) of a stage ---------------------------------
-// The main loops keep two Frag sets: while the 4*TM*TN MFMAs of slice kq run, the ds_reads of slice kq+1 are in
-// flight, the global loads of the next stage are issued (slice 0) and stored to the other LDS buffer (slice 3).
-// The only LDS latency a wave exposes per stage is the first slice's reads right after the barrier.
-template <int TM, int TN, bool A_MMAJOR, int LDA, int LDB>
-struct Frag {
-    f32x4 a[TM];
-    float b[4][TN];
-    __device__ __forceinline__ void load(const float* __restrict__ As, const float* __restrict__ Bs, int kq, int wm0, int wn0,
-                                         int lane) {
-        const int l31 = lane & 31;
-        const int kb = kq * 8 + 4 * (lane >> 5);
-        if constexpr (A_MMAJOR) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(As + (wm0 + tm * 32 + l31) * LDA + kb);
-        } else {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[tm][j] = As[(kb + j) * LDA + wm0 + tm * 32 + l31];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) b[j][tn] = Bs[(kb + j) * LDB + wn0 + tn * 32 + l31];
-    }
-    __device__ __forceinline__ void mma(Acc<TM, TN>& acc) const {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[j][tn], acc.v[tm][tn], 0, 0, 0);
-    }
-};
 // Split accumulation (narrow tiles): a wave with TM*TN <= 2 accumulator tiles rotates through only two dependent MFMA chains; with a
 // second accumulator set for the odd k of every 8-group it rotates through four, like the 2x2 tile (summed once in front of the epilogue).
 #ifndef PNP_SPLIT_ACC
@@ -380,67 +345,6 @@ __device__ __forceinline__ void acc_add(Acc<TM, TN>& a, const Acc<TM, TN>& b) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) a.v[i][j][e] += b.v[i][j][e];
 }
-#define PNP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// Schedule of slices 1..3 of a stage (two Frag sets: the fragment reads of the NEXT slice and the MFMAs of THIS slice are independent).
-// PNP_CONV_ILV selects where the next stage's LDS stores go (compile-time; measured A/B/A/B on the 512-channel layers at B=16):
-//   0  after the last slice's MFMAs (round 1)
-//   1  as 0, with the fragment reads of slices 2 / 3 interleaved behind single MFMAs instead of in front of them: no change
-//   2  behind the second half of the last slice's MFMAs: 512->512 forward +2.4 %, g10 forward +3.2 % / wgrad +4.6 %, segmenter step
-//      422 -> 434 slices/s, joint GAN step 147.4 -> 151.1 — the stores (and the vmcnt wait in front of them) left the exposed chain
-//      [last MFMA -> stores -> barrier -> first fragment reads -> first MFMA] that the co-resident workgroup has to cover
-//   3  behind the first half of the last slice;  4  behind the second half of slice 2 (loads are issued under slice 0)
-#ifndef PNP_CONV_ILV
-#define PNP_CONV_ILV 2
-#endif
-#define PNP_STORE_BEHIND(MMA, STORE, NMFMA, LEAD)                           \
-    MMA;                                                                    \
-    STORE;                                                                  \
-    if ((LEAD) > 0) __builtin_amdgcn_sched_group_barrier(0x008, (LEAD), 0); \
-    _Pragma("unroll") for (int i_ = 0; i_ < (NMFMA) / 2; ++i_) {            \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                  \
-    }                                                                       \
-    PNP_SCHED_FENCE();
-// last slice (+ the next stage's LDS stores unless they already went behind slice 2)
-#define PNP_LAST_SLICE(MMA, STORE, NMFMA)                                   \
-    if constexpr (PNP_CONV_ILV == 2) {                                      \
-        PNP_STORE_BEHIND(MMA, STORE, NMFMA, (NMFMA) / 2)                    \
-    } else if constexpr (PNP_CONV_ILV == 3) {                               \
-        PNP_STORE_BEHIND(MMA, STORE, NMFMA, 0)                              \
-    } else if constexpr (PNP_CONV_ILV == 4) {                               \
-        MMA;                                                                \
-        PNP_SCHED_FENCE();                                                  \
-    } else {                                                                \
-        MMA;                                                                \
-        PNP_SCHED_FENCE();                                                  \
-        STORE;                                                              \
-        PNP_SCHED_FENCE();                                                  \
-    }
-// slice 2 (variant 4 carries the stores here)
-#define PNP_SLICE2(LOAD, MMA, STORE, NMFMA, NDS)                            \
-    if constexpr (PNP_CONV_ILV == 4) {                                      \
-        LOAD;                                                               \
-        PNP_SCHED_FENCE();                                                  \
-        PNP_STORE_BEHIND(MMA, STORE, NMFMA, (NMFMA) / 2)                    \
-    } else {                                                                \
-        PNP_SLICE(LOAD, MMA, NMFMA, NDS)                                    \
-    }
-#define PNP_SLICE(LOAD, MMA, NMFMA, NDS)                                   \
-    if constexpr (PNP_CONV_ILV == 1) {                                      \
-        LOAD;                                                               \
-        MMA;                                                                \
-        _Pragma("unroll") for (int i_ = 0; i_ < (NMFMA); ++i_) {            \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
-            __builtin_amdgcn_sched_group_barrier(0x100, (NDS), 0);          \
-        }                                                                   \
-        PNP_SCHED_FENCE();                                                  \
-    } else {                                                                \
-        LOAD;                                                               \
-        PNP_SCHED_FENCE();                                                  \
-        MMA;                                                                \
-        PNP_SCHED_FENCE();                                                  \
-    }
-
 // ================================ forward / dgrad kernel ========================================
 // KIND 0 = forward, 1 = data gradient of a stride-1 convolution, 2 = data gradient of a strided convolution (input = dy
 // zero-upsampled by `ups`).  0 and 1 run the same code; the distinct symbol lets rocprof separate forward from backward
@@ -2258,6 +2162,7 @@ static int fwd_split(const pnp_conv_geom* g) {
 
 size_t pnp_conv2d_fwd_workspace_bytes(const pnp_conv_geom* g) {
     if (!g) return 0;
+    if (wino_chosen(g)) return wino_workspace_bytes(g);           // Winograd route: transformed filter + input + product (conv_wino.hip)
     const int ns = fwd_split(g);
     return ns > 1 ? (size_t)ns * g->N * g->OH * g->OW * g->K * sizeof(float) : 0;
 }
@@ -2282,6 +2187,10 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
     }
     if (n16_geom_ok(g)) return launch_n16_fwd(a, 0, (hipStream_t)stream);
     if (narrow_fwd_ok(g, nullptr)) return launch_narrow(x, w, y, g, a, (hipStream_t)stream);
+    if (wino_chosen(g)) {          // (without the workspace the direct kernel runs: same result up to fp32 rounding)
+        if (workspace && workspace_bytes >= wino_workspace_bytes(g)) return launch_wino(a, 0, false, workspace, workspace_bytes, (hipStream_t)stream);
+        return launch_fwd<0>(a, (hipStream_t)stream, nullptr);
+    }
     float* split_ws = (workspace && workspace_bytes >= pnp_conv2d_fwd_workspace_bytes(g) && pnp_conv2d_fwd_workspace_bytes(g) > 0)
                           ? (float*)workspace : nullptr;
     return launch_fwd<0>(a, (hipStream_t)stream, split_ws);
@@ -2290,6 +2199,10 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
 // ---- forward convolution that also leaves the batch-norm statistics partials of its output (training-mode conv -> dropout -> BN) ----
 // Only on the MFMA kernels with an un-split reduction (the epilogue owns complete output rows there); 0 parts = not available for
 // this geometry (narrow-output vector-ALU kernels, reduction-split tiny layers): the caller runs pnp_bn_stats on the output instead.
+static int fwd_stats_impl(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
+                          uint32_t stream_id, const float* shift, float* parts, size_t parts_bytes, void* workspace, size_t workspace_bytes,
+                          void* stream, bool with_ws);
+
 int32_t pnp_conv2d_fwd_stats_parts(const pnp_conv_geom* g) {
     if (!g || check_geom(g, "pnp_conv2d_fwd_stats_parts") != PNP_OK) return 0;
     if (n16_geom_ok(g) || narrow_fwd_ok(g, nullptr) || fwd_split(g) > 1) return 0;
@@ -2300,10 +2213,33 @@ int32_t pnp_conv2d_fwd_stats_parts(const pnp_conv_geom* g) {
 
 int pnp_conv2d_fwd_stats(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
                          uint32_t stream_id, const float* shift, float* parts, size_t parts_bytes, void* stream) {
+    return fwd_stats_impl(x, w, y, g, keep_prob, seed, stream_id, shift, parts, parts_bytes, nullptr, 0, stream, false);
+}
+
+// The same with a workspace (pnp_conv2d_fwd_workspace_bytes): layers the planner gives to the Winograd route (conv_wino.hip) leave one
+// partial row per tile slab of its output transform — pnp_conv2d_fwd_stats_ws_parts says how many; every other layer is
+// pnp_conv2d_fwd_stats / pnp_conv2d_fwd_stats_parts.
+int32_t pnp_conv2d_fwd_stats_ws_parts(const pnp_conv_geom* g) {
+    if (!g || check_geom(g, "pnp_conv2d_fwd_stats_ws_parts") != PNP_OK) return 0;
+    if (wino_chosen(g)) return wino_stats_parts(g);
+    return pnp_conv2d_fwd_stats_parts(g);
+}
+
+int pnp_conv2d_fwd_stats_ws(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
+                            uint32_t stream_id, const float* shift, float* parts, size_t parts_bytes, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    return fwd_stats_impl(x, w, y, g, keep_prob, seed, stream_id, shift, parts, parts_bytes, workspace, workspace_bytes, stream, true);
+}
+
+static int fwd_stats_impl(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
+                          uint32_t stream_id, const float* shift, float* parts, size_t parts_bytes, void* workspace, size_t workspace_bytes,
+                          void* stream, bool with_ws) {
     if (int e = check_geom(g, "pnp_conv2d_fwd_stats")) return e;
     PNP_REQUIRE(x && w && y && parts, "pnp_conv2d_fwd_stats: null pointer");
     PNP_REQUIRE(keep_prob > 0.f, "pnp_conv2d_fwd_stats: keep_prob must be > 0");
-    const int nparts = pnp_conv2d_fwd_stats_parts(g);
+    const bool wino = with_ws && wino_chosen(g);
+    if (wino) PNP_REQUIRE(workspace && workspace_bytes >= wino_workspace_bytes(g), "pnp_conv2d_fwd_stats_ws: workspace too small (pnp_conv2d_fwd_workspace_bytes)");
+    const int nparts = wino ? wino_stats_parts(g) : pnp_conv2d_fwd_stats_parts(g);
     PNP_REQUIRE(nparts > 0, "pnp_conv2d_fwd_stats: no epilogue statistics for this geometry (pnp_conv2d_fwd_stats_parts == 0)");
     if (parts_bytes < (size_t)nparts * 2 * g->K * sizeof(float)) {
         pnp_set_error("pnp_conv2d_fwd_stats: parts buffer too small (%zu < %zu)", parts_bytes, (size_t)nparts * 2 * g->K * sizeof(float));
@@ -2319,6 +2255,7 @@ int pnp_conv2d_fwd_stats(const float* x, const float* w, float* y, const pnp_con
     }
     a.stat_ws = parts;
     a.stat_shift = shift;
+    if (wino) return launch_wino(a, 0, false, workspace, workspace_bytes, (hipStream_t)stream);
     return launch_fwd<0>(a, (hipStream_t)stream);
 }
 
@@ -2334,6 +2271,13 @@ int pnp_bn_fold(const float* gamma, const float* beta, const float* mean, const 
 int pnp_conv2d_fwd_bn(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
                       uint32_t stream_id, const float* scale, const float* shift, const float* shortcut, int32_t Cs, float alpha,
                       void* stream) {
+    return pnp_conv2d_fwd_bn_ws(x, w, y, g, keep_prob, seed, stream_id, scale, shift, shortcut, Cs, alpha, nullptr, 0, stream);
+}
+
+// with a workspace of pnp_conv2d_fwd_workspace_bytes(g) bytes the layers the planner gives to the Winograd route take it (conv_wino.hip)
+int pnp_conv2d_fwd_bn_ws(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
+                         uint32_t stream_id, const float* scale, const float* shift, const float* shortcut, int32_t Cs, float alpha,
+                         void* workspace, size_t workspace_bytes, void* stream) {
     if (int e = check_geom(g, "pnp_conv2d_fwd_bn")) return e;
     PNP_REQUIRE(x && w && y && scale && shift, "pnp_conv2d_fwd_bn: null pointer");
     PNP_REQUIRE(keep_prob > 0.f, "pnp_conv2d_fwd_bn: keep_prob must be > 0");
@@ -2348,7 +2292,9 @@ int pnp_conv2d_fwd_bn(const float* x, const float* w, float* y, const pnp_conv_g
     }
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = shortcut; a.ep_cs = shortcut ? Cs : g->K; a.ep_alpha = alpha;
     if (n16_geom_ok(g)) return launch_n16_fwd(a, 0, (hipStream_t)stream);
-    return launch_fwd<0>(a, (hipStream_t)stream);      // no workspace: the reduction is never split on this path
+    if (wino_chosen(g) && workspace && workspace_bytes >= wino_workspace_bytes(g))
+        return launch_wino(a, 0, false, workspace, workspace_bytes, (hipStream_t)stream);
+    return launch_fwd<0>(a, (hipStream_t)stream);      // the reduction is never split on this path
 }
 
 int pnp_conv2d_fwd_naive(const float* x, const float* w, float* y, const pnp_conv_geom* g, void* stream) {
@@ -2362,8 +2308,37 @@ int pnp_conv2d_fwd_naive(const float* x, const float* w, float* y, const pnp_con
 }
 
 // dgrad workspace: [flipped/transposed filters R*S*K*C] [+ padded dx for SYMMETRIC]
+// the data gradient of a stride-1 zero-padded convolution AS a convolution of dy (flipped, transposed filter)
+static pnp_conv_geom dgrad_as_conv(const pnp_conv_geom* g) {
+    pnp_conv_geom d{};
+    d.N = g->N; d.H = g->OH; d.W = g->OW; d.C = g->K; d.K = g->C; d.R = g->R; d.S = g->S;
+    d.OH = g->H; d.OW = g->W;
+    d.stride = 1; d.dil = g->dil;
+    d.pad_t = g->dil * (g->R - 1) - g->pad_t;
+    d.pad_l = g->dil * (g->S - 1) - g->pad_l;
+    d.pad_mode = PNP_PAD_ZERO;
+    d.dtype = g->dtype;
+    return d;
+}
+static bool dgrad_wino(const pnp_conv_geom* g, pnp_conv_geom* d) {
+    if (g->stride != 1 || g->pad_mode != PNP_PAD_ZERO) return false;
+    *d = dgrad_as_conv(g);
+    return d->pad_t >= 0 && d->pad_l >= 0 && wino_chosen(d);
+}
+
+// 1: the planner gives this layer to the Winograd route (kind 0: forward; 1: data gradient, g = the FORWARD geometry); 0: direct kernels
+int32_t pnp_conv2d_wino_chosen(const pnp_conv_geom* g, int32_t kind) {
+    if (!g || check_geom(g, "pnp_conv2d_wino_chosen") != PNP_OK) return 0;
+    pnp_conv_geom d;
+    return kind == 0 ? (wino_chosen(g) ? 1 : 0) : (dgrad_wino(g, &d) ? 1 : 0);
+}
+
 size_t pnp_conv2d_dgrad_workspace_bytes(const pnp_conv_geom* g) {
     if (!g) return 0;
+    {
+        pnp_conv_geom d;
+        if (dgrad_wino(g, &d)) return wino_workspace_bytes(&d);
+    }
     size_t b = (size_t)g->R * g->S * g->C * g->K * sizeof(float);
     b = (b + 255) & ~(size_t)255;
     size_t outb = (size_t)g->N * g->H * g->W * g->C * sizeof(float);
@@ -2450,6 +2425,14 @@ static int dgrad_impl(const float* dy, const float* w, float* dx, const pnp_conv
             PNP_CHECK_LAUNCH("sympad_bwd_kernel");
         }
         return add_residual(dx, residual);
+    }
+    {
+        pnp_conv_geom dw_;
+        if (dgrad_wino(g, &dw_)) {           // Winograd route: the filter transform flips and transposes on the way (no flip launch)
+            ConvArgs a = make_args(dy, w, dx, &dw_);
+            a.res_add = residual;
+            return launch_wino(a, 1, true, workspace, workspace_bytes, st);
+        }
     }
     dim3 tg((unsigned)pnp_cdiv(g->K, 32), (unsigned)pnp_cdiv(g->C, 32), (unsigned)(g->R * g->S));
     hipLaunchKernelGGL(flip_transpose_kernel, tg, dim3(256), 0, st, w, wt, g->R, g->S, g->C, g->K);

@@ -105,7 +105,26 @@ def conv2d_fwd(x, w, g, keep_prob=1.0, seed=0, stream_id=0, out=None, naive=Fals
 
 def conv_stats_parts(g):
     """number of BN-statistics partial rows the forward of `g` can leave behind (0: not available, use bn_stats)"""
-    return int(_lib.load().pnp_conv2d_fwd_stats_parts(ctypes.byref(g)))
+    return int(_lib.load().pnp_conv2d_fwd_stats_ws_parts(ctypes.byref(g)))
+
+
+def wino_mode(mode=-1):
+    """route policy of the wide stride-1 3x3 convolutions (csrc/conv_wino.hip): 0 direct kernels only, 1 Winograd F(2x2, 3x3) where the
+    cost model says it pays, 2 wherever the geometry allows; returns the previous mode (mode < 0: read only)"""
+    return int(_lib.load().pnp_conv2d_wino_mode(int(mode)))
+
+
+def wino_chosen(g, kind=0):
+    """True: pnp_conv2d_fwd* (kind 0) / pnp_conv2d_dgrad* (kind 1, g = the forward geometry) run this layer on the Winograd route"""
+    return bool(_lib.load().pnp_conv2d_wino_chosen(ctypes.byref(g), int(kind)))
+
+
+def _fwd_ws(g, device):
+    nbytes = _lib.load().pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))
+    if not nbytes:
+        return None, 0
+    ws = workspace(nbytes, device)
+    return ctypes.c_void_p(ws.data_ptr()), ws.numel()
 
 
 def conv2d_fwd_stats(x, w, g, shift, keep_prob=1.0, seed=0, stream_id=0):
@@ -114,8 +133,9 @@ def conv2d_fwd_stats(x, w, g, shift, keep_prob=1.0, seed=0, stream_id=0):
     nparts = conv_stats_parts(g)
     y = torch.empty((g.N, g.OH, g.OW, g.K), dtype=torch.float32, device=x.device)
     parts = workspace(nparts * 2 * g.K * 4, x.device, slot="stats")
-    check(lib.pnp_conv2d_fwd_stats(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _p(shift),
-                                   ctypes.c_void_p(parts.data_ptr()), parts.numel(), _stream()), "pnp_conv2d_fwd_stats")
+    wsp, wsn = _fwd_ws(g, x.device)
+    check(lib.pnp_conv2d_fwd_stats_ws(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _p(shift),
+                                      ctypes.c_void_p(parts.data_ptr()), parts.numel(), wsp, wsn, _stream()), "pnp_conv2d_fwd_stats_ws")
     return y, (parts, nparts)
 
 
@@ -144,8 +164,9 @@ def conv2d_fwd_bn(x, w, g, scale_shift, shortcut=None, alpha=0.2, keep_prob=1.0,
     lib = _lib.load()
     y = torch.empty((g.N, g.OH, g.OW, g.K), dtype=torch.float32, device=x.device)
     cs = shortcut.shape[-1] if shortcut is not None else 0
-    check(lib.pnp_conv2d_fwd_bn(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _p(scale_shift[0]),
-                                _p(scale_shift[1]), _p(shortcut), cs, float(alpha), _stream()), "pnp_conv2d_fwd_bn")
+    wsp, wsn = _fwd_ws(g, x.device)
+    check(lib.pnp_conv2d_fwd_bn_ws(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _p(scale_shift[0]),
+                                   _p(scale_shift[1]), _p(shortcut), cs, float(alpha), wsp, wsn, _stream()), "pnp_conv2d_fwd_bn_ws")
     return y
 
 

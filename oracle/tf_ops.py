@@ -426,3 +426,82 @@ def wgrad_ring_walk(N, H, W, C, OH, OW, stride, dil, pad_t, pad_l, r, s, c, p_fi
             ih -= wrap_h
             off += wrap_h_off
     return out
+
+
+# ---- Winograd F(2x2, 3x3) restated the way the HIP path computes it (csrc/conv_wino.hip) --------------------------------------------
+# 1-D: Y = A^T [ (G g) * (B^T d) ], d = 4 inputs, g = 3 taps, Y = 2 outputs (Lavin & Gray 2016, the minimal filtering algorithm F(2,3)).
+WINO_BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+WINO_AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+
+
+def wino_tiles(N, Ho, Wo, dil):
+    """tile enumeration of csrc/conv_wino.hip: a dilation-d stride-1 3x3 convolution is d*d independent dense 3x3 convolutions of the
+    sub-images (a + d u, b + d v); every OUTPUT sub-image is cut into 2x2 tiles.  Returns (Hso, Wso, th, tw, T)."""
+    assert Ho % dil == 0 and Wo % dil == 0
+    Hs, Ws = Ho // dil, Wo // dil
+    th, tw = -(-Hs // 2), -(-Ws // 2)
+    return Hs, Ws, th, tw, N * dil * dil * th * tw
+
+
+def wino_tile_coords(t, dil, th, tw):
+    """tile id -> (image, sub-image phase a, b, tile row, tile column): t = (((n d + a) d + b) th + ti) tw + tj"""
+    tj = t % tw
+    t //= tw
+    ti = t % th
+    t //= th
+    b = t % dil
+    t //= dil
+    a = t % dil
+    return t // dil, a, b, ti, tj
+
+
+def conv3x3_winograd_np(x, w, dil=1, flip_transpose=False, dtype=np.float32, pad=None):
+    """Stride-1 3x3 (dilated) convolution with zero padding `pad` on every side (default dil = TF SAME; 0 = VALID, the model's g10 on its
+    mirror-padded input; 2 dil = the data gradient of a VALID convolution) in the four steps of the HIP path, intermediates in `dtype`:
+      V[pos][t][c] = (B^T d B)[pos]   input transform of the 4x4 patch of tile t (zeros outside the image)
+      U[pos][c][k] = (G g G^T)[pos]   filter transform (flip_transpose: of the data gradient's filter w'[r][s][k][c] = w[2-r][2-s][c][k])
+      M[pos] = V[pos] @ U[pos]        16 GEMMs [T x C] x [C x K]
+      y tile  = A^T M A               output transform, scattered to the tile's 2x2 pixels (those inside the image)
+    x: [N][H][W][C] numpy, w: [3][3][C][K] numpy."""
+    x = np.asarray(x, dtype)
+    w = np.asarray(w, dtype)
+    if flip_transpose:
+        w = np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2))
+    pad = dil if pad is None else pad
+    assert pad % dil == 0 and pad <= 2 * dil
+    ps = pad // dil
+    N, Hi, Wi, C = x.shape
+    assert Hi % dil == 0 and Wi % dil == 0
+    Ho, Wo = Hi + 2 * pad - 2 * dil, Wi + 2 * pad - 2 * dil
+    Hsi, Wsi = Hi // dil, Wi // dil
+    K = w.shape[3]
+    Hso, Wso, th, tw, T = wino_tiles(N, Ho, Wo, dil)
+    BT, G, AT = WINO_BT.astype(dtype), WINO_G.astype(dtype), WINO_AT.astype(dtype)
+    V = np.zeros((16, T, C), dtype)
+    for t in range(T):
+        n, a, b, ti, tj = wino_tile_coords(t, dil, th, tw)
+        d = np.zeros((4, 4, C), dtype)
+        for i in range(4):
+            for j in range(4):
+                u, v = 2 * ti - ps + i, 2 * tj - ps + j
+                if 0 <= u < Hsi and 0 <= v < Wsi:
+                    d[i, j] = x[n, a + dil * u, b + dil * v]
+        # rows first, then columns (the kernel's order of additions)
+        r = np.einsum("ip,pjc->ijc", BT, d).astype(dtype)
+        V[:, t, :] = np.einsum("ipc,jp->ijc", r, BT).astype(dtype).reshape(16, C)
+    g1 = np.einsum("ir,rsck->isck", G, w).astype(dtype)
+    U = np.einsum("isck,js->ijck", g1, G).astype(dtype).reshape(16, C, K)
+    Mm = np.stack([V[p] @ U[p] for p in range(16)]).astype(dtype)
+    y = np.zeros((N, Ho, Wo, K), dtype)
+    for t in range(T):
+        n, a, b, ti, tj = wino_tile_coords(t, dil, th, tw)
+        m = Mm[:, t, :].reshape(4, 4, K)
+        r = np.einsum("pi,ijk->pjk", AT, m).astype(dtype)
+        o = np.einsum("pjk,qj->pqk", r, AT).astype(dtype)
+        for p in range(2):
+            for q in range(2):
+                u, v = 2 * ti + p, 2 * tj + q
+                if u < Hso and v < Wso:
+                    y[n, a + dil * u, b + dil * v] = o[p, q]
+    return y

@@ -174,3 +174,50 @@ def test_resident_bf16_planners_on_the_host(built):
         assert ws(g) % nout == 0 and 0 <= ws(g) // nout <= 64
     assert ws(geo(16, 256, 64, 64, 3)) // (9 * 64 * 64 * 4) >= 16                # 9 tiles over 16 384 chunks: split deep
     assert ws(geo(16, 256, 16, 16, 3)) == 0 and lib.pnp_conv2d_wgrad_bf16r_workspace_bytes(None) == 0
+
+
+def test_winograd_route_planner_on_the_host(built):
+    """which layers the Winograd F(2x2, 3x3) route takes (csrc/conv_wino.hip), its workspace (transformed filter + input + product) and
+    its statistics partial rows are host functions of the C-ABI: pinned here without a GPU, for every policy mode"""
+    import ctypes
+    import importlib
+    K, L = importlib.import_module(built.__name__ + ".kernels"), built._lib
+    lib = L.load()
+    geo = lambda N, H, C, Kf, k=3, stride=1, dil=1, pad="SAME", dt=L.DTYPE_F32: K.conv_geom((N, H, H, C), (k, k, C, Kf), stride, dil, pad, dtype=dt)
+    ch = lambda g: (K.wino_chosen(g, 0), K.wino_chosen(g, 1))
+    prev = K.wino_mode(-1)
+    try:
+        K.wino_mode(0)
+        assert ch(geo(16, 32, 512, 512)) == (False, False)
+        g = geo(16, 32, 512, 512)
+        direct_ws, direct_parts = int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))), K.conv_stats_parts(g)
+        assert direct_ws == 0 and direct_parts == int(lib.pnp_conv2d_fwd_stats_parts(ctypes.byref(g))) > 0
+        K.wino_mode(1)
+        assert ch(geo(16, 32, 512, 512)) == (True, True)                        # group_7..9
+        assert ch(geo(16, 32, 512, 512, dil=2)) == (True, True)                 # group_8 (atrous rate 2)
+        assert ch(geo(16, 32, 256, 256)) == (True, True) and ch(geo(16, 32, 256, 512)) == (True, True)
+        assert ch(geo(16, 34, 512, 2560, pad="VALID")) == (True, True)          # group_10 on its mirror-padded input; dgrad: padding 2
+        assert ch(geo(16, 32, 128, 128)) == (False, False)                      # C K / (C + K) = 64: the transforms would cost more than they save
+        assert ch(geo(16, 256, 64, 64)) == (False, False)
+        assert ch(geo(16, 64, 256, 256, stride=2)) == (False, False)            # strided: direct / stride-phase kernels
+        assert ch(geo(16, 128, 128, 128, k=5, stride=2)) == (False, False)
+        assert ch(geo(16, 32, 512, 512, dt=L.DTYPE_BF16)) == (False, False)     # bf16 operands: conv_bf16 / conv_bf16r
+        assert ch(geo(1, 8, 512, 512)) == (False, False)                        # 16 tiles: below the 512-tile floor
+        assert ch(geo(16, 33, 512, 512, dil=2)) == (False, False)               # odd extent with dilation 2: no phase decomposition
+        K.wino_mode(2)
+        assert ch(geo(16, 32, 128, 128)) == (True, True) and ch(geo(1, 8, 64, 32)) == (True, True)
+        assert ch(geo(16, 256, 16, 16)) == (False, False) and ch(geo(16, 256, 32, 16)) == (False, False)     # K = 16: conv_small / narrow kernels
+        assert ch(geo(16, 256, 3, 32)) == (False, False)                        # C % 32
+        # workspace = 16 x (C K + T C + T K) floats (each block 256-byte aligned), T = N d^2 ceil(OHs/2) ceil(OWs/2)
+        K.wino_mode(1)
+        for g, T in ((geo(16, 32, 512, 512), 16 * 16 * 16), (geo(16, 32, 512, 512, dil=2), 16 * 4 * 8 * 8), (geo(16, 34, 512, 2560, pad="VALID"), 16 * 16 * 16)):
+            want = 16 * 4 * (g.C * g.K + T * g.C + T * g.K)
+            assert int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))) == want, (g.C, g.K)
+        g10 = geo(16, 34, 512, 2560, pad="VALID")
+        assert int(lib.pnp_conv2d_dgrad_workspace_bytes(ctypes.byref(g10))) == 16 * 4 * (2560 * 512 + 16 * 17 * 17 * (2560 + 512))
+        # statistics partial rows = tile slabs of the output transform (~1024 per channel slice, a multiple of the tiles per pass)
+        assert K.conv_stats_parts(geo(16, 32, 512, 512)) == 4096 // 4 and K.conv_stats_parts(geo(16, 34, 512, 2560, pad="VALID")) == 4096 // 4
+        assert K.conv_stats_parts(geo(16, 32, 128, 128)) == int(lib.pnp_conv2d_fwd_stats_parts(ctypes.byref(geo(16, 32, 128, 128))))
+    finally:
+        K.wino_mode(prev)
+    assert K.wino_mode(-1) == prev

@@ -1,0 +1,172 @@
+"""-m gpu: the Winograd F(2x2, 3x3) route of the wide stride-1 3x3 convolutions (csrc/conv_wino.hip), forward and data gradient.
+
+Oracle: the float64 convolution (oracle.tf_ops.conv2d / autograd) of the same float32 operands; bar 2e-5 of max|ref| (the direct fp32
+kernels land at 1e-7..5e-6 on the same cases; the Winograd transforms add ~1 ulp in front of and behind the contraction).  Every case
+runs BOTH routes through the same entry points (kernels.wino_mode 0 / 2) and checks which kernel symbols ran, so a silent fall-back to
+the direct kernels cannot pass as Winograd.  Epilogue features (dropout mask stream, residual add, BN statistics partials, fused inference
+BN + channel-padded shortcut + leaky-ReLU) are held to the direct route's results: same mask bits, same statistics to fp32 rounding."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+# (N, H, W, C, K, dil, padding)
+CASES = [
+    (4, 32, 32, 512, 512, 1, "SAME"),        # group_7..9
+    (4, 32, 32, 512, 512, 2, "SAME"),        # group_8: atrous rate 2 = four dense sub-images
+    (2, 34, 34, 512, 2560, 1, "VALID"),      # group_10 on its mirror-padded input (K = 2560: three channel slices of the output transform)
+    (4, 32, 32, 256, 512, 1, "SAME"),        # group_7's first layer
+    (2, 64, 64, 256, 256, 1, "SAME"),        # critic cls_3
+    (1, 31, 33, 64, 96, 1, "SAME"),          # odd extents: ragged 2x2 tiles, T and K not multiples of the GEMM tile
+    (1, 30, 34, 32, 160, 2, "SAME"),         # dilation 2 on odd sub-image extents (15 x 17), K = 160: 40 channel quads
+    (3, 12, 20, 96, 36, 1, "VALID"),         # VALID, C = 96 (three 32-groups), K = 36
+    (1, 16, 16, 32, 1056, 1, "SAME"),        # K / 4 = 264: two channel slices, the second 8 quads wide
+]
+BAR = 2e-5
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+def _ran(L, fn, cls):
+    L.prof_summary()
+    L.prof_enable(cls)
+    out = fn()
+    torch.cuda.synchronize()
+    L.prof_enable(0)
+    return out, [r["name"] for r in L.prof_summary()]
+
+
+@pytest.fixture
+def wino():
+    """yields a setter of the route policy; restores the mode in force before the test"""
+    K = pkg("kernels")
+    prev = K.wino_mode(-1)
+    yield K.wino_mode
+    K.wino_mode(prev)
+
+
+def _where(err, K_):
+    """where a mismatch sits (for the log of a failing run): output-tile position, border vs interior, channel block"""
+    e = err.abs().cpu().double()
+    N, H, W, Kc = e.shape
+    pos = [[float(e[:, p::2, q::2].max()) for q in (0, 1)] for p in (0, 1)]
+    border = float(torch.cat([e[:, :2].flatten(), e[:, -2:].flatten(), e[:, :, :2].flatten(), e[:, :, -2:].flatten()]).max())
+    inner = float(e[:, 2:-2, 2:-2].max()) if H > 4 and W > 4 else 0.0
+    blocks = [float(e[..., i:i + 32].max()) for i in range(0, min(Kc, 256), 32)]
+    return {"by tile position": pos, "border": border, "interior": inner, "per 32 channels": blocks}
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_winograd_fwd_dgrad_vs_float64_and_direct(dev, wino, case):
+    K, L = pkg("kernels"), pkg("_lib")
+    N, H, W, C, Kf, dil, padding = case
+    rng = np.random.default_rng(sum(case[:6]))
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, C, Kf)) * np.sqrt(2.0 / (9 * C))).astype(np.float32)
+    g = K.conv_geom(x.shape, w.shape, 1, dil, padding)
+    dy = rng.standard_normal((N, g.OH, g.OW, Kf)).astype(np.float32)
+    res = rng.standard_normal(x.shape).astype(np.float32)
+    xd, wd, dyd, resd = (torch.from_numpy(a).to(dev) for a in (x, w, dy, res))
+    xg = torch.from_numpy(x).double().requires_grad_(True)
+    yo = T.conv2d(xg, torch.from_numpy(w).double(), 1, dil, padding)
+    yo.backward(torch.from_numpy(dy).double())
+
+    wino(0)
+    assert not K.wino_chosen(g, 0) and not K.wino_chosen(g, 1)
+    y0, names0 = _ran(L, lambda: K.conv2d_fwd(xd, wd, g), L.PROF_CONV_FWD)
+    dx0 = K.conv2d_dgrad(dyd, wd, g)
+    assert not any("wino" in n for n in names0), names0
+    wino(2)
+    assert K.wino_chosen(g, 0) and K.wino_chosen(g, 1)
+    y1, names1 = _ran(L, lambda: K.conv2d_fwd(xd, wd, g), L.PROF_CONV_FWD)
+    assert sorted(n.split("<")[0] for n in names1) == ["wino_gemm_kernel", "wino_in_kernel", "wino_out_kernel"], names1
+    dx1, names2 = _ran(L, lambda: K.conv2d_dgrad(dyd, wd, g), L.PROF_CONV_DGRAD)
+    assert sorted(n.split("<")[0] for n in names2) == ["wino_gemm_kernel", "wino_in_kernel", "wino_out_kernel"], names2
+    dxr = K.conv2d_dgrad(dyd, wd, g, residual=resd)
+    errs = {"y direct": _rel(y0, yo), "y wino": _rel(y1, yo), "dx direct": _rel(dx0, xg.grad), "dx wino": _rel(dx1, xg.grad),
+            "dx+res wino": _rel(dxr, xg.grad + torch.from_numpy(res).double())}
+    print("wino %s: %s" % (case, {k: "%.2e" % v for k, v in errs.items()}))
+    if errs["y wino"] > BAR:
+        print("  forward mismatch:", _where(y1.cpu().double() - yo.detach(), Kf))
+    if errs["dx wino"] > BAR:
+        print("  data-gradient mismatch:", _where(dx1.cpu().double() - xg.grad, C))
+    assert max(errs.values()) < BAR, errs
+
+
+def test_winograd_epilogues_equal_the_direct_route(dev, wino):
+    """dropout (the same mask stream: identical zero pattern), BN statistics partials -> mean / variance / moving averages, fused
+    inference BN + channel-padded shortcut + leaky-ReLU: the Winograd route's output transform against conv_epilogue of the direct kernels"""
+    K, L = pkg("kernels"), pkg("_lib")
+    rng = np.random.default_rng(5)
+    for (N, H, C, Kf, dil, Cs) in ((2, 32, 256, 256, 1, 128), (1, 32, 64, 160, 2, 160), (2, 16, 32, 1056, 1, 1000)):
+        x = torch.from_numpy(rng.standard_normal((N, H, H, C)).astype(np.float32)).to(dev)
+        w = torch.from_numpy((rng.standard_normal((3, 3, C, Kf)) * np.sqrt(2.0 / (9 * C))).astype(np.float32)).to(dev)
+        g = K.conv_geom(tuple(x.shape), tuple(w.shape), 1, dil, "SAME")
+        shift = torch.from_numpy((rng.standard_normal(Kf) * 0.1).astype(np.float32)).to(dev)
+        sc = torch.from_numpy(rng.standard_normal((N, H, H, Cs)).astype(np.float32)).to(dev)
+        ss = torch.from_numpy(np.stack([rng.uniform(0.5, 1.5, Kf), rng.standard_normal(Kf)]).astype(np.float32)).to(dev)
+        out = {}
+        for mode in (0, 2):
+            wino(mode)
+            assert K.wino_chosen(g, 0) == (mode == 2)
+            yd = K.conv2d_fwd(x, w, g, keep_prob=0.75, seed=1234, stream_id=7)
+            mm, mv = torch.zeros(Kf, device=dev), torch.ones(Kf, device=dev)
+            nparts = K.conv_stats_parts(g)
+            if nparts > 0:
+                ys, parts = K.conv2d_fwd_stats(x, w, g, shift, keep_prob=0.75, seed=1234, stream_id=7)
+                mean, var = K.bn_stats_finish(parts, shift, N * H * H, mm, mv)
+            else:                                   # (the direct route splits the reduction of a layer with few tiles: no epilogue statistics)
+                ys = yd
+                mean, var = K.bn_stats(yd)
+            yb = K.conv2d_fwd_bn(x, w, g, ss, shortcut=sc, alpha=0.2, keep_prob=0.75, seed=1234, stream_id=7)
+            out[mode] = (yd, ys, mean, var, yb)
+        (yd0, ys0, m0, v0, yb0), (yd1, ys1, m1, v1, yb1) = out[0], out[2]
+        assert torch.equal(yd0 == 0, yd1 == 0), "dropout masks differ"               # the counter hash on the flat output index
+        assert 0.2 < float((yd1 == 0).float().mean()) < 0.3
+        assert torch.equal(ys1, yd1)                                                    # the statistics launch leaves the same output
+        errs = {"drop": _rel(yd1, yd0), "mean": _rel(m1, m0), "var": _rel(v1, v0), "fused bn": _rel(yb1, yb0)}
+        # the statistics against float64 moments of the route's own output
+        yd64 = yd1.double().reshape(-1, Kf)
+        errs["mean vs f64"] = float((m1.double() - yd64.mean(0)).abs().max() / yd64.std())
+        errs["var vs f64"] = _rel(v1, yd64.var(0, unbiased=False))
+        print("wino epilogues (%d, %d, %d->%d, dil %d): %s" % (N, H, C, Kf, dil, {k: "%.2e" % v for k, v in errs.items()}))
+        assert max(errs.values()) < BAR, errs
+
+
+def test_segmenter_step_on_the_winograd_route(dev, wino):
+    """one source-segmenter train step (source_segmenter.py:484-489) with the planner's own choice (mode 1) against the direct kernels
+    (mode 0): the wide layers really take the route (wino_gemm_kernel in both passes), loss and every gradient agree to fp32 rounding
+    through 33 convolutions (cosine over the whole gradient arena, loss to 1e-5)"""
+    ss, L, K = pkg("source_segmenter"), pkg("_lib"), pkg("kernels")
+    B = 4
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((B, 256, 256, 3)).astype(np.float32)).to(dev)
+    lab = rng.integers(0, 5, (B, 256, 256))
+    y = torch.from_numpy(np.eye(5, dtype=np.float32)[lab]).to(dev)
+    res = {}
+    for mode in (0, 1):
+        wino(mode)
+        net = ss.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, cost_kwargs={"cross_flag": True, "miu_cross": 1.0, "dice_flag": True, "miu_dice": 1.0, "regularizer": 1e-4}, seed=0)
+        tr = ss.Trainer(net, None, None, num_cls=5, batch_size=B, optimizer="adam", opt_kwargs={"learning_rate": 1e-3})
+        tr.opt = tr._get_optimizer(10)
+        L.prof_summary()
+        L.prof_enable(L.PROF_CONV_FWD | L.PROF_CONV_DGRAD)
+        loss = float(tr.train_step(x, y, 0.75, 11))
+        torch.cuda.synchronize()
+        L.prof_enable(0)
+        names = [r["name"] for r in L.prof_summary()]
+        res[mode] = (loss, net.store.grad_arena.clone(), net.store.arena.clone(), names)
+    (l0, g0, w0, n0), (l1, g1, w1, n1) = res[0], res[1]
+    assert not any("wino" in n for n in n0)
+    assert any(n.startswith("wino_gemm_kernel<128, 128, 2, 2, 0>") for n in n1) and any(n.startswith("wino_gemm_kernel<128, 128, 2, 2, 1>") for n in n1), sorted(set(n1))
+    cos = float(torch.nn.functional.cosine_similarity(g0.double().flatten(), g1.double().flatten(), dim=0))
+    cw = float(torch.nn.functional.cosine_similarity(w0.double().flatten(), w1.double().flatten(), dim=0))
+    print("segmenter step, Winograd route vs direct: loss %.7f vs %.7f, gradient cosine %.8f, weights-after-Adam cosine %.8f" % (l1, l0, cos, cw))
+    assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0)) and cos > 0.99999 and cw > 0.999999

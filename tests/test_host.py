@@ -597,3 +597,27 @@ def test_ring_filter_gradient_coordinate_walk():
                                         assert off >= N * H * W * C * 4     # rows past the last pixel lie beyond x: hardware zero
                                     checked += 1
     assert checked > 50000
+
+
+def test_winograd_restatement_equals_the_direct_convolution():
+    """the tile enumeration (dilation phases, ragged 2x2 tiles, padding 0 / dil / 2 dil), the three transforms and the flipped, transposed
+    filter of the data gradient of csrc/conv_wino.hip, restated in numpy (oracle.tf_ops.conv3x3_winograd_np): equal to tf.nn.conv2d /
+    atrous_conv2d and to autograd's data gradient in float64; in float32 as close to float64 as the direct sum is"""
+    rng = np.random.default_rng(11)
+    for (N, H, W, C, K, d, pad) in ((2, 8, 8, 4, 5, 1, 1), (1, 6, 10, 3, 4, 2, 2), (2, 5, 7, 4, 4, 1, 1), (1, 12, 4, 2, 3, 2, 2),
+                                    (1, 7, 9, 3, 2, 1, 0), (1, 8, 12, 3, 2, 2, 0), (1, 2, 2, 3, 2, 1, 1)):
+        x, w = rng.standard_normal((N, H, W, C)), rng.standard_normal((3, 3, C, K))
+        xt = torch.from_numpy(x).requires_grad_(True)
+        ref = T.conv2d(xt, torch.from_numpy(w), 1, d, "SAME" if pad == d else "VALID")
+        got = T.conv3x3_winograd_np(x, w, d, dtype=np.float64, pad=pad)
+        assert got.shape == tuple(ref.shape) and np.allclose(got, ref.detach().numpy(), rtol=1e-12, atol=1e-12), (N, H, W, C, K, d, pad)
+        dy = rng.standard_normal(tuple(ref.shape))
+        ref.backward(torch.from_numpy(dy))
+        gd = T.conv3x3_winograd_np(dy, w, d, flip_transpose=True, dtype=np.float64, pad=2 * d - pad)
+        assert gd.shape == x.shape and np.allclose(gd, xt.grad.numpy(), rtol=1e-12, atol=1e-12), (N, H, W, C, K, d, pad)
+    x = rng.standard_normal((1, 8, 8, 512)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 512, 32)) * 0.02).astype(np.float32)
+    ref = T.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), 1, 1, "SAME").numpy()
+    e_w = np.abs(T.conv3x3_winograd_np(x, w, 1, dtype=np.float32) - ref).max() / np.abs(ref).max()
+    e_d = np.abs(T.conv2d(torch.from_numpy(x), torch.from_numpy(w), 1, 1, "SAME").numpy() - ref).max() / np.abs(ref).max()
+    assert e_w < 5e-6 and e_w < 4 * e_d + 1e-6, (e_w, e_d)

@@ -13,6 +13,9 @@ L = importlib.import_module("medical-cross-modality-domain-adaptation_amd._lib")
 DTYPE = os.environ.get("DTYPE", "f32")          # bf16: bf16 MFMA operands (csrc/conv_bf16.hip) where the layer is on those kernels
 PEAK = 2500.0 if DTYPE == "bf16" else 157.3
 B = int(os.environ.get("B", 16))
+if os.environ.get("WINO") is not None:          # route of the wide stride-1 3x3 layers (csrc/conv_wino.hip): 0 direct, 1 planner, 2 wherever eligible
+    K.wino_mode(int(os.environ["WINO"]))
+SKIP_WGRAD = bool(os.environ.get("SKIP_WGRAD"))
 LAYERS = [  # name, H, C, K, R, dil, padding, count in segmenter fwd
     ("g1 3->16", 256, 3, 16, 3, 1, "SAME", 1),
     ("g1 16->16", 256, 16, 16, 3, 1, "SAME", 2),
@@ -77,9 +80,10 @@ def main():
         flop = 2.0 * B * g.OH * g.OW * R * R * C * Kc
         tf = timeit(lambda: K.conv2d_fwd(x, w, g))
         td = timeit(lambda: K.conv2d_dgrad(dy, w, g))
-        tw = timeit(lambda: K.conv2d_wgrad(x, dy, g))
-        print("%-18s %9.2f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f" % (name, flop / 1e9, tf, flop / tf / 1e9, td, flop / td / 1e9, tw,
-                                                                   flop / tw / 1e9))
+        tw = float('nan') if SKIP_WGRAD else timeit(lambda: K.conv2d_wgrad(x, dy, g))
+        print("%-18s %9.2f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f%s" % (name, flop / 1e9, tf, flop / tf / 1e9, td, flop / td / 1e9, tw,
+                                                                     flop / tw / 1e9, "  [winograd fwd/dgrad: %d/%d]" % (K.wino_chosen(g, 0), K.wino_chosen(g, 1))
+                                                                     if (K.wino_chosen(g, 0) or K.wino_chosen(g, 1)) else ""))
         tot["fwd"] += tf * cnt
         tot["dgrad"] += td * cnt
         tot["wgrad"] += tw * cnt
