@@ -14,7 +14,7 @@
 //   y tile       = A^T M A            wino_out_kernel     + the whole convolution epilogue: dropout, residual add, BN statistics partials,
 //                                                         fused inference BN + shortcut + leaky-ReLU (conv_common.h: conv_epilogue's order)
 // pos = 4 i + j indexes the 16 points of the transformed 4x4 tile.  V and M pass through HBM (workspace): 4x the input / output size
-// each, which is why the route only pays where the contraction is deep — the planner takes it when C K / (C + K) >= 100 (256->256 up).
+// each, which is why the route only pays where the contraction is deep — the planner takes it when C K / (C + K) >= 85 (128->256 up).
 // A dilation-d SAME convolution is d x d independent dense convolutions of the sub-images (a + d u, b + d v): the tile enumeration
 // walks (image, a, b, tile row, tile column), everything else is unchanged (oracle/tf_ops.py::conv3x3_winograd_np restates the index
 // arithmetic; tests/test_host.py holds it to the direct convolution).
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(NT) wino_out_kernel(WinoOutArgs a) {
 
 // ------------------------------------------------------------ host side ----------------------------------------------------------
 #ifndef PNP_WINOGRAD_DEFAULT
-#define PNP_WINOGRAD_DEFAULT 0
+#define PNP_WINOGRAD_DEFAULT 1
 #endif
 std::atomic<int> g_wino_mode{-1};          // -1: not read yet (environment PNP_WINOGRAD, else the compiled-in default)
 int wino_mode() {
@@ -467,9 +467,10 @@ bool wino_chosen(const pnp_conv_geom* g) {
     const int mode = wino_mode();
     if (mode <= 0 || !wino_eligible(g)) return false;
     if (mode >= 2) return true;
-    // the transforms move 20 M (C + K) bytes through HBM that the direct kernel does not; the contraction saves 10 M C K flops:
-    // measured break-even C K / (C + K) ~ 100 (tools/bench_conv.py, PNP_WINOGRAD=2 against 0)
-    static const double thr = getenv("PNP_WINOGRAD_MIN") ? atof(getenv("PNP_WINOGRAD_MIN")) : 100.0;
+    // the transforms move 20 M (C + K) bytes through HBM that the direct kernel does not; the contraction saves 10 M C K flops.  Measured
+    // at B = 16 (tools/bench_conv.py WINO=2 against 0, profiles/r04_conv_layers_wino_B16.txt): 512->512 0.546 -> 0.336 ms, 256->256
+    // 0.156 -> 0.121, 128->256 0.083 -> 0.078 (C K / (C + K) = 85: break-even), 128->128 0.047 -> 0.050, 64->128@128^2 0.287 -> 0.429
+    static const double thr = getenv("PNP_WINOGRAD_MIN") ? atof(getenv("PNP_WINOGRAD_MIN")) : 85.0;
     const WinoGeom w = make_wgeom(g);
     return (double)g->C * g->K / ((double)g->C + g->K) >= thr && w.T >= 512;
 }

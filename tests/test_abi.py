@@ -79,7 +79,14 @@ def test_host_planners_through_the_workspace_queries(built):
     import ctypes
     lib = built._lib.load()
     K = pkg("kernels")
+    prev = K.wino_mode(0)            # the planners of the DIRECT kernels (the Winograd route's own: test_winograd_route_planner_on_the_host)
+    try:
+        _direct_planners(lib, K, ctypes)
+    finally:
+        K.wino_mode(prev)
 
+
+def _direct_planners(lib, K, ctypes):
     def geo(N, H, C, Kc, R, stride=1, dil=1, padding="SAME"):
         return K.conv_geom((N, H, H, C), (R, R, C, Kc), stride, dil, padding)
 
@@ -111,7 +118,7 @@ def test_host_planners_through_the_workspace_queries(built):
     logits = K.conv_geom((16, 260, 260, 40), (5, 5, 40, 5), 1, 1, "VALID")
     assert wgr(logits) == 2048 * 5 * 5 * 40 * 5 * 4
     # PNP_DTYPE_BF16 permits bf16 operands; the 16-channel layers keep conv_small.hip's fp32 plan (round 3, run 14), wide layers do not
-    L = built._lib
+    L = pkg("_lib")
     g1b = K.conv_geom((16, 256, 256, 16), (3, 3, 16, 16), 1, 1, "SAME", dtype=L.DTYPE_BF16)
     assert wgr(g1b) == wgr(g1)
     g2b = K.conv_geom((16, 128, 128, 32), (3, 3, 32, 32), 1, 1, "SAME", dtype=L.DTYPE_BF16)
@@ -197,7 +204,8 @@ def test_winograd_route_planner_on_the_host(built):
         assert ch(geo(16, 32, 512, 512, dil=2)) == (True, True)                 # group_8 (atrous rate 2)
         assert ch(geo(16, 32, 256, 256)) == (True, True) and ch(geo(16, 32, 256, 512)) == (True, True)
         assert ch(geo(16, 34, 512, 2560, pad="VALID")) == (True, True)          # group_10 on its mirror-padded input; dgrad: padding 2
-        assert ch(geo(16, 32, 128, 128)) == (False, False)                      # C K / (C + K) = 64: the transforms would cost more than they save
+        assert ch(geo(16, 32, 128, 256)) == (True, True)                        # C K / (C + K) = 85: break-even, measured
+        assert ch(geo(16, 32, 128, 128)) == (False, False)                      # 64: the transforms cost more than they save
         assert ch(geo(16, 256, 64, 64)) == (False, False)
         assert ch(geo(16, 64, 256, 256, stride=2)) == (False, False)            # strided: direct / stride-phase kernels
         assert ch(geo(16, 128, 128, 128, k=5, stride=2)) == (False, False)

@@ -21,9 +21,9 @@ CASES = [
     (2, 34, 34, 512, 2560, 1, "VALID"),      # group_10 on its mirror-padded input (K = 2560: three channel slices of the output transform)
     (4, 32, 32, 256, 512, 1, "SAME"),        # group_7's first layer
     (2, 64, 64, 256, 256, 1, "SAME"),        # critic cls_3
-    (1, 31, 33, 64, 96, 1, "SAME"),          # odd extents: ragged 2x2 tiles, T and K not multiples of the GEMM tile
+    (1, 31, 33, 64, 96, 1, "SAME"),          # odd extents: ragged 2x2 tiles, T and K not multiples of the GEMM tile (K = 96, 24 channel quads)
     (1, 30, 34, 32, 160, 2, "SAME"),         # dilation 2 on odd sub-image extents (15 x 17), K = 160: 40 channel quads
-    (3, 12, 20, 96, 36, 1, "VALID"),         # VALID, C = 96 (three 32-groups), K = 36
+    (3, 12, 20, 96, 64, 1, "VALID"),         # VALID (padding 0; its data gradient: padding 2), C = 96 (three 32-groups)
     (1, 16, 16, 32, 1056, 1, "SAME"),        # K / 4 = 264: two channel slices, the second 8 quads wide
 ]
 BAR = 2e-5
