@@ -108,7 +108,7 @@ int pnp_conv2d_fwd_stats(const float* x, const float* w, float* y, const pnp_con
  * groups, source_segmenter.py:140-200) may be given to the Winograd F(2x2, 3x3) route (csrc/conv_wino.hip: 2.25x fewer multiplications,
  * transformed tensors through the workspace; same result up to fp32 rounding, ~1e-6 relative); its partial rows are the tile slabs of its
  * output transform, so the count comes from pnp_conv2d_fwd_stats_ws_parts(g).  Every other layer: identical to pnp_conv2d_fwd_stats.
- * pnp_conv2d_wino_chosen(g, kind) tells which route a layer takes (kind 0: forward; 1: data gradient, g = the FORWARD geometry);
+ * pnp_conv2d_wino_chosen(g, kind) tells which route a layer takes (kind 0: forward; 1: data gradient; 2: filter gradient — g = the FORWARD geometry);
  * environment PNP_WINOGRAD = 0 never / 1 where the cost model says it pays / 2 wherever the geometry allows. */
 int32_t pnp_conv2d_fwd_stats_ws_parts(const pnp_conv_geom* g);
 int pnp_conv2d_fwd_stats_ws(const float* x, const float* w, float* y, const pnp_conv_geom* g,
@@ -118,6 +118,9 @@ int pnp_conv2d_fwd_stats_ws(const float* x, const float* w, float* y, const pnp_
 int32_t pnp_conv2d_wino_chosen(const pnp_conv_geom* g, int32_t kind);
 /* sets the route policy at run time (0 / 1 / 2 as PNP_WINOGRAD; < 0: read only) and returns the previous one */
 int32_t pnp_conv2d_wino_mode(int32_t mode);
+/* the filter gradient (pnp_conv2d_wgrad / _wgrad_acc, given pnp_conv2d_wgrad_workspace_bytes) has its own switch (PNP_WINOGRAD_WGRAD,
+ * same values); pnp_conv2d_wino_chosen(g, 2) tells its route */
+int32_t pnp_conv2d_wino_wgrad_mode(int32_t mode);
 
 /* Inference-mode conv -> dropout -> batch norm -> (+ shortcut) -> leaky-ReLU in ONE kernel (the monitoring forwards of
  * source_segmenter.py:525-570 / adversarial.py:948-991, every frozen-BN forward of the GAN steps, Trainer.test_eval):

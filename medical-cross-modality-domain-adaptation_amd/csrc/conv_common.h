@@ -380,6 +380,10 @@ bool wino_chosen(const pnp_conv_geom* g);
 size_t wino_workspace_bytes(const pnp_conv_geom* g);
 int wino_stats_parts(const pnp_conv_geom* g);
 int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size_t ws_bytes, hipStream_t st);
+// the filter gradient on the same route (its own switch, PNP_WINOGRAD_WGRAD): a = make_args(x, dy, -, g) of the forward geometry
+bool wino_wgrad_chosen(const pnp_conv_geom* g);
+size_t wino_wgrad_workspace_bytes(const pnp_conv_geom* g);
+int launch_wino_wgrad(const ConvArgs& a, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 inline double conv_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.K * a.Kred; }
 inline double conv_bytes(const ConvArgs& a) {
     return 4.0 * ((double)a.N * a.H * a.W * a.C + (double)a.M * a.K + (double)a.Kred * a.K);

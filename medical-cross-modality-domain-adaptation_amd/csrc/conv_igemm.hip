@@ -2027,6 +2027,7 @@ int launch_wgd(const WgdArgs& a, const WgdPlan& pl, hipStream_t st) {
 }
 
 size_t wgrad_ws(const pnp_conv_geom* g) {
+    if (wino_wgrad_chosen(g)) return wino_wgrad_workspace_bytes(g);         // Winograd route (conv_wino.hip)
     const size_t nout = (size_t)g->R * g->S * g->C * g->K;
     if (n16_wgrad_ok(g)) return (size_t)n16_wgrad_blocks(g) * nout * sizeof(float);
     const long long P = (long long)g->N * g->OH * g->OW;
@@ -2326,10 +2327,11 @@ static bool dgrad_wino(const pnp_conv_geom* g, pnp_conv_geom* d) {
     return d->pad_t >= 0 && d->pad_l >= 0 && wino_chosen(d);
 }
 
-// 1: the planner gives this layer to the Winograd route (kind 0: forward; 1: data gradient, g = the FORWARD geometry); 0: direct kernels
+// 1: the planner gives this layer to the Winograd route (kind 0: forward; 1: data gradient; 2: filter gradient — g = the FORWARD geometry); 0: direct kernels
 int32_t pnp_conv2d_wino_chosen(const pnp_conv_geom* g, int32_t kind) {
     if (!g || check_geom(g, "pnp_conv2d_wino_chosen") != PNP_OK) return 0;
     pnp_conv_geom d;
+    if (kind == 2) return wino_wgrad_chosen(g) ? 1 : 0;
     return kind == 0 ? (wino_chosen(g) ? 1 : 0) : (dgrad_wino(g, &d) ? 1 : 0);
 }
 
@@ -2494,6 +2496,8 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, const pnp_conv
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     if (!ws) workspace_bytes = 0;
+    if (wino_wgrad_chosen(g) && workspace_bytes >= wino_wgrad_workspace_bytes(g))
+        return launch_wino_wgrad(a, dw, accumulate, workspace, workspace_bytes, st);
     if (n16_wgrad_ok(g) && workspace_bytes >= wgrad_ws(g)) {
         if (int e = launch_n16_wgrad(a, ws, st)) return e;
         const size_t nout = (size_t)a.Kred * a.K;

@@ -409,10 +409,228 @@ __global__ void __launch_bounds__(NT) wino_out_kernel(WinoOutArgs a) {
     }
 }
 
+
+// =================================================================================================================================
+// Filter gradient on the route: dW = G^T [ sum over tiles of (B^T d B) (.) (A y A^T) ] G  — the transposition of F(2x2, 3x3): the SAME
+// input transform V as the forward, the 2x2 tile of dy spread to the 4x4 transform points (A = (A^T)^T: z0 = y0, z1 = y0 + y1,
+// z2 = y0 - y1, z3 = -y1 along each axis), 16 GEMMs S[pos] = V[pos]^T x Y[pos] ([C x T] x [T x K], reduction over the tiles, split
+// across workgroups like every filter gradient here) and a 4x4 -> 3x3 transform that also sums the split partials.
+struct WinoDyArgs {
+    const float* dy;
+    float* Y;
+    WinoGeom g;
+    int K;
+};
+
+__global__ void __launch_bounds__(NT) wino_dy_kernel(WinoDyArgs a) {
+    const int K4 = a.K >> 2;
+    const size_t nvec = (size_t)a.g.T * K4;
+    const size_t plane = (size_t)a.g.T * a.K;
+    const size_t gs = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += gs) {
+        const int t = (int)(i / K4);
+        const int k = (int)(i - (size_t)t * K4) * 4;
+        int n, pa, pb, ti, tj;
+        tile_of(a.g, t, n, pa, pb, ti, tj);
+        f32x4 y[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int u = 2 * ti + p, v = 2 * tj + q;
+                const f32x4 zero = {0, 0, 0, 0};
+                y[p][q] = (u < a.g.Hso && v < a.g.Wso) ? ld4(a.dy + ((size_t)(n * a.g.Ho + pa + a.g.dil * u) * a.g.Wo + pb + a.g.dil * v) * a.K + k) : zero;
+            }
+        f32x4 z[4][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            z[0][q] = y[0][q];
+            z[1][q] = y[0][q] + y[1][q];
+            z[2][q] = y[0][q] - y[1][q];
+            z[3][q] = -y[1][q];
+        }
+        float* out = a.Y + (size_t)t * a.K + k;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            st4(out + (size_t)(4 * p + 0) * plane, z[p][0]);
+            st4(out + (size_t)(4 * p + 1) * plane, z[p][0] + z[p][1]);
+            st4(out + (size_t)(4 * p + 2) * plane, z[p][0] - z[p][1]);
+            st4(out + (size_t)(4 * p + 3) * plane, -z[p][1]);
+        }
+    }
+}
+
+// S[z][pos] = V[pos][rows of split z]^T x Y[pos][rows of split z].  Workgroup = one 128 x 128 tile of (C x K) of one transform point and
+// one reduction split; both operands are [tile row][channel] with the reduction index as the ROW, so both LDS tiles are [32][128 + 4]
+// like the B tile of the convolutions (fragments by ds_read_b32: Frag<.., A_MMAJOR = false>, the layout of conv_wgrad_kernel).
+struct WinoWgradGemmArgs {
+    const float* V;
+    const float* Y;
+    float* S;
+    int T, C, K;
+    int nblk_m, nblk_n, nsplit, chunks_per_split, xcd_swizzle;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(NTHREADS, 2) wino_wgrad_gemm_kernel(WinoWgradGemmArgs g) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
+    constexpr int A4 = BM / 4, ARPB = NTHREADS / A4, ANPB = BK / ARPB;        // A tile: 32 rows x BM/4 float4 columns
+    constexpr int B4 = BN / 4, BRPB = NTHREADS / B4, BNPB = BK / BRPB;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nblk = g.nblk_m * g.nblk_n;
+    // all (channel, filter) tiles of one (transform point, split) re-read the same rows of V and Y: consecutive logical ids = one XCD's L2
+    const int lid = g.xcd_swizzle ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int pz = lid / nblk;
+    const int bid = lid - pz * nblk;
+    const int pos = pz / g.nsplit, z = pz - pos * g.nsplit;
+    const int mt = bid / g.nblk_n, nt = bid - mt * g.nblk_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+    const float* Ap = g.V + (size_t)pos * g.T * g.C;
+    const float* Bp = g.Y + (size_t)pos * g.T * g.K;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ap, (unsigned)((size_t)g.T * g.C * 4));
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bp, (unsigned)((size_t)g.T * g.K * 4));
+
+    const int acol = t % A4, arow = t / A4;
+    const int bcol = t % B4, brow = t / B4;
+    const bool aok = m0 + 4 * acol < g.C, bok = n0 + 4 * bcol < g.K;
+    const int r_begin = z * g.chunks_per_split * BK;
+    int r_end = r_begin + g.chunks_per_split * BK;
+    if (r_end > g.T) r_end = g.T;
+    const int nchunks = (r_end - r_begin + BK - 1) / BK;
+
+    f32x4 areg[ANPB], breg[BNPB];
+    auto gload = [&](int r0) {               // rows r0 .. r0 + 31 of this split (past r_end: out-of-range offset = zeros)
+#pragma unroll
+        for (int i = 0; i < ANPB; ++i) {
+            const int r = r0 + arow + ARPB * i;
+            areg[i] = bload4s(ra, (aok & (r < r_end)) ? (unsigned)((r * g.C + m0 + 4 * acol) * 4) : OOB2, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BNPB; ++i) {
+            const int r = r0 + brow + BRPB * i;
+            breg[i] = bload4s(rb, (bok & (r < r_end)) ? (unsigned)((r * g.K + n0 + 4 * bcol) * 4) : OOB2, 0);
+        }
+    };
+    auto lstore = [&](float* An, float* Bn) {
+#pragma unroll
+        for (int i = 0; i < ANPB; ++i) *reinterpret_cast<f32x4*>(An + (arow + ARPB * i) * LDA + 4 * acol) = areg[i];
+#pragma unroll
+        for (int i = 0; i < BNPB; ++i) *reinterpret_cast<f32x4*>(Bn + (brow + BRPB * i) * LDB + 4 * bcol) = breg[i];
+    };
+
+    Acc<TM, TN> acc;
+    acc.zero();
+    if (nchunks > 0) {
+        gload(r_begin);
+        lstore(lds, lds + 2 * ASZ);
+        __syncthreads();
+        Frag<TM, TN, false, LDA, LDB> f0, f1;
+        f0.load(lds, lds + 2 * ASZ, 0, wm0, wn0, lane);
+        for (int c = 0; c < nchunks; ++c) {
+            const int cur = c & 1;
+            const float* As = lds + cur * ASZ;
+            const float* Bs = lds + 2 * ASZ + cur * BSZ;
+            float* An = lds + (cur ^ 1) * ASZ;
+            float* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
+            f1.load(As, Bs, 1, wm0, wn0, lane);
+            gload(r_begin + (c + 1) * BK);
+            f0.mma(acc);
+            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+            for (int i = 0; i < 4 * TM * TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            PNP_SCHED_FENCE();
+            PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, (4 * TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
+            PNP_SLICE2(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), lstore(An, Bn), 4 * TM * TN, (4 * TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
+            PNP_LAST_SLICE(f1.mma(acc), lstore(An, Bn), 4 * TM * TN)
+            __syncthreads();
+            f0.load(An, Bn, 0, wm0, wn0, lane);
+        }
+    }
+    // S[z][pos] rows = channels, columns = filters: wgrad_epilogue with Kred = C
+    ConvArgs e{};
+    e.Kred = g.C;
+    e.K = g.K;
+    wgrad_epilogue<TM, TN>(e, acc, g.S + ((size_t)z * 16 + pos) * g.C * g.K, m0, n0, wm0, wn0, lane);
+}
+
+// dW[r][s][c][k] (+)= sum_ij G[i][r] G[j][s] sum_z S[z][4i+j][c][k]: one thread = one channel x 4 filters
+__global__ void __launch_bounds__(NT) wino_wgrad_out_kernel(const float* __restrict__ S, float* __restrict__ dw, int C, int K, int nsplit,
+                                                            int accumulate) {
+    const int K4 = K >> 2;
+    const size_t nvec = (size_t)C * K4;
+    const size_t plane = (size_t)C * K;
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= nvec) return;
+    const size_t off = i * 4;                 // (c, k) -> c*K + k
+    f32x4 s[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        f32x4 v = ld4(S + (size_t)p * plane + off);
+        for (int z = 1; z < nsplit; ++z) v += ld4(S + ((size_t)z * 16 + p) * plane + off);
+        s[p] = v;
+    }
+    f32x4 t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = s[j] + 0.5f * (s[4 + j] + s[8 + j]);
+        t[1][j] = 0.5f * (s[4 + j] - s[8 + j]);
+        t[2][j] = 0.5f * (s[4 + j] + s[8 + j]) + s[12 + j];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        f32x4 o[3];
+        o[0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+        o[1] = 0.5f * (t[r][1] - t[r][2]);
+        o[2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float* dst = dw + (size_t)(r * 3 + q) * plane + off;
+            if (accumulate) o[q] += ld4(dst);
+            st4(dst, o[q]);
+        }
+    }
+}
+
 // ------------------------------------------------------------ host side ----------------------------------------------------------
 #ifndef PNP_WINOGRAD_DEFAULT
 #define PNP_WINOGRAD_DEFAULT 1
 #endif
+#ifndef PNP_WINOGRAD_WGRAD_DEFAULT
+#define PNP_WINOGRAD_WGRAD_DEFAULT 1
+#endif
+std::atomic<int> g_wino_wgrad_mode{-1};    // the filter gradient's own switch (PNP_WINOGRAD_WGRAD): 0 never / 1 planner / 2 wherever eligible
+int wino_wgrad_mode() {
+    int m = g_wino_wgrad_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        m = getenv("PNP_WINOGRAD_WGRAD") ? atoi(getenv("PNP_WINOGRAD_WGRAD")) : PNP_WINOGRAD_WGRAD_DEFAULT;
+        if (m < 0) m = 0;
+        g_wino_wgrad_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+// reduction split of the filter gradient's GEMMs: enough workgroups for >= 1 dispatch round (512 slots), >= 8 stages each
+int wgrad_split(int T, int C, int K, int* chunks_per_split) {
+    const int nblk = pnp_cdiv(C, 128) * pnp_cdiv(K, 128) * 16;
+    const int nchunks = pnp_cdiv(T, BK);
+    int ns = pnp_cdiv(512, nblk);
+    if (ns > nchunks / 8) ns = nchunks / 8;
+    if (ns < 1) ns = 1;
+    *chunks_per_split = pnp_cdiv(nchunks, ns);
+    return pnp_cdiv(nchunks, *chunks_per_split);
+}
+
 std::atomic<int> g_wino_mode{-1};          // -1: not read yet (environment PNP_WINOGRAD, else the compiled-in default)
 int wino_mode() {
     int m = g_wino_mode.load(std::memory_order_relaxed);
@@ -547,10 +765,85 @@ int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size
     return PNP_OK;
 }
 
+bool wino_wgrad_chosen(const pnp_conv_geom* g) {
+    const int mode = wino_wgrad_mode();
+    if (mode <= 0 || !wino_eligible(g)) return false;
+    if (mode >= 2) return true;
+    // measured at B = 16 (profiles/r04_conv_layers_wino_wgrad_B16.txt, direct ring kernel -> route): 512->512 0.610 -> 0.350 ms, g10 3.022 ->
+    // 1.516, 256->512 0.331 -> 0.217, 256->256 0.193 -> 0.142 (@64^2: 0.615 -> 0.425), 128->256@32^2 0.120 -> 0.131: two transforms in front of
+    // the contraction instead of one, so the break-even sits higher than the forward's
+    static const double thr = getenv("PNP_WINOGRAD_WGRAD_MIN") ? atof(getenv("PNP_WINOGRAD_WGRAD_MIN")) : 120.0;
+    const WinoGeom w = make_wgeom(g);
+    return (double)g->C * g->K / ((double)g->C + g->K) >= thr && w.T >= 512;
+}
+
+size_t wino_wgrad_workspace_bytes(const pnp_conv_geom* g) {
+    const WinoGeom w = make_wgeom(g);
+    int cps;
+    const int ns = wgrad_split(w.T, g->C, g->K, &cps);
+    return al256((size_t)16 * w.T * g->C * 4) + al256((size_t)16 * w.T * g->K * 4) + al256((size_t)ns * 16 * g->C * g->K * 4);
+}
+
+// a: make_args(x, dy, dw, g) of the FORWARD geometry (a.x = x, a.w = dy, a.y unused); dw [3][3][C][K]
+int launch_wino_wgrad(const ConvArgs& a, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    const WinoGeom w = make_wgeom(a.N, a.H, a.W, a.OH, a.OW, a.dil, a.pad_t);
+    int cps;
+    const int ns = wgrad_split(w.T, a.C, a.K, &cps);
+    const size_t vb = al256((size_t)16 * w.T * a.C * 4), yb = al256((size_t)16 * w.T * a.K * 4), sb = al256((size_t)ns * 16 * a.C * a.K * 4);
+    if (!ws || ws_bytes < vb + yb + sb) {
+        pnp_set_error("launch_wino_wgrad: workspace too small (%zu < %zu)", ws_bytes, vb + yb + sb);
+        return PNP_EWORKSPACE;
+    }
+    float* V = (float*)ws;
+    float* Y = (float*)((char*)ws + vb);
+    float* S = (float*)((char*)ws + vb + yb);
+    {
+        WinoInArgs ia{};
+        ia.x = a.x; ia.V = V; ia.g = w; ia.C = a.C; ia.x_bytes = a.x_bytes;
+        long long nb = (long long)(((size_t)w.T * (a.C / 4) + NT - 1) / NT);
+        if (nb > 65536) nb = 65536;
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)a.N * a.H * a.W * a.C + 16.0 * w.T * a.C), "wino_in_kernel");
+        hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)nb), dim3(NT), 0, st, ia);
+        PNP_CHECK_LAUNCH("wino_in_kernel");
+    }
+    {
+        WinoDyArgs da{};
+        da.dy = a.w; da.Y = Y; da.g = w; da.K = a.K;
+        long long nb = (long long)(((size_t)w.T * (a.K / 4) + NT - 1) / NT);
+        if (nb > 65536) nb = 65536;
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)a.M * a.K + 16.0 * w.T * a.K), "wino_dy_kernel");
+        hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)nb), dim3(NT), 0, st, da);
+        PNP_CHECK_LAUNCH("wino_dy_kernel");
+    }
+    {
+        WinoWgradGemmArgs ga{};
+        ga.V = V; ga.Y = Y; ga.S = S; ga.T = w.T; ga.C = a.C; ga.K = a.K;
+        ga.nblk_m = pnp_cdiv(a.C, 128); ga.nblk_n = pnp_cdiv(a.K, 128);
+        ga.nsplit = ns; ga.chunks_per_split = cps; ga.xcd_swizzle = a.xcd_swizzle;
+        dim3 grid((unsigned)(ga.nblk_m * ga.nblk_n * 16 * ns));
+        const double fl = 2.0 * 16.0 * (double)w.T * a.C * a.K;
+        const double by = 4.0 * 16.0 * ((double)w.T * a.C + (double)w.T * a.K + (double)ns * a.C * a.K);
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, fl, by, "wino_wgrad_gemm_kernel<128, 128, 2, 2>");
+        hipLaunchKernelGGL((wino_wgrad_gemm_kernel<128, 128, 2, 2>), grid, dim3(NTHREADS), 0, st, ga);
+        PNP_CHECK_LAUNCH("wino_wgrad_gemm_kernel");
+    }
+    {
+        const size_t nvec = (size_t)a.C * (a.K / 4);
+        hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((nvec + NT - 1) / NT)), dim3(NT), 0, st, (const float*)S, dw, a.C, a.K, ns, accumulate);
+        PNP_CHECK_LAUNCH("wino_wgrad_out_kernel");
+    }
+    return PNP_OK;
+}
+
 }  // namespace pnpconv
 
 // route policy at run time (tests, A/B measurements): mode 0 never / 1 where the cost model says it pays / 2 wherever the geometry
 // allows; mode < 0 only reads.  Returns the previous mode.  The workspace / parts queries follow the mode in force when they are called.
+extern "C" int32_t pnp_conv2d_wino_wgrad_mode(int32_t mode) {
+    const int prev = wino_wgrad_mode();
+    if (mode >= 0) g_wino_wgrad_mode.store(mode > 2 ? 2 : mode, std::memory_order_relaxed);
+    return prev;
+}
 extern "C" int32_t pnp_conv2d_wino_mode(int32_t mode) {
     const int prev = wino_mode();
     if (mode >= 0) g_wino_mode.store(mode > 2 ? 2 : mode, std::memory_order_relaxed);

@@ -114,8 +114,14 @@ def wino_mode(mode=-1):
     return int(_lib.load().pnp_conv2d_wino_mode(int(mode)))
 
 
+def wino_wgrad_mode(mode=-1):
+    """the same switch for the filter gradient (pnp_conv2d_wgrad*); returns the previous mode"""
+    return int(_lib.load().pnp_conv2d_wino_wgrad_mode(int(mode)))
+
+
 def wino_chosen(g, kind=0):
-    """True: pnp_conv2d_fwd* (kind 0) / pnp_conv2d_dgrad* (kind 1, g = the forward geometry) run this layer on the Winograd route"""
+    """True: pnp_conv2d_fwd* (kind 0) / pnp_conv2d_dgrad* (kind 1) / pnp_conv2d_wgrad* (kind 2) run this layer (g = the forward geometry)
+    on the Winograd route"""
     return bool(_lib.load().pnp_conv2d_wino_chosen(ctypes.byref(g), int(kind)))
 
 

@@ -505,3 +505,46 @@ def conv3x3_winograd_np(x, w, dil=1, flip_transpose=False, dtype=np.float32, pad
                 if u < Hso and v < Wso:
                     y[n, a + dil * u, b + dil * v] = o[p, q]
     return y
+
+
+def wgrad3x3_winograd_np(x, dy, dil=1, dtype=np.float32, pad=None, nsplit=1):
+    """Filter gradient of the same convolution the way csrc/conv_wino.hip computes it — the transposition of F(2x2, 3x3):
+      V[pos][t][c] = (B^T d B)[pos]                  the forward's input transform
+      Y[pos][t][k] = (A y A^T)[pos]                  the 2x2 tile of dy spread to the 16 transform points (zeros for pixels outside the image)
+      S[z][pos]    = V[pos][rows of split z]^T @ Y[pos][rows of split z]      16 GEMMs [C x T] x [T x K], reduction over tiles split nsplit ways
+      dW           = G^T (sum_z S[z]) G              4x4 -> 3x3
+    x: [N][H][W][C], dy: [N][Ho][Wo][K] numpy -> [3][3][C][K]."""
+    x, dy = np.asarray(x, dtype), np.asarray(dy, dtype)
+    pad = dil if pad is None else pad
+    ps = pad // dil
+    N, Hi, Wi, C = x.shape
+    Ho, Wo, K = dy.shape[1], dy.shape[2], dy.shape[3]
+    assert Ho == Hi + 2 * pad - 2 * dil and Wo == Wi + 2 * pad - 2 * dil
+    Hsi, Wsi = Hi // dil, Wi // dil
+    Hso, Wso, th, tw, T = wino_tiles(N, Ho, Wo, dil)
+    BT, G, A = WINO_BT.astype(dtype), WINO_G.astype(dtype), WINO_AT.T.astype(dtype)
+    V = np.zeros((16, T, C), dtype)
+    Y = np.zeros((16, T, K), dtype)
+    for t in range(T):
+        n, a, b, ti, tj = wino_tile_coords(t, dil, th, tw)
+        d = np.zeros((4, 4, C), dtype)
+        for i in range(4):
+            for j in range(4):
+                u, v = 2 * ti - ps + i, 2 * tj - ps + j
+                if 0 <= u < Hsi and 0 <= v < Wsi:
+                    d[i, j] = x[n, a + dil * u, b + dil * v]
+        V[:, t, :] = np.einsum("ipc,jp->ijc", np.einsum("ip,pjc->ijc", BT, d).astype(dtype), BT).astype(dtype).reshape(16, C)
+        y = np.zeros((2, 2, K), dtype)
+        for p in range(2):
+            for q in range(2):
+                u, v = 2 * ti + p, 2 * tj + q
+                if u < Hso and v < Wso:
+                    y[p, q] = dy[n, a + dil * u, b + dil * v]
+        Y[:, t, :] = np.einsum("iqk,jq->ijk", np.einsum("ip,pqk->iqk", A, y).astype(dtype), A).astype(dtype).reshape(16, K)
+    rows = -(-T // nsplit)
+    S = np.zeros((16, C, K), dtype)
+    for z in range(nsplit):
+        sl = slice(z * rows, min((z + 1) * rows, T))
+        S += np.stack([V[p, sl].T @ Y[p, sl] for p in range(16)]).astype(dtype)
+    S = S.reshape(4, 4, C, K)
+    return np.einsum("rjck,js->rsck", np.einsum("ir,ijck->rjck", G, S).astype(dtype), G).astype(dtype)

@@ -79,11 +79,12 @@ def test_host_planners_through_the_workspace_queries(built):
     import ctypes
     lib = built._lib.load()
     K = pkg("kernels")
-    prev = K.wino_mode(0)            # the planners of the DIRECT kernels (the Winograd route's own: test_winograd_route_planner_on_the_host)
+    prev, prev_w = K.wino_mode(0), K.wino_wgrad_mode(0)     # the planners of the DIRECT kernels (the Winograd route's own: test_winograd_route_planner_on_the_host)
     try:
         _direct_planners(lib, K, ctypes)
     finally:
         K.wino_mode(prev)
+        K.wino_wgrad_mode(prev_w)
 
 
 def _direct_planners(lib, K, ctypes):
@@ -226,6 +227,21 @@ def test_winograd_route_planner_on_the_host(built):
         # statistics partial rows = tile slabs of the output transform (~1024 per channel slice, a multiple of the tiles per pass)
         assert K.conv_stats_parts(geo(16, 32, 512, 512)) == 4096 // 4 and K.conv_stats_parts(geo(16, 34, 512, 2560, pad="VALID")) == 4096 // 4
         assert K.conv_stats_parts(geo(16, 32, 128, 128)) == int(lib.pnp_conv2d_fwd_stats_parts(ctypes.byref(geo(16, 32, 128, 128))))
+        # the filter gradient has its own switch; workspace = V + Y + split partials of the 16 [C x K] products
+        prev_w = K.wino_wgrad_mode(0)
+        try:
+            g = geo(16, 32, 512, 512)
+            direct = int(lib.pnp_conv2d_wgrad_workspace_bytes(ctypes.byref(g)))
+            assert not K.wino_chosen(g, 2) and direct % (9 * 512 * 512 * 4) == 0
+            K.wino_wgrad_mode(1)
+            assert K.wino_chosen(g, 2) and K.wino_chosen(geo(16, 32, 256, 256), 2) and not K.wino_chosen(geo(16, 32, 128, 256), 2)      # break-even 256 -> 256
+            assert not K.wino_chosen(geo(16, 32, 128, 128), 2) and not K.wino_chosen(geo(16, 64, 256, 256, stride=2), 2)
+            T = 16 * 16 * 16                    # 256 tiles of 128 x 128 x 16 points: split in two to fill a dispatch round
+            assert int(lib.pnp_conv2d_wgrad_workspace_bytes(ctypes.byref(g))) == 16 * 4 * (T * 512 + T * 512 + 2 * 512 * 512)
+            g10 = geo(16, 34, 512, 2560, pad="VALID")       # 1280 tiles: un-split
+            assert int(lib.pnp_conv2d_wgrad_workspace_bytes(ctypes.byref(g10))) == 16 * 4 * (T * 512 + T * 2560 + 512 * 2560)
+        finally:
+            K.wino_wgrad_mode(prev_w)
     finally:
         K.wino_mode(prev)
     assert K.wino_mode(-1) == prev

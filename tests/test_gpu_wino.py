@@ -45,11 +45,12 @@ def _ran(L, fn, cls):
 
 @pytest.fixture
 def wino():
-    """yields a setter of the route policy; restores the mode in force before the test"""
+    """yields a setter of the route policy; restores the modes in force before the test (forward / data gradient and filter gradient)"""
     K = pkg("kernels")
-    prev = K.wino_mode(-1)
+    prev, prev_w = K.wino_mode(-1), K.wino_wgrad_mode(-1)
     yield K.wino_mode
     K.wino_mode(prev)
+    K.wino_wgrad_mode(prev_w)
 
 
 def _where(err, K_):
@@ -90,8 +91,21 @@ def test_winograd_fwd_dgrad_vs_float64_and_direct(dev, wino, case):
     dx1, names2 = _ran(L, lambda: K.conv2d_dgrad(dyd, wd, g), L.PROF_CONV_DGRAD)
     assert sorted(n.split("<")[0] for n in names2) == ["wino_gemm_kernel", "wino_in_kernel", "wino_out_kernel"], names2
     dxr = K.conv2d_dgrad(dyd, wd, g, residual=resd)
+    # the filter gradient on the route (its own switch): plain and added into a buffer that already holds a contribution
+    wg = torch.from_numpy(w).double().requires_grad_(True)
+    T.conv2d(torch.from_numpy(x).double(), wg, 1, dil, padding).backward(torch.from_numpy(dy).double())
+    K.wino_wgrad_mode(0)
+    assert not K.wino_chosen(g, 2)
+    dw0 = K.conv2d_wgrad(xd, dyd, g)
+    K.wino_wgrad_mode(2)
+    assert K.wino_chosen(g, 2)
+    dw1, names3 = _ran(L, lambda: K.conv2d_wgrad(xd, dyd, g), L.PROF_CONV_WGRAD)
+    assert sorted(n.split("<")[0] for n in names3) == ["wino_dy_kernel", "wino_in_kernel", "wino_wgrad_gemm_kernel"], names3
+    held = torch.from_numpy(rng.standard_normal(w.shape).astype(np.float32)).to(dev)
+    dwa = K.conv2d_wgrad(xd, dyd, g, into=held.clone())
     errs = {"y direct": _rel(y0, yo), "y wino": _rel(y1, yo), "dx direct": _rel(dx0, xg.grad), "dx wino": _rel(dx1, xg.grad),
-            "dx+res wino": _rel(dxr, xg.grad + torch.from_numpy(res).double())}
+            "dx+res wino": _rel(dxr, xg.grad + torch.from_numpy(res).double()), "dw direct": _rel(dw0, wg.grad), "dw wino": _rel(dw1, wg.grad),
+            "dw+held wino": _rel(dwa, wg.grad + held.cpu().double())}
     print("wino %s: %s" % (case, {k: "%.2e" % v for k, v in errs.items()}))
     if errs["y wino"] > BAR:
         print("  forward mismatch:", _where(y1.cpu().double() - yo.detach(), Kf))
@@ -142,7 +156,7 @@ def test_winograd_epilogues_equal_the_direct_route(dev, wino):
 
 def test_segmenter_step_on_the_winograd_route(dev, wino):
     """one source-segmenter train step (source_segmenter.py:484-489) with the planner's own choice (mode 1) against the direct kernels
-    (mode 0): the wide layers really take the route (wino_gemm_kernel in both passes), loss and every gradient agree to fp32 rounding
+    (mode 0): the wide layers really take the route (wino_gemm_kernel in both passes, wino_wgrad_gemm_kernel for the filter gradients), loss and every gradient agree to fp32 rounding
     through 33 convolutions (cosine over the whole gradient arena, loss to 1e-5)"""
     ss, L, K = pkg("source_segmenter"), pkg("_lib"), pkg("kernels")
     B = 4
@@ -153,11 +167,12 @@ def test_segmenter_step_on_the_winograd_route(dev, wino):
     res = {}
     for mode in (0, 1):
         wino(mode)
+        K.wino_wgrad_mode(mode)
         net = ss.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, cost_kwargs={"cross_flag": True, "miu_cross": 1.0, "dice_flag": True, "miu_dice": 1.0, "regularizer": 1e-4}, seed=0)
         tr = ss.Trainer(net, None, None, num_cls=5, batch_size=B, optimizer="adam", opt_kwargs={"learning_rate": 1e-3})
         tr.opt = tr._get_optimizer(10)
         L.prof_summary()
-        L.prof_enable(L.PROF_CONV_FWD | L.PROF_CONV_DGRAD)
+        L.prof_enable(L.PROF_CONV_FWD | L.PROF_CONV_DGRAD | L.PROF_CONV_WGRAD)
         loss = float(tr.train_step(x, y, 0.75, 11))
         torch.cuda.synchronize()
         L.prof_enable(0)
@@ -165,6 +180,7 @@ def test_segmenter_step_on_the_winograd_route(dev, wino):
         res[mode] = (loss, net.store.grad_arena.clone(), net.store.arena.clone(), names)
     (l0, g0, w0, n0), (l1, g1, w1, n1) = res[0], res[1]
     assert not any("wino" in n for n in n0)
+    assert any(n.startswith("wino_wgrad_gemm_kernel") for n in n1), sorted(set(n1))
     assert any(n.startswith("wino_gemm_kernel<128, 128, 2, 2, 0>") for n in n1) and any(n.startswith("wino_gemm_kernel<128, 128, 2, 2, 1>") for n in n1), sorted(set(n1))
     cos = float(torch.nn.functional.cosine_similarity(g0.double().flatten(), g1.double().flatten(), dim=0))
     cw = float(torch.nn.functional.cosine_similarity(w0.double().flatten(), w1.double().flatten(), dim=0))

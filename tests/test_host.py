@@ -615,6 +615,11 @@ def test_winograd_restatement_equals_the_direct_convolution():
         ref.backward(torch.from_numpy(dy))
         gd = T.conv3x3_winograd_np(dy, w, d, flip_transpose=True, dtype=np.float64, pad=2 * d - pad)
         assert gd.shape == x.shape and np.allclose(gd, xt.grad.numpy(), rtol=1e-12, atol=1e-12), (N, H, W, C, K, d, pad)
+        # the filter gradient: the transposed algorithm (dy tile spread to the transform points, reduction over tiles split 3 ways)
+        wt = torch.from_numpy(w).requires_grad_(True)
+        T.conv2d(torch.from_numpy(x), wt, 1, d, "SAME" if pad == d else "VALID").backward(torch.from_numpy(dy))
+        gw = T.wgrad3x3_winograd_np(x, dy, d, dtype=np.float64, pad=pad, nsplit=3)
+        assert gw.shape == w.shape and np.allclose(gw, wt.grad.numpy(), rtol=1e-12, atol=1e-11), (N, H, W, C, K, d, pad)
     x = rng.standard_normal((1, 8, 8, 512)).astype(np.float32)
     w = (rng.standard_normal((3, 3, 512, 32)) * 0.02).astype(np.float32)
     ref = T.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), 1, 1, "SAME").numpy()

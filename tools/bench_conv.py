@@ -15,6 +15,8 @@ PEAK = 2500.0 if DTYPE == "bf16" else 157.3
 B = int(os.environ.get("B", 16))
 if os.environ.get("WINO") is not None:          # route of the wide stride-1 3x3 layers (csrc/conv_wino.hip): 0 direct, 1 planner, 2 wherever eligible
     K.wino_mode(int(os.environ["WINO"]))
+if os.environ.get("WINO_WGRAD") is not None:    # the same for the filter gradient
+    K.wino_wgrad_mode(int(os.environ["WINO_WGRAD"]))
 SKIP_WGRAD = bool(os.environ.get("SKIP_WGRAD"))
 LAYERS = [  # name, H, C, K, R, dil, padding, count in segmenter fwd
     ("g1 3->16", 256, 3, 16, 3, 1, "SAME", 1),
@@ -82,8 +84,8 @@ def main():
         td = timeit(lambda: K.conv2d_dgrad(dy, w, g))
         tw = float('nan') if SKIP_WGRAD else timeit(lambda: K.conv2d_wgrad(x, dy, g))
         print("%-18s %9.2f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f%s" % (name, flop / 1e9, tf, flop / tf / 1e9, td, flop / td / 1e9, tw,
-                                                                     flop / tw / 1e9, "  [winograd fwd/dgrad: %d/%d]" % (K.wino_chosen(g, 0), K.wino_chosen(g, 1))
-                                                                     if (K.wino_chosen(g, 0) or K.wino_chosen(g, 1)) else ""))
+                                                                     flop / tw / 1e9, "  [winograd fwd/dgrad/wgrad: %d/%d/%d]" % (K.wino_chosen(g, 0), K.wino_chosen(g, 1), K.wino_chosen(g, 2))
+                                                                     if (K.wino_chosen(g, 0) or K.wino_chosen(g, 1) or K.wino_chosen(g, 2)) else ""))
         tot["fwd"] += tf * cnt
         tot["dgrad"] += td * cnt
         tot["wgrad"] += tw * cnt
