@@ -480,7 +480,9 @@ def main():
                                         "algorithmic FLOP (2*N*OH*OW*R*S*C*K) / sum of launch durations, HIP events recorded by libpnp_hip.so on the "
                                         "launch stream around every launch of the symbol in the first %d steps of the timed region; `traffic` = HBM-side "
                                         "bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, separate passes; "
-                                        "`traffic_source` names the file), null if absent" % PROBE_STEPS)
+                                        "`traffic_source` names the file), null if absent.  Symbols of the Winograd route (csrc/conv_wino.hip): `wino_gemm_kernel` / "
+                                        "`wino_wgrad_gemm_kernel` are priced at the flops they EXECUTE (2*16*T*C*K, T = tiles = pixels/4: 2.25x fewer than the "
+                                        "convolution's 2*N*OH*OW*9*C*K), their transform kernels appear as HBM-bound rows (bytes / duration against 8 TB/s)" % PROBE_STEPS)
                 res["roofline_kernels"] = recs
                 fl, ms = sum(r["flops"] for r in rows), sum(r["ms"] for r in rows)
                 res["roofline_all_mfma_convs"] = {"achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "frac": fl / (ms * 1e-3) / 1e12 / peak,

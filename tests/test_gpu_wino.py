@@ -1,4 +1,5 @@
-"""-m gpu: the Winograd F(2x2, 3x3) route of the wide stride-1 3x3 convolutions (csrc/conv_wino.hip), forward and data gradient.
+"""-m gpu: the Winograd F(2x2, 3x3) route of the wide stride-1 3x3 convolutions (csrc/conv_wino.hip): forward, data gradient and filter
+gradient (the transposed algorithm).
 
 Oracle: the float64 convolution (oracle.tf_ops.conv2d / autograd) of the same float32 operands; bar 2e-5 of max|ref| (the direct fp32
 kernels land at 1e-7..5e-6 on the same cases; the Winograd transforms add ~1 ulp in front of and behind the contraction).  Every case
