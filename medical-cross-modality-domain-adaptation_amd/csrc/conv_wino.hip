@@ -767,7 +767,7 @@ int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size
 
 bool wino_wgrad_chosen(const pnp_conv_geom* g) {
     const int mode = wino_wgrad_mode();
-    if (mode <= 0 || !wino_eligible(g)) return false;
+    if (mode <= 0 || wino_mode() <= 0 || !wino_eligible(g)) return false;        // PNP_WINOGRAD=0 switches the whole route off
     if (mode >= 2) return true;
     // measured at B = 16 (profiles/r04_conv_layers_wino_wgrad_B16.txt, direct ring kernel -> route): 512->512 0.610 -> 0.350 ms, g10 3.022 ->
     // 1.516, 256->512 0.331 -> 0.217, 256->256 0.193 -> 0.142 (@64^2: 0.615 -> 0.425), 128->256@32^2 0.120 -> 0.131: two transforms in front of

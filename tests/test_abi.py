@@ -238,6 +238,9 @@ def test_winograd_route_planner_on_the_host(built):
             assert not K.wino_chosen(geo(16, 32, 128, 128), 2) and not K.wino_chosen(geo(16, 64, 256, 256, stride=2), 2)
             T = 16 * 16 * 16                    # 256 tiles of 128 x 128 x 16 points: split in two to fill a dispatch round
             assert int(lib.pnp_conv2d_wgrad_workspace_bytes(ctypes.byref(g))) == 16 * 4 * (T * 512 + T * 512 + 2 * 512 * 512)
+            K.wino_mode(0)
+            assert not K.wino_chosen(g, 2)              # PNP_WINOGRAD=0 is the master switch of the route
+            K.wino_mode(1)
             g10 = geo(16, 34, 512, 2560, pad="VALID")       # 1280 tiles: un-split
             assert int(lib.pnp_conv2d_wgrad_workspace_bytes(ctypes.byref(g10))) == 16 * 4 * (T * 512 + T * 2560 + 512 * 2560)
         finally:
