@@ -125,3 +125,28 @@ def test_gpu_suite_wall_time_guard():
     assert conftest.GPU_SUITE_BUDGET_S <= 900
     assert conftest.suite_over_budget(901.0, 170, 900.0) and not conftest.suite_over_budget(899.0, 170, 900.0)
     assert not conftest.suite_over_budget(5000.0, 0, 900.0)          # the CPU suite ran no GPU test
+
+
+def test_bench_prices_the_winograd_transforms_against_the_hbm_roof():
+    """the transform kernels of the Winograd route carry no contraction (flops = 0 in pnp_prof_*): bench.roofline_records reports them as
+    HBM-bound rows (algorithmic bytes / duration against 8 TB/s); a GEMM symbol next to them stays an MFMA row; a compact record whose
+    dominant symbol is an HBM row still round-trips"""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rows = [{"name": "wino_gemm_kernel<128, 128, 2, 2, 0>", "ms": 42.0, "launches": 200, "flops": 200 * 2.7e10, "bytes": 200 * 2.5e8},
+            {"name": "wino_in_kernel", "ms": 6.0, "launches": 200, "flops": 0.0, "bytes": 200 * 1.45e8},
+            {"name": "wino_out_kernel", "ms": 60.0, "launches": 200, "flops": 0.0, "bytes": 200 * 1.6e8}]
+    recs = bench.roofline_records(rows, bench.PEAK_FP32_MFMA_TFLOPS)
+    by = {r["kernel"]: r for r in recs}
+    g, i = by["wino_gemm_kernel<128, 128, 2, 2, 0>"], by["wino_in_kernel"]
+    assert g["bound"] == "mfma" and g["unit"] == "TFLOP/s" and abs(g["achieved"] - 200 * 2.7e10 / 42e-3 / 1e12) < 1e-6
+    assert i["bound"] == "hbm" and i["unit"] == "GB/s" and i["peak"] == bench.PEAK_HBM_GBS
+    assert abs(i["achieved"] - 200 * 1.45e8 / 6e-3 / 1e9) < 1e-3 and abs(i["frac"] - i["achieved"] / 8000.0) < 1e-9
+    assert recs[0]["kernel"] == "wino_out_kernel" and recs[0]["bound"] == "hbm"          # sorted by time, whatever the bound
+    rec = bench.compact_record({"metric": "m", "value": 1.0, "unit": "slices/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+                                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                                "config": {"workload": "w"}, "roofline": dict(recs[0])})
+    back = json.loads(json.dumps(rec))
+    assert back["roofline"]["bound"] == "hbm" and back["roofline"]["unit"] == "GB/s"
