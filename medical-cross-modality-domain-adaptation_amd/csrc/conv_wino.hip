@@ -1,4 +1,5 @@
-// conv_wino.hip — Winograd F(2x2, 3x3) route for the wide stride-1 3x3 convolutions (forward and data gradient) on fp32 matrix cores.
+// conv_wino.hip — Winograd F(2x2, 3x3) route for the wide stride-1 3x3 convolutions (forward, data gradient, filter gradient) on fp32
+// matrix cores.
 //
 // Replaces, for the layers the planner picks, the direct implicit GEMM of conv_igemm.hip behind the same entry points
 // (tf.nn.conv2d / tf.nn.atrous_conv2d at /root/reference/layers.py:18,24,67,73,86,92 and their TF-autodiff data gradients): the
@@ -13,6 +14,7 @@
 //                                                         the 128x128 tile / 4-slice register pipeline of conv_taps_kernel
 //   y tile       = A^T M A            wino_out_kernel     + the whole convolution epilogue: dropout, residual add, BN statistics partials,
 //                                                         fused inference BN + shortcut + leaky-ReLU (conv_common.h: conv_epilogue's order)
+// (the filter gradient is the transposed algorithm on the same V: second half of this file.)
 // pos = 4 i + j indexes the 16 points of the transformed 4x4 tile.  V and M pass through HBM (workspace): 4x the input / output size
 // each, which is why the route only pays where the contraction is deep — the planner takes it when C K / (C + K) >= 85 (128->256 up).
 // A dilation-d SAME convolution is d x d independent dense convolutions of the sub-images (a + d u, b + d v): the tile enumeration
