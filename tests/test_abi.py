@@ -248,3 +248,43 @@ def test_winograd_route_planner_on_the_host(built):
     finally:
         K.wino_mode(prev)
     assert K.wino_mode(-1) == prev
+
+
+def test_winograd_eligibility_and_tile_count_agree_with_the_restatement(built):
+    """random geometries: the C planner's eligibility (mode 2 = wherever the geometry allows) is exactly the set of conditions the numpy
+    restatement needs (stride 1, 3x3, zero padding 0 / dil / 2 dil on both axes, extents divisible by the dilation, C % 32, K % 4, K >= 32,
+    fp32), and its workspace is 16 x (C K + T C + T K) floats with the restatement's tile count T"""
+    import ctypes
+    import importlib
+    import numpy as np
+    from oracle import tf_ops as T_
+    K, L = importlib.import_module(built.__name__ + ".kernels"), built._lib
+    lib = L.load()
+    rng = np.random.default_rng(21)
+    prev = K.wino_mode(2)
+    try:
+        seen = {True: 0, False: 0}
+        for _ in range(400):
+            N, H, W = int(rng.integers(1, 5)), int(rng.integers(2, 40)), int(rng.integers(2, 40))
+            C, Kf = int(rng.choice([3, 16, 32, 64, 96, 100])), int(rng.choice([5, 16, 32, 36, 64, 130]))
+            k, stride, dil = int(rng.choice([3, 3, 3, 5])), int(rng.choice([1, 1, 1, 2])), int(rng.choice([1, 1, 2, 3]))
+            pad = int(rng.choice([0, dil, 2 * dil, 1]))
+            g = L.ConvGeom()
+            g.N, g.H, g.W, g.C, g.K, g.R, g.S = N, H, W, C, Kf, k, k
+            g.stride, g.dil, g.pad_t, g.pad_l, g.pad_mode, g.dtype = stride, dil, pad, pad, L.PAD_ZERO, L.DTYPE_F32
+            eff = (k - 1) * dil + 1
+            if H + 2 * pad < eff or W + 2 * pad < eff:
+                continue
+            g.OH, g.OW = (H + 2 * pad - eff) // stride + 1, (W + 2 * pad - eff) // stride + 1
+            want = (k == 3 and stride == 1 and dil <= 2 and pad % dil == 0 and pad <= 2 * dil and H % dil == 0 and W % dil == 0
+                    and g.OH % dil == 0 and g.OW % dil == 0 and C % 32 == 0 and Kf % 4 == 0 and Kf >= 32)
+            got = K.wino_chosen(g, 0)
+            assert got == want, (N, H, W, C, Kf, k, stride, dil, pad, got, want)
+            seen[want] += 1
+            if want:
+                Tn = T_.wino_tiles(N, g.OH, g.OW, dil)[4]
+                al = lambda b: (b + 255) // 256 * 256
+                assert int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))) == al(64 * C * Kf) + al(64 * Tn * C) + al(64 * Tn * Kf)
+        assert seen[True] >= 10 and seen[False] >= 100, seen
+    finally:
+        K.wino_mode(prev)
