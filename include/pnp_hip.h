@@ -115,9 +115,15 @@ int pnp_conv2d_fwd_stats_ws(const float* x, const float* w, float* y, const pnp_
                             float keep_prob, uint64_t seed, uint32_t stream_id,
                             const float* shift /*nullable*/, float* parts, size_t parts_bytes,
                             void* workspace, size_t workspace_bytes, void* stream);
-int32_t pnp_conv2d_wino_chosen(const pnp_conv_geom* g, int32_t kind);
+int32_t pnp_conv2d_wino_chosen(const pnp_conv_geom* g, int32_t kind);   /* 0: direct kernels; else the route's output tile edge (2 or 4) */
 /* sets the route policy at run time (0 / 1 / 2 as PNP_WINOGRAD; < 0: read only) and returns the previous one */
 int32_t pnp_conv2d_wino_mode(int32_t mode);
+/* Round 5: the route has two output tiles.  F(4x4, 3x3) — 36 multiplications per 4x4 output tile instead of the direct sum's 144
+ * (F(2x2): 64), transformed tensors 2.25x the activations (F(2x2): 4x) — on the interpolation points (0, 1, -1, 1/2, -2, inf), whose
+ * float32 error against the float64 convolution is the direct kernel's (3e-6..5e-6 of max|y| on the 256- / 512-channel layers;
+ * profiles/r05_wino_f43_tolerance.txt).  tile = 2: F(2x2) only; 4 (the default, environment PNP_WINOGRAD_TILE): F(4x4) where its planner
+ * takes the layer, else F(2x2), else the direct kernels; tile < 2: read only.  Returns the previous value. */
+int32_t pnp_conv2d_wino_tile(int32_t tile);
 /* the filter gradient (pnp_conv2d_wgrad / _wgrad_acc, given pnp_conv2d_wgrad_workspace_bytes) has its own switch (PNP_WINOGRAD_WGRAD,
  * same values); pnp_conv2d_wino_chosen(g, 2) tells its route */
 int32_t pnp_conv2d_wino_wgrad_mode(int32_t mode);

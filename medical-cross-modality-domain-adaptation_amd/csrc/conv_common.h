@@ -375,13 +375,17 @@ int launch_n16_wgrad(const ConvArgs& a, float* part, hipStream_t st);
 // run it; chosen: eligible and the policy takes it (PNP_WINOGRAD = 0 never / 1 where the cost model says it pays / 2 wherever eligible).
 // launch_wino honours the whole epilogue of ConvArgs (dropout, residual add, statistics partials, fused inference BN); its statistics
 // partial rows are the tile slabs of the output transform (wino_stats_parts), not the direct kernel's wave rows.
+// Round 5: the route has two output tiles, F(2x2, 3x3) and F(4x4, 3x3) (36 instead of 64 multiplications per 4x4 outputs; PNP_WINOGRAD_TILE /
+// pnp_conv2d_wino_tile: the largest the planner may pick).  wino_tile: 0 (direct kernels), 2 or 4 for the forward of this geometry.
 bool wino_eligible(const pnp_conv_geom* g);
 bool wino_chosen(const pnp_conv_geom* g);
+int wino_tile(const pnp_conv_geom* g);
 size_t wino_workspace_bytes(const pnp_conv_geom* g);
 int wino_stats_parts(const pnp_conv_geom* g);
 int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size_t ws_bytes, hipStream_t st);
 // the filter gradient on the same route (its own switch, PNP_WINOGRAD_WGRAD): a = make_args(x, dy, -, g) of the forward geometry
 bool wino_wgrad_chosen(const pnp_conv_geom* g);
+int wino_wgrad_tile(const pnp_conv_geom* g);
 size_t wino_wgrad_workspace_bytes(const pnp_conv_geom* g);
 int launch_wino_wgrad(const ConvArgs& a, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 inline double conv_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.K * a.Kred; }

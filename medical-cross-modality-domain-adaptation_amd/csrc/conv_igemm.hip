@@ -2331,8 +2331,8 @@ static bool dgrad_wino(const pnp_conv_geom* g, pnp_conv_geom* d) {
 int32_t pnp_conv2d_wino_chosen(const pnp_conv_geom* g, int32_t kind) {
     if (!g || check_geom(g, "pnp_conv2d_wino_chosen") != PNP_OK) return 0;
     pnp_conv_geom d;
-    if (kind == 2) return wino_wgrad_chosen(g) ? 1 : 0;
-    return kind == 0 ? (wino_chosen(g) ? 1 : 0) : (dgrad_wino(g, &d) ? 1 : 0);
+    if (kind == 2) return wino_wgrad_tile(g);
+    return kind == 0 ? wino_tile(g) : (dgrad_wino(g, &d) ? wino_tile(&d) : 0);
 }
 
 size_t pnp_conv2d_dgrad_workspace_bytes(const pnp_conv_geom* g) {

@@ -1,5 +1,5 @@
-// conv_wino.hip — Winograd F(2x2, 3x3) route for the wide stride-1 3x3 convolutions (forward, data gradient, filter gradient) on fp32
-// matrix cores.
+// conv_wino.hip — Winograd F(2x2, 3x3) and F(4x4, 3x3) routes for the wide stride-1 3x3 convolutions (forward, data gradient, filter
+// gradient) on fp32 matrix cores.
 //
 // Replaces, for the layers the planner picks, the direct implicit GEMM of conv_igemm.hip behind the same entry points
 // (tf.nn.conv2d / tf.nn.atrous_conv2d at /root/reference/layers.py:18,24,67,73,86,92 and their TF-autodiff data gradients): the
@@ -23,6 +23,14 @@
 //
 // Arithmetic: every product and sum in fp32; the transforms add a rounding of ~1 ulp per element in front of and behind the
 // contraction (measured against float64: same 1e-6 level as the direct kernel, tests/test_gpu_wino.py), inside north_star's 1e-4.
+//
+// F(4x4, 3x3) (round 5; every transform kernel is a template on the output tile edge M = 2 / 4): a 4x4 output tile from a 6x6 patch with 36
+// multiplications instead of 144 — 4x fewer MFMA flops than the direct sum (F(2x2): 2.25x), V and M are 2.25x the input / output (F(2x2):
+// 4x), the GEMM kernels are the same with 36 transform points.  The price is rounding: the transforms are no longer pure additions.  On the
+// interpolation points (0, 1, -1, 1/2, -2, inf) the float32 error against the float64 convolution is 3e-6..5e-6 of max|y| on the 256- /
+// 512-channel layers — the direct fp32 kernel's level (2e-6..3e-6), Lavin & Gray's classic (0, +-1, +-2) lands at 1e-5 — forward, data and
+// filter gradient alike (tools/wino_f43_study.py -> profiles/r05_wino_f43_tolerance.txt; oracle/tf_ops.py WINO4_* are the matrices).
+// B^T and A^T are exact in binary on these points; G has thirds and fifteenths (rounded once, as float32 constants).
 #include <atomic>
 #include "conv_common.h"
 #include "conv_mma.h"
@@ -40,7 +48,58 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // data gradient of a VALID convolution); Hsi / Hso ...: extents of one dilation phase's sub-image; tiles enumerate the OUTPUT
 struct WinoGeom {
     int N, Hi, Wi, Ho, Wo, dil, ps, Hsi, Wsi, Hso, Wso, th, tw, T;
+    int m;        // output tile edge: 2 (F(2x2, 3x3)) or 4 (F(4x4, 3x3))
 };
+
+// ---- the 1-D transforms of F(4, 3) on the points (0, 1, -1, 1/2, -2, inf) (oracle/tf_ops.py: WINO4_BT / WINO4_G / WINO4_AT) --------------
+// B^T d (6 -> 6): every coefficient exact in binary
+template <typename V>
+__device__ __forceinline__ void w4_bt(const V& d0, const V& d1, const V& d2, const V& d3, const V& d4, const V& d5, V* o) {
+    o[0] = (d0 + d4) + (1.5f * (d3 - d1) - 2.f * d2);
+    o[1] = (d4 - d1) + (0.5f * d2 + 2.5f * d3);
+    o[2] = (d4 + d1) + (0.5f * d3 - 2.5f * d2);
+    o[3] = (d4 - d2) + 2.f * (d3 - d1);
+    o[4] = (d4 - d2) + 0.5f * (d1 - d3);
+    o[5] = (d1 + d5) + (1.5f * (d4 - d2) - 2.f * d3);
+}
+// A^T m (6 -> 4)
+template <typename V>
+__device__ __forceinline__ void w4_at(const V& m0, const V& m1, const V& m2, const V& m3, const V& m4, const V& m5, V* o) {
+    const V s = m1 + m2, d = m1 - m2;
+    o[0] = (m0 + s) + (m3 + m4);
+    o[1] = d + (0.5f * m3 - 2.f * m4);
+    o[2] = s + (0.25f * m3 + 4.f * m4);
+    o[3] = (d + m5) + (0.125f * m3 - 8.f * m4);
+}
+// A y (4 -> 6): the transposition of A^T (filter gradient: the dy tile spread to the transform points)
+template <typename V>
+__device__ __forceinline__ void w4_a(const V& y0, const V& y1, const V& y2, const V& y3, V* z) {
+    const V e = y0 + y2, o = y1 + y3;
+    z[0] = y0;
+    z[1] = e + o;
+    z[2] = e - o;
+    z[3] = (y0 + 0.5f * y1) + (0.25f * y2 + 0.125f * y3);
+    z[4] = (y0 - 2.f * y1) + (4.f * y2 - 8.f * y3);
+    z[5] = y3;
+}
+constexpr float W4_3 = 1.f / 3.f, W4_15 = 1.f / 15.f;
+// G g (3 -> 6)
+template <typename V>
+__device__ __forceinline__ void w4_g(const V& g0, const V& g1, const V& g2, V* t) {
+    t[0] = g0;
+    t[1] = W4_3 * ((g0 + g2) + g1);
+    t[2] = W4_3 * (g1 - (g0 + g2));
+    t[3] = -W4_15 * ((16.f * g0 + 4.f * g2) + 8.f * g1);
+    t[4] = W4_15 * ((g0 + 4.f * g2) - 2.f * g1);
+    t[5] = g2;
+}
+// G^T s (6 -> 3): the transposition of G (filter gradient: transform points -> taps)
+template <typename V>
+__device__ __forceinline__ void w4_gt(const V& s0, const V& s1, const V& s2, const V& s3, const V& s4, const V& s5, V* o) {
+    o[0] = s0 + (W4_3 * (s1 - s2) + W4_15 * (s4 - 16.f * s3));
+    o[1] = W4_3 * (s1 + s2) - W4_15 * (8.f * s3 + 2.f * s4);
+    o[2] = s5 + (W4_3 * (s1 - s2) + (4.f * W4_15) * (s4 - s3));
+}
 
 // tile id -> (image, phase a, phase b, tile row, tile column): t = (((n d + a) d + b) th + ti) tw + tj
 __device__ __forceinline__ void tile_of(const WinoGeom& g, int t, int& n, int& a, int& b, int& ti, int& tj) {
@@ -65,7 +124,9 @@ struct WinoInArgs {
     unsigned x_bytes;
 };
 
+template <int M>
 __global__ void __launch_bounds__(NT) wino_in_kernel(WinoInArgs a) {
+    constexpr int P = M + 2;                 // patch edge
     const int C4 = a.C >> 2;
     const size_t nvec = (size_t)a.g.T * C4;
     const size_t plane = (size_t)a.g.T * a.C;
@@ -76,35 +137,52 @@ __global__ void __launch_bounds__(NT) wino_in_kernel(WinoInArgs a) {
         const int c = (int)(i - (size_t)t * C4) * 4;
         int n, pa, pb, ti, tj;
         tile_of(a.g, t, n, pa, pb, ti, tj);
-        f32x4 d[4][4];
+        f32x4 d[P][P];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int u = 2 * ti - a.g.ps + p;
+        for (int p = 0; p < P; ++p) {
+            const int u = M * ti - a.g.ps + p;
             const bool uok = (unsigned)u < (unsigned)a.g.Hsi;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int v = 2 * tj - a.g.ps + q;
+            for (int q = 0; q < P; ++q) {
+                const int v = M * tj - a.g.ps + q;
                 const bool ok = uok & ((unsigned)v < (unsigned)a.g.Wsi);
                 const unsigned off = (unsigned)(((n * a.g.Hi + pa + a.g.dil * u) * a.g.Wi + pb + a.g.dil * v) * a.C + c) * 4u;    // (host: < 2^30 elements)
                 d[p][q] = bload4(rx, ok ? off : OOB);
             }
         }
         // rows (B^T d), then columns ((B^T d) B)
-        f32x4 r[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            r[0][q] = d[0][q] - d[2][q];
-            r[1][q] = d[1][q] + d[2][q];
-            r[2][q] = d[2][q] - d[1][q];
-            r[3][q] = d[1][q] - d[3][q];
-        }
+        f32x4 r[P][P];
         float* out = a.V + (size_t)t * a.C + c;
+        if constexpr (M == 2) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            st4(out + (size_t)(4 * p + 0) * plane, r[p][0] - r[p][2]);
-            st4(out + (size_t)(4 * p + 1) * plane, r[p][1] + r[p][2]);
-            st4(out + (size_t)(4 * p + 2) * plane, r[p][2] - r[p][1]);
-            st4(out + (size_t)(4 * p + 3) * plane, r[p][1] - r[p][3]);
+            for (int q = 0; q < 4; ++q) {
+                r[0][q] = d[0][q] - d[2][q];
+                r[1][q] = d[1][q] + d[2][q];
+                r[2][q] = d[2][q] - d[1][q];
+                r[3][q] = d[1][q] - d[3][q];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                st4(out + (size_t)(4 * p + 0) * plane, r[p][0] - r[p][2]);
+                st4(out + (size_t)(4 * p + 1) * plane, r[p][1] + r[p][2]);
+                st4(out + (size_t)(4 * p + 2) * plane, r[p][2] - r[p][1]);
+                st4(out + (size_t)(4 * p + 3) * plane, r[p][1] - r[p][3]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                f32x4 o[6];
+                w4_bt(d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q], o);
+#pragma unroll
+                for (int p = 0; p < 6; ++p) r[p][q] = o[p];
+            }
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                f32x4 o[6];
+                w4_bt(r[p][0], r[p][1], r[p][2], r[p][3], r[p][4], r[p][5], o);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) st4(out + (size_t)(6 * p + q) * plane, o[q]);
+            }
         }
     }
 }
@@ -114,8 +192,9 @@ __global__ void __launch_bounds__(NT) wino_in_kernel(WinoInArgs a) {
 //   TRANS false (forward):        g[r][s] = w[r][s][row][col]
 //   TRANS true  (data gradient):  g[r][s] = w[2-r][2-s][col][row]   (the flipped, transposed filter; 32x32 tiles through LDS so that both
 //                                 the read along w's last axis and the write along U's last axis are coalesced)
-template <bool TRANS>
+template <bool TRANS, int M>
 __global__ void __launch_bounds__(NT) wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int rows, int cols) {
+    constexpr int P = M + 2;
     __shared__ float tile[TRANS ? 9 : 1][32][33];
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
@@ -141,22 +220,36 @@ __global__ void __launch_bounds__(NT) wino_filter_kernel(const float* __restrict
                 if constexpr (TRANS) g[r][s] = tile[(2 - r) * 3 + (2 - s)][tx][j];
                 else g[r][s] = ok ? w[((size_t)(r * 3 + s) * rows + row) * cols + col] : 0.f;
             }
-        float t[4][3];
+        float t[P][3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            t[0][s] = g[0][s];
-            t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
-            t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
-            t[3][s] = g[2][s];
+            if constexpr (M == 2) {
+                t[0][s] = g[0][s];
+                t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+                t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+                t[3][s] = g[2][s];
+            } else {
+                float o[6];
+                w4_g(g[0][s], g[1][s], g[2][s], o);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) t[i][s] = o[i];
+            }
         }
         if (ok) {
             float* out = U + (size_t)row * cols + col;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                out[(size_t)(4 * i + 0) * plane] = t[i][0];
-                out[(size_t)(4 * i + 1) * plane] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-                out[(size_t)(4 * i + 2) * plane] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-                out[(size_t)(4 * i + 3) * plane] = t[i][2];
+            for (int i = 0; i < P; ++i) {
+                if constexpr (M == 2) {
+                    out[(size_t)(4 * i + 0) * plane] = t[i][0];
+                    out[(size_t)(4 * i + 1) * plane] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+                    out[(size_t)(4 * i + 2) * plane] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+                    out[(size_t)(4 * i + 3) * plane] = t[i][2];
+                } else {
+                    float o[6];
+                    w4_g(t[i][0], t[i][1], t[i][2], o);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) out[(size_t)(6 * i + q) * plane] = o[q];
+                }
             }
         }
     }
@@ -300,7 +393,9 @@ struct WinoOutArgs {
     float ep_alpha;
 };
 
+template <int M>
 __global__ void __launch_bounds__(NT) wino_out_kernel(WinoOutArgs a) {
+    constexpr int P = M + 2;
     __shared__ float red[NT * 8];
     const int K4 = a.K >> 2;
     const int kq0 = blockIdx.y * NT;                               // first channel quad of this slice
@@ -329,29 +424,42 @@ __global__ void __launch_bounds__(NT) wino_out_kernel(WinoOutArgs a) {
             int n, pa, pb, ti, tj;
             tile_of(a.g, t, n, pa, pb, ti, tj);
             const float* src = a.Mm + (size_t)t * a.K + k;
-            f32x4 m[4][4];
+            f32x4 m[P][P];
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < P; ++p)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) m[p][q] = ld4(src + (size_t)(4 * p + q) * plane);
+                for (int q = 0; q < P; ++q) m[p][q] = ld4(src + (size_t)(P * p + q) * plane);
             // rows (A^T m), then columns ((A^T m) A)
-            f32x4 r[2][4];
+            f32x4 o[M][M];
+            if constexpr (M == 2) {
+                f32x4 r[2][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                r[0][q] = m[0][q] + m[1][q] + m[2][q];
-                r[1][q] = m[1][q] - m[2][q] - m[3][q];
+                for (int q = 0; q < 4; ++q) {
+                    r[0][q] = m[0][q] + m[1][q] + m[2][q];
+                    r[1][q] = m[1][q] - m[2][q] - m[3][q];
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    o[p][0] = r[p][0] + r[p][1] + r[p][2];
+                    o[p][1] = r[p][1] - r[p][2] - r[p][3];
+                }
+            } else {
+                f32x4 r[4][6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    f32x4 c4[4];
+                    w4_at(m[0][q], m[1][q], m[2][q], m[3][q], m[4][q], m[5][q], c4);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) r[p][q] = c4[p];
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) w4_at(r[p][0], r[p][1], r[p][2], r[p][3], r[p][4], r[p][5], o[p]);
             }
-            f32x4 o[2][2];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                o[p][0] = r[p][0] + r[p][1] + r[p][2];
-                o[p][1] = r[p][1] - r[p][2] - r[p][3];
-            }
+            for (int p = 0; p < M; ++p)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int u = 2 * ti + p, v = 2 * tj + q;
+                for (int q = 0; q < M; ++q) {
+                    const int u = M * ti + p, v = M * tj + q;
                     if (u >= a.g.Hso || v >= a.g.Wso) continue;
                     const size_t row = (size_t)(n * a.g.Ho + pa + a.g.dil * u) * a.g.Wo + pb + a.g.dil * v;
                     const size_t idx = row * a.K + k;
@@ -424,6 +532,7 @@ struct WinoDyArgs {
     int K;
 };
 
+template <int M>
 __global__ void __launch_bounds__(NT) wino_dy_kernel(WinoDyArgs a) {
     const int K4 = a.K >> 2;
     const size_t nvec = (size_t)a.g.T * K4;
@@ -434,30 +543,48 @@ __global__ void __launch_bounds__(NT) wino_dy_kernel(WinoDyArgs a) {
         const int k = (int)(i - (size_t)t * K4) * 4;
         int n, pa, pb, ti, tj;
         tile_of(a.g, t, n, pa, pb, ti, tj);
-        f32x4 y[2][2];
+        f32x4 y[M][M];
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < M; ++p)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int u = 2 * ti + p, v = 2 * tj + q;
+            for (int q = 0; q < M; ++q) {
+                const int u = M * ti + p, v = M * tj + q;
                 const f32x4 zero = {0, 0, 0, 0};
                 y[p][q] = (u < a.g.Hso && v < a.g.Wso) ? ld4(a.dy + ((size_t)(n * a.g.Ho + pa + a.g.dil * u) * a.g.Wo + pb + a.g.dil * v) * a.K + k) : zero;
             }
-        f32x4 z[4][2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            z[0][q] = y[0][q];
-            z[1][q] = y[0][q] + y[1][q];
-            z[2][q] = y[0][q] - y[1][q];
-            z[3][q] = -y[1][q];
-        }
         float* out = a.Y + (size_t)t * a.K + k;
+        if constexpr (M == 2) {
+            f32x4 z[4][2];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            st4(out + (size_t)(4 * p + 0) * plane, z[p][0]);
-            st4(out + (size_t)(4 * p + 1) * plane, z[p][0] + z[p][1]);
-            st4(out + (size_t)(4 * p + 2) * plane, z[p][0] - z[p][1]);
-            st4(out + (size_t)(4 * p + 3) * plane, -z[p][1]);
+            for (int q = 0; q < 2; ++q) {
+                z[0][q] = y[0][q];
+                z[1][q] = y[0][q] + y[1][q];
+                z[2][q] = y[0][q] - y[1][q];
+                z[3][q] = -y[1][q];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                st4(out + (size_t)(4 * p + 0) * plane, z[p][0]);
+                st4(out + (size_t)(4 * p + 1) * plane, z[p][0] + z[p][1]);
+                st4(out + (size_t)(4 * p + 2) * plane, z[p][0] - z[p][1]);
+                st4(out + (size_t)(4 * p + 3) * plane, -z[p][1]);
+            }
+        } else {
+            f32x4 z[6][4];          // rows (A y), then columns ((A y) A^T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 c6[6];
+                w4_a(y[0][q], y[1][q], y[2][q], y[3][q], c6);
+#pragma unroll
+                for (int p = 0; p < 6; ++p) z[p][q] = c6[p];
+            }
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                f32x4 o[6];
+                w4_a(z[p][0], z[p][1], z[p][2], z[p][3], o);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) st4(out + (size_t)(6 * p + q) * plane, o[q]);
+            }
         }
     }
 }
@@ -471,9 +598,11 @@ struct WinoWgradGemmArgs {
     float* S;
     int T, C, K;
     int nblk_m, nblk_n, nsplit, chunks_per_split, xcd_swizzle;
+    int npos;      // transform points: 16 (F(2x2)) or 36 (F(4x4))
 };
 
-template <int BM, int BN, int WM, int WN>
+// TILE (2 / 4) only names the symbol
+template <int BM, int BN, int WM, int WN, int TILE>
 __global__ void __launch_bounds__(NTHREADS, 2) wino_wgrad_gemm_kernel(WinoWgradGemmArgs g) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -564,38 +693,52 @@ __global__ void __launch_bounds__(NTHREADS, 2) wino_wgrad_gemm_kernel(WinoWgradG
     ConvArgs e{};
     e.Kred = g.C;
     e.K = g.K;
-    wgrad_epilogue<TM, TN>(e, acc, g.S + ((size_t)z * 16 + pos) * g.C * g.K, m0, n0, wm0, wn0, lane);
+    wgrad_epilogue<TM, TN>(e, acc, g.S + ((size_t)z * g.npos + pos) * g.C * g.K, m0, n0, wm0, wn0, lane);
 }
 
-// dW[r][s][c][k] (+)= sum_ij G[i][r] G[j][s] sum_z S[z][4i+j][c][k]: one thread = one channel x 4 filters
+// dW[r][s][c][k] (+)= sum_ij G[i][r] G[j][s] sum_z S[z][P i + j][c][k]: one thread = one channel x 4 filters
+template <int M>
 __global__ void __launch_bounds__(NT) wino_wgrad_out_kernel(const float* __restrict__ S, float* __restrict__ dw, int C, int K, int nsplit,
                                                             int accumulate) {
+    constexpr int P = M + 2, NP = P * P;
     const int K4 = K >> 2;
     const size_t nvec = (size_t)C * K4;
     const size_t plane = (size_t)C * K;
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= nvec) return;
     const size_t off = i * 4;                 // (c, k) -> c*K + k
-    f32x4 s[16];
+    f32x4 s[NP];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
+    for (int p = 0; p < NP; ++p) {
         f32x4 v = ld4(S + (size_t)p * plane + off);
-        for (int z = 1; z < nsplit; ++z) v += ld4(S + ((size_t)z * 16 + p) * plane + off);
+        for (int z = 1; z < nsplit; ++z) v += ld4(S + ((size_t)z * NP + p) * plane + off);
         s[p] = v;
     }
-    f32x4 t[3][4];
+    f32x4 t[3][P];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        t[0][j] = s[j] + 0.5f * (s[4 + j] + s[8 + j]);
-        t[1][j] = 0.5f * (s[4 + j] - s[8 + j]);
-        t[2][j] = 0.5f * (s[4 + j] + s[8 + j]) + s[12 + j];
+    for (int j = 0; j < P; ++j) {
+        if constexpr (M == 2) {
+            t[0][j] = s[j] + 0.5f * (s[4 + j] + s[8 + j]);
+            t[1][j] = 0.5f * (s[4 + j] - s[8 + j]);
+            t[2][j] = 0.5f * (s[4 + j] + s[8 + j]) + s[12 + j];
+        } else {
+            f32x4 o[3];
+            w4_gt(s[j], s[6 + j], s[12 + j], s[18 + j], s[24 + j], s[30 + j], o);
+            t[0][j] = o[0];
+            t[1][j] = o[1];
+            t[2][j] = o[2];
+        }
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         f32x4 o[3];
-        o[0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
-        o[1] = 0.5f * (t[r][1] - t[r][2]);
-        o[2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        if constexpr (M == 2) {
+            o[0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+            o[1] = 0.5f * (t[r][1] - t[r][2]);
+            o[2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        } else {
+            w4_gt(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], o);
+        }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             float* dst = dw + (size_t)(r * 3 + q) * plane + off;
@@ -612,19 +755,45 @@ __global__ void __launch_bounds__(NT) wino_wgrad_out_kernel(const float* __restr
 #ifndef PNP_WINOGRAD_WGRAD_DEFAULT
 #define PNP_WINOGRAD_WGRAD_DEFAULT 1
 #endif
+#ifndef PNP_WINOGRAD_TILE_DEFAULT
+#define PNP_WINOGRAD_TILE_DEFAULT 4
+#endif
+int env_int(const char* name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; }
+double env_dbl(const char* name, double dflt) { return getenv(name) ? atof(getenv(name)) : dflt; }
+
 std::atomic<int> g_wino_wgrad_mode{-1};    // the filter gradient's own switch (PNP_WINOGRAD_WGRAD): 0 never / 1 planner / 2 wherever eligible
 int wino_wgrad_mode() {
     int m = g_wino_wgrad_mode.load(std::memory_order_relaxed);
     if (m < 0) {
-        m = getenv("PNP_WINOGRAD_WGRAD") ? atoi(getenv("PNP_WINOGRAD_WGRAD")) : PNP_WINOGRAD_WGRAD_DEFAULT;
+        m = env_int("PNP_WINOGRAD_WGRAD", PNP_WINOGRAD_WGRAD_DEFAULT);
         if (m < 0) m = 0;
         g_wino_wgrad_mode.store(m, std::memory_order_relaxed);
     }
     return m;
 }
+std::atomic<int> g_wino_mode{-1};          // -1: not read yet (environment PNP_WINOGRAD, else the compiled-in default)
+int wino_mode() {
+    int m = g_wino_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        m = env_int("PNP_WINOGRAD", PNP_WINOGRAD_DEFAULT);
+        if (m < 0) m = 0;
+        g_wino_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+std::atomic<int> g_wino_tile{-1};          // largest output tile the route may use (PNP_WINOGRAD_TILE): 2 = F(2x2, 3x3) only, 4 = F(4x4, 3x3) first
+int wino_tile_max() {
+    int m = g_wino_tile.load(std::memory_order_relaxed);
+    if (m < 0) {
+        m = env_int("PNP_WINOGRAD_TILE", PNP_WINOGRAD_TILE_DEFAULT) >= 4 ? 4 : 2;
+        g_wino_tile.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
 // reduction split of the filter gradient's GEMMs: enough workgroups for >= 1 dispatch round (512 slots), >= 8 stages each
-int wgrad_split(int T, int C, int K, int* chunks_per_split) {
-    const int nblk = pnp_cdiv(C, 128) * pnp_cdiv(K, 128) * 16;
+int wgrad_split(int T, int C, int K, int npos, int* chunks_per_split) {
+    const int nblk = pnp_cdiv(C, 128) * pnp_cdiv(K, 128) * npos;
     const int nchunks = pnp_cdiv(T, BK);
     int ns = pnp_cdiv(512, nblk);
     if (ns > nchunks / 8) ns = nchunks / 8;
@@ -633,26 +802,15 @@ int wgrad_split(int T, int C, int K, int* chunks_per_split) {
     return pnp_cdiv(nchunks, *chunks_per_split);
 }
 
-std::atomic<int> g_wino_mode{-1};          // -1: not read yet (environment PNP_WINOGRAD, else the compiled-in default)
-int wino_mode() {
-    int m = g_wino_mode.load(std::memory_order_relaxed);
-    if (m < 0) {
-        m = getenv("PNP_WINOGRAD") ? atoi(getenv("PNP_WINOGRAD")) : PNP_WINOGRAD_DEFAULT;
-        if (m < 0) m = 0;
-        g_wino_mode.store(m, std::memory_order_relaxed);
-    }
-    return m;
-}
-
-WinoGeom make_wgeom(int N, int Hi, int Wi, int Ho, int Wo, int dil, int pad) {
+WinoGeom make_wgeom(int N, int Hi, int Wi, int Ho, int Wo, int dil, int pad, int m) {
     WinoGeom g{};
-    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.dil = dil; g.ps = pad / dil;
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.dil = dil; g.ps = pad / dil; g.m = m;
     g.Hsi = Hi / dil; g.Wsi = Wi / dil; g.Hso = Ho / dil; g.Wso = Wo / dil;
-    g.th = (g.Hso + 1) / 2; g.tw = (g.Wso + 1) / 2;
+    g.th = (g.Hso + m - 1) / m; g.tw = (g.Wso + m - 1) / m;
     g.T = N * dil * dil * g.th * g.tw;
     return g;
 }
-WinoGeom make_wgeom(const pnp_conv_geom* g) { return make_wgeom(g->N, g->H, g->W, g->OH, g->OW, g->dil, g->pad_t); }
+WinoGeom make_wgeom(const pnp_conv_geom* g, int m) { return make_wgeom(g->N, g->H, g->W, g->OH, g->OW, g->dil, g->pad_t, m); }
 
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -667,51 +825,84 @@ void out_plan(int T, int K, int* tpb, int* nblk) {
     *nblk = pnp_cdiv(T, *tpb);
 }
 
+// can F(m x m, 3x3) run this stride-1 3x3 geometry at all
+bool eligible_dims(int dtype, int R, int S, int stride, int pad_mode, int dil, int pad_t, int pad_l, int H, int W, int OH, int OW, int N, int C, int K,
+                   int m) {
+    if (dtype != PNP_DTYPE_F32 || R != 3 || S != 3 || stride != 1 || pad_mode != PNP_PAD_ZERO) return false;
+    // padding 0 (VALID on a mirror-padded image: g10), dil (SAME) or 2 dil (the data gradient of a VALID convolution), same on both axes
+    if (dil < 1 || dil > 2 || pad_t != pad_l || (pad_t % dil) != 0 || pad_t > 2 * dil) return false;
+    if (OH != H + 2 * pad_t - 2 * dil || OW != W + 2 * pad_l - 2 * dil) return false;
+    if ((H % dil) != 0 || (W % dil) != 0 || (OH % dil) != 0 || (OW % dil) != 0) return false;
+    if ((C % 32) != 0 || (K % 4) != 0 || K < 32) return false;       // (K <= 16: vector-ALU kernels)
+    const WinoGeom w = make_wgeom(N, H, W, OH, OW, dil, pad_t, m);
+    const long long lim = 1ll << 29;        // 2 GiB per transform-point plane: 32-bit buffer offsets with the OOB2 sentinel
+    return (long long)w.T * C < lim && (long long)w.T * K < lim && (long long)C * K < lim;
+}
+
+// The planner: which output tile (0 = the direct kernels, 2, 4) a layer gets.  wgrad: the filter gradient's own thresholds.
+// The transforms move ~(2 + 2 P^2/M^2) 4 (C + K) bytes per output pixel through HBM that the direct kernel does not (P = M + 2: V and M are
+// P^2/M^2 times the input / output, written once and read once), the contraction saves 2 (9 - P^2/M^2) C K flops per pixel: break-even in
+// C K / (C + K).  F(2x2), measured at B = 16 (profiles/r04_conv_layers_wino_B16.txt): 512->512 0.546 -> 0.336 ms, 256->256 0.156 -> 0.121,
+// 128->256 0.083 -> 0.078 (C K / (C + K) = 85: break-even), 128->128 0.047 -> 0.050; filter gradient (two transforms in front of the
+// contraction): break-even 120.  F(4x4) moves 0.66x the bytes and saves 1.35x the flops: break-even ~ 0.5x F(2x2)'s (profiles/r05_*).
+int plan_tile(int dtype, int R, int S, int stride, int pad_mode, int dil, int pad_t, int pad_l, int H, int W, int OH, int OW, int N, int C, int K,
+              bool wgrad) {
+    const int mode = wgrad ? wino_wgrad_mode() : wino_mode();
+    if (mode <= 0 || wino_mode() <= 0) return 0;              // PNP_WINOGRAD=0 switches the whole route off
+    static const double thr2 = env_dbl("PNP_WINOGRAD_MIN", 85.0), thr2w = env_dbl("PNP_WINOGRAD_WGRAD_MIN", 120.0);
+    static const double thr4 = env_dbl("PNP_WINOGRAD4_MIN", 60.0), thr4w = env_dbl("PNP_WINOGRAD4_WGRAD_MIN", 85.0);
+    static const int tmin2 = env_int("PNP_WINOGRAD_TMIN", 512), tmin4 = env_int("PNP_WINOGRAD4_TMIN", 128);
+    const double ck = (double)C * K / ((double)C + K);
+    for (int m = wino_tile_max(); m >= 2; m -= 2) {
+        if (!eligible_dims(dtype, R, S, stride, pad_mode, dil, pad_t, pad_l, H, W, OH, OW, N, C, K, m)) continue;
+        if (mode >= 2) return m;
+        const WinoGeom w = make_wgeom(N, H, W, OH, OW, dil, pad_t, m);
+        if (ck >= (m == 4 ? (wgrad ? thr4w : thr4) : (wgrad ? thr2w : thr2)) && w.T >= (m == 4 ? tmin4 : tmin2)) return m;
+    }
+    return 0;
+}
+int plan_tile(const pnp_conv_geom* g, bool wgrad) {
+    if (!g) return 0;
+    return plan_tile(g->dtype, g->R, g->S, g->stride, g->pad_mode, g->dil, g->pad_t, g->pad_l, g->H, g->W, g->OH, g->OW, g->N, g->C, g->K, wgrad);
+}
+int plan_tile(const ConvArgs& a, bool wgrad) {
+    return plan_tile(a.dtype, a.R, a.S, a.stride, a.pad_mode, a.dil, a.pad_t, a.pad_l, a.H, a.W, a.OH, a.OW, a.N, a.C, a.K, wgrad);
+}
+
 }  // namespace
 
 namespace pnpconv {
 
 bool wino_eligible(const pnp_conv_geom* g) {
-    if (!g || g->dtype != PNP_DTYPE_F32 || g->R != 3 || g->S != 3 || g->stride != 1 || g->pad_mode != PNP_PAD_ZERO) return false;
-    // padding 0 (VALID on a mirror-padded image: g10), dil (SAME) or 2 dil (the data gradient of a VALID convolution), same on both axes
-    if (g->dil < 1 || g->dil > 2 || g->pad_t != g->pad_l || (g->pad_t % g->dil) != 0 || g->pad_t > 2 * g->dil) return false;
-    if (g->OH != g->H + 2 * g->pad_t - 2 * g->dil || g->OW != g->W + 2 * g->pad_l - 2 * g->dil) return false;
-    if ((g->H % g->dil) != 0 || (g->W % g->dil) != 0 || (g->OH % g->dil) != 0 || (g->OW % g->dil) != 0) return false;
-    if ((g->C % 32) != 0 || (g->K % 4) != 0 || g->K < 32) return false;       // (K <= 16: vector-ALU kernels)
-    const WinoGeom w = make_wgeom(g);
-    const long long lim = 1ll << 29;        // 2 GiB per transform-point plane: 32-bit buffer offsets with the OOB2 sentinel
-    return (long long)w.T * g->C < lim && (long long)w.T * g->K < lim && (long long)g->C * g->K < lim;
+    return g && eligible_dims(g->dtype, g->R, g->S, g->stride, g->pad_mode, g->dil, g->pad_t, g->pad_l, g->H, g->W, g->OH, g->OW, g->N, g->C, g->K, 2);
 }
 
-bool wino_chosen(const pnp_conv_geom* g) {
-    const int mode = wino_mode();
-    if (mode <= 0 || !wino_eligible(g)) return false;
-    if (mode >= 2) return true;
-    // the transforms move 20 M (C + K) bytes through HBM that the direct kernel does not; the contraction saves 10 M C K flops.  Measured
-    // at B = 16 (tools/bench_conv.py WINO=2 against 0, profiles/r04_conv_layers_wino_B16.txt): 512->512 0.546 -> 0.336 ms, 256->256
-    // 0.156 -> 0.121, 128->256 0.083 -> 0.078 (C K / (C + K) = 85: break-even), 128->128 0.047 -> 0.050, 64->128@128^2 0.287 -> 0.429
-    static const double thr = getenv("PNP_WINOGRAD_MIN") ? atof(getenv("PNP_WINOGRAD_MIN")) : 85.0;
-    const WinoGeom w = make_wgeom(g);
-    return (double)g->C * g->K / ((double)g->C + g->K) >= thr && w.T >= 512;
+int wino_tile(const pnp_conv_geom* g) { return plan_tile(g, false); }
+bool wino_chosen(const pnp_conv_geom* g) { return plan_tile(g, false) != 0; }
+
+static size_t fwd_ws_bytes(const WinoGeom& w, int C, int K) {
+    const size_t np = (size_t)(w.m + 2) * (w.m + 2);
+    return al256(np * C * K * 4) + al256(np * w.T * C * 4) + al256(np * w.T * K * 4);
 }
 
 size_t wino_workspace_bytes(const pnp_conv_geom* g) {
-    const WinoGeom w = make_wgeom(g);
-    return al256((size_t)16 * g->C * g->K * 4) + al256((size_t)16 * w.T * g->C * 4) + al256((size_t)16 * w.T * g->K * 4);
+    const int m = plan_tile(g, false);
+    return fwd_ws_bytes(make_wgeom(g, m ? m : 2), g->C, g->K);
 }
 
 int wino_stats_parts(const pnp_conv_geom* g) {
-    const WinoGeom w = make_wgeom(g);
+    const int m = plan_tile(g, false);
+    const WinoGeom w = make_wgeom(g, m ? m : 2);
     int tpb, nblk;
     out_plan(w.T, g->K, &tpb, &nblk);
     return nblk;
 }
 
-// a: the convolution's arguments as make_args built them (kind 1: of the data gradient AS a convolution of dy: a.C = the forward's K,
-// a.K = its C) with every epilogue field honoured; flip_transpose: a.w is the FORWARD filter [3][3][a.K][a.C]
-int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size_t ws_bytes, hipStream_t st) {
-    const WinoGeom w = make_wgeom(a.N, a.H, a.W, a.OH, a.OW, a.dil, a.pad_t);
-    const size_t ub = al256((size_t)16 * a.C * a.K * 4), vb = al256((size_t)16 * w.T * a.C * 4), mb = al256((size_t)16 * w.T * a.K * 4);
+template <int M>
+static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int NP = (M + 2) * (M + 2);
+    const WinoGeom w = make_wgeom(a.N, a.H, a.W, a.OH, a.OW, a.dil, a.pad_t, M);
+    const size_t ub = al256((size_t)NP * a.C * a.K * 4), vb = al256((size_t)NP * w.T * a.C * 4), mb = al256((size_t)NP * w.T * a.K * 4);
     if (!ws || ws_bytes < ub + vb + mb) {
         pnp_set_error("launch_wino: workspace too small (%zu < %zu)", ws_bytes, ub + vb + mb);
         return PNP_EWORKSPACE;
@@ -723,8 +914,9 @@ int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size
     const int cls = prof_class(kind);
     {
         dim3 grid((unsigned)pnp_cdiv(a.K, 32), (unsigned)pnp_cdiv(a.C, 32));
-        if (flip_transpose) hipLaunchKernelGGL(wino_filter_kernel<true>, grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
-        else hipLaunchKernelGGL(wino_filter_kernel<false>, grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
+        PnpProfScope ps(cls, st, 0.0, 4.0 * (9.0 + NP) * a.C * a.K, "wino_filter_kernel<%s, %d>", flip_transpose ? "true" : "false", M);
+        if (flip_transpose) hipLaunchKernelGGL((wino_filter_kernel<true, M>), grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
+        else hipLaunchKernelGGL((wino_filter_kernel<false, M>), grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
         PNP_CHECK_LAUNCH("wino_filter_kernel");
     }
     {
@@ -733,8 +925,8 @@ int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size
         const size_t nvec = (size_t)w.T * (a.C / 4);
         long long nb = (long long)((nvec + NT - 1) / NT);
         if (nb > 65536) nb = 65536;
-        PnpProfScope ps(cls, st, 0.0, 4.0 * ((double)a.N * a.H * a.W * a.C + 16.0 * w.T * a.C), "wino_in_kernel");
-        hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)nb), dim3(NT), 0, st, ia);
+        PnpProfScope ps(cls, st, 0.0, 4.0 * ((double)a.N * a.H * a.W * a.C + (double)NP * w.T * a.C), "wino_in_kernel<%d>", M);
+        hipLaunchKernelGGL(wino_in_kernel<M>, dim3((unsigned)nb), dim3(NT), 0, st, ia);
         PNP_CHECK_LAUNCH("wino_in_kernel");
     }
     {
@@ -742,12 +934,13 @@ int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size
         ga.V = V; ga.U = U; ga.Mm = Mm; ga.T = w.T; ga.C = a.C; ga.K = a.K;
         ga.nblk_m = pnp_cdiv(w.T, 128); ga.nblk_n = pnp_cdiv(a.K, 128);
         ga.gn = a.gn; ga.xcd_swizzle = a.xcd_swizzle;
-        dim3 grid((unsigned)(ga.nblk_m * ga.nblk_n * 16));
-        const double fl = 2.0 * 16.0 * (double)w.T * a.C * a.K;
-        const double by = 4.0 * 16.0 * ((double)w.T * a.C + (double)a.C * a.K + (double)w.T * a.K);
-        PnpProfScope ps(cls, st, fl, by, "wino_gemm_kernel<128, 128, 2, 2, %d>", kind);
-        if (kind == 0) hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 0>), grid, dim3(NTHREADS), 0, st, ga);
-        else hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 1>), grid, dim3(NTHREADS), 0, st, ga);
+        dim3 grid((unsigned)(ga.nblk_m * ga.nblk_n * NP));
+        const double fl = 2.0 * NP * (double)w.T * a.C * a.K;
+        const double by = 4.0 * NP * ((double)w.T * a.C + (double)a.C * a.K + (double)w.T * a.K);
+        constexpr int KB = M == 4 ? 2 : 0;            // symbol: <.., 0 / 1> F(2x2) forward / data gradient, <.., 2 / 3> F(4x4)
+        PnpProfScope ps(cls, st, fl, by, "wino_gemm_kernel<128, 128, 2, 2, %d>", KB + (kind != 0));
+        if (kind == 0) hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, KB>), grid, dim3(NTHREADS), 0, st, ga);
+        else hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, KB + 1>), grid, dim3(NTHREADS), 0, st, ga);
         PNP_CHECK_LAUNCH("wino_gemm_kernel");
     }
     {
@@ -760,38 +953,44 @@ int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size
         oa.res_add = a.res_add; oa.stat_ws = a.stat_ws; oa.stat_shift = a.stat_shift;
         oa.ep_scale = a.ep_scale; oa.ep_shift = a.ep_shift; oa.ep_res = a.ep_res; oa.ep_cs = a.ep_cs; oa.ep_alpha = a.ep_alpha;
         dim3 grid((unsigned)nblk, (unsigned)pnp_cdiv(a.K / 4, NT));
-        PnpProfScope ps(cls, st, 0.0, 4.0 * (16.0 * w.T * a.K + (double)a.M * a.K), "wino_out_kernel");
-        hipLaunchKernelGGL(wino_out_kernel, grid, dim3(NT), 0, st, oa);
+        PnpProfScope ps(cls, st, 0.0, 4.0 * ((double)NP * w.T * a.K + (double)a.M * a.K), "wino_out_kernel<%d>", M);
+        hipLaunchKernelGGL(wino_out_kernel<M>, grid, dim3(NT), 0, st, oa);
         PNP_CHECK_LAUNCH("wino_out_kernel");
     }
     return PNP_OK;
 }
 
-bool wino_wgrad_chosen(const pnp_conv_geom* g) {
-    const int mode = wino_wgrad_mode();
-    if (mode <= 0 || wino_mode() <= 0 || !wino_eligible(g)) return false;        // PNP_WINOGRAD=0 switches the whole route off
-    if (mode >= 2) return true;
-    // measured at B = 16 (profiles/r04_conv_layers_wino_wgrad_B16.txt, direct ring kernel -> route): 512->512 0.610 -> 0.350 ms, g10 3.022 ->
-    // 1.516, 256->512 0.331 -> 0.217, 256->256 0.193 -> 0.142 (@64^2: 0.615 -> 0.425), 128->256@32^2 0.120 -> 0.131: two transforms in front of
-    // the contraction instead of one, so the break-even sits higher than the forward's
-    static const double thr = getenv("PNP_WINOGRAD_WGRAD_MIN") ? atof(getenv("PNP_WINOGRAD_WGRAD_MIN")) : 120.0;
-    const WinoGeom w = make_wgeom(g);
-    return (double)g->C * g->K / ((double)g->C + g->K) >= thr && w.T >= 512;
+// a: the convolution's arguments as make_args built them (kind 1: of the data gradient AS a convolution of dy: a.C = the forward's K,
+// a.K = its C) with every epilogue field honoured; flip_transpose: a.w is the FORWARD filter [3][3][a.K][a.C].  The tile is planned here
+// from the same fields the workspace / parts queries see (one decision per call)
+int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int m = plan_tile(a, false);
+    PNP_REQUIRE(m == 2 || m == 4, "launch_wino: the planner does not route this layer (policy changed between the query and the launch?)");
+    return m == 4 ? launch_wino_m<4>(a, kind, flip_transpose, ws, ws_bytes, st) : launch_wino_m<2>(a, kind, flip_transpose, ws, ws_bytes, st);
+}
+
+bool wino_wgrad_chosen(const pnp_conv_geom* g) { return plan_tile(g, true) != 0; }
+int wino_wgrad_tile(const pnp_conv_geom* g) { return plan_tile(g, true); }
+
+static size_t wgrad_ws_bytes(const WinoGeom& w, int C, int K) {
+    const int np = (w.m + 2) * (w.m + 2);
+    int cps;
+    const int ns = wgrad_split(w.T, C, K, np, &cps);
+    return al256((size_t)np * w.T * C * 4) + al256((size_t)np * w.T * K * 4) + al256((size_t)ns * np * C * K * 4);
 }
 
 size_t wino_wgrad_workspace_bytes(const pnp_conv_geom* g) {
-    const WinoGeom w = make_wgeom(g);
-    int cps;
-    const int ns = wgrad_split(w.T, g->C, g->K, &cps);
-    return al256((size_t)16 * w.T * g->C * 4) + al256((size_t)16 * w.T * g->K * 4) + al256((size_t)ns * 16 * g->C * g->K * 4);
+    const int m = plan_tile(g, true);
+    return wgrad_ws_bytes(make_wgeom(g, m ? m : 2), g->C, g->K);
 }
 
-// a: make_args(x, dy, dw, g) of the FORWARD geometry (a.x = x, a.w = dy, a.y unused); dw [3][3][C][K]
-int launch_wino_wgrad(const ConvArgs& a, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
-    const WinoGeom w = make_wgeom(a.N, a.H, a.W, a.OH, a.OW, a.dil, a.pad_t);
+template <int M>
+static int launch_wino_wgrad_m(const ConvArgs& a, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int NP = (M + 2) * (M + 2);
+    const WinoGeom w = make_wgeom(a.N, a.H, a.W, a.OH, a.OW, a.dil, a.pad_t, M);
     int cps;
-    const int ns = wgrad_split(w.T, a.C, a.K, &cps);
-    const size_t vb = al256((size_t)16 * w.T * a.C * 4), yb = al256((size_t)16 * w.T * a.K * 4), sb = al256((size_t)ns * 16 * a.C * a.K * 4);
+    const int ns = wgrad_split(w.T, a.C, a.K, NP, &cps);
+    const size_t vb = al256((size_t)NP * w.T * a.C * 4), yb = al256((size_t)NP * w.T * a.K * 4), sb = al256((size_t)ns * NP * a.C * a.K * 4);
     if (!ws || ws_bytes < vb + yb + sb) {
         pnp_set_error("launch_wino_wgrad: workspace too small (%zu < %zu)", ws_bytes, vb + yb + sb);
         return PNP_EWORKSPACE;
@@ -804,8 +1003,8 @@ int launch_wino_wgrad(const ConvArgs& a, float* dw, int accumulate, void* ws, si
         ia.x = a.x; ia.V = V; ia.g = w; ia.C = a.C; ia.x_bytes = a.x_bytes;
         long long nb = (long long)(((size_t)w.T * (a.C / 4) + NT - 1) / NT);
         if (nb > 65536) nb = 65536;
-        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)a.N * a.H * a.W * a.C + 16.0 * w.T * a.C), "wino_in_kernel");
-        hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)nb), dim3(NT), 0, st, ia);
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)a.N * a.H * a.W * a.C + (double)NP * w.T * a.C), "wino_in_kernel<%d>", M);
+        hipLaunchKernelGGL(wino_in_kernel<M>, dim3((unsigned)nb), dim3(NT), 0, st, ia);
         PNP_CHECK_LAUNCH("wino_in_kernel");
     }
     {
@@ -813,28 +1012,36 @@ int launch_wino_wgrad(const ConvArgs& a, float* dw, int accumulate, void* ws, si
         da.dy = a.w; da.Y = Y; da.g = w; da.K = a.K;
         long long nb = (long long)(((size_t)w.T * (a.K / 4) + NT - 1) / NT);
         if (nb > 65536) nb = 65536;
-        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)a.M * a.K + 16.0 * w.T * a.K), "wino_dy_kernel");
-        hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)nb), dim3(NT), 0, st, da);
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)a.M * a.K + (double)NP * w.T * a.K), "wino_dy_kernel<%d>", M);
+        hipLaunchKernelGGL(wino_dy_kernel<M>, dim3((unsigned)nb), dim3(NT), 0, st, da);
         PNP_CHECK_LAUNCH("wino_dy_kernel");
     }
     {
         WinoWgradGemmArgs ga{};
         ga.V = V; ga.Y = Y; ga.S = S; ga.T = w.T; ga.C = a.C; ga.K = a.K;
         ga.nblk_m = pnp_cdiv(a.C, 128); ga.nblk_n = pnp_cdiv(a.K, 128);
-        ga.nsplit = ns; ga.chunks_per_split = cps; ga.xcd_swizzle = a.xcd_swizzle;
-        dim3 grid((unsigned)(ga.nblk_m * ga.nblk_n * 16 * ns));
-        const double fl = 2.0 * 16.0 * (double)w.T * a.C * a.K;
-        const double by = 4.0 * 16.0 * ((double)w.T * a.C + (double)w.T * a.K + (double)ns * a.C * a.K);
-        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, fl, by, "wino_wgrad_gemm_kernel<128, 128, 2, 2>");
-        hipLaunchKernelGGL((wino_wgrad_gemm_kernel<128, 128, 2, 2>), grid, dim3(NTHREADS), 0, st, ga);
+        ga.nsplit = ns; ga.chunks_per_split = cps; ga.xcd_swizzle = a.xcd_swizzle; ga.npos = NP;
+        dim3 grid((unsigned)(ga.nblk_m * ga.nblk_n * NP * ns));
+        const double fl = 2.0 * NP * (double)w.T * a.C * a.K;
+        const double by = 4.0 * NP * ((double)w.T * a.C + (double)w.T * a.K + (double)ns * a.C * a.K);
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, fl, by, "wino_wgrad_gemm_kernel<128, 128, 2, 2, %d>", M);
+        hipLaunchKernelGGL((wino_wgrad_gemm_kernel<128, 128, 2, 2, M>), grid, dim3(NTHREADS), 0, st, ga);
         PNP_CHECK_LAUNCH("wino_wgrad_gemm_kernel");
     }
     {
         const size_t nvec = (size_t)a.C * (a.K / 4);
-        hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((nvec + NT - 1) / NT)), dim3(NT), 0, st, (const float*)S, dw, a.C, a.K, ns, accumulate);
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)ns * NP + 9.0 * (1 + (accumulate != 0))) * a.C * a.K, "wino_wgrad_out_kernel<%d>", M);
+        hipLaunchKernelGGL(wino_wgrad_out_kernel<M>, dim3((unsigned)((nvec + NT - 1) / NT)), dim3(NT), 0, st, (const float*)S, dw, a.C, a.K, ns, accumulate);
         PNP_CHECK_LAUNCH("wino_wgrad_out_kernel");
     }
     return PNP_OK;
+}
+
+// a: make_args(x, dy, dw, g) of the FORWARD geometry (a.x = x, a.w = dy, a.y unused); dw [3][3][C][K]
+int launch_wino_wgrad(const ConvArgs& a, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int m = plan_tile(a, true);
+    PNP_REQUIRE(m == 2 || m == 4, "launch_wino_wgrad: the planner does not route this layer (policy changed between the query and the launch?)");
+    return m == 4 ? launch_wino_wgrad_m<4>(a, dw, accumulate, ws, ws_bytes, st) : launch_wino_wgrad_m<2>(a, dw, accumulate, ws, ws_bytes, st);
 }
 
 }  // namespace pnpconv
@@ -849,5 +1056,12 @@ extern "C" int32_t pnp_conv2d_wino_wgrad_mode(int32_t mode) {
 extern "C" int32_t pnp_conv2d_wino_mode(int32_t mode) {
     const int prev = wino_mode();
     if (mode >= 0) g_wino_mode.store(mode > 2 ? 2 : mode, std::memory_order_relaxed);
+    return prev;
+}
+// largest output tile of the route: 2 = F(2x2, 3x3) only, 4 = F(4x4, 3x3) wherever the planner takes it (else F(2x2), else the direct
+// kernels); tile < 2 only reads.  Returns the previous value.
+extern "C" int32_t pnp_conv2d_wino_tile(int32_t tile) {
+    const int prev = wino_tile_max();
+    if (tile >= 2) g_wino_tile.store(tile >= 4 ? 4 : 2, std::memory_order_relaxed);
     return prev;
 }

@@ -119,10 +119,16 @@ def wino_wgrad_mode(mode=-1):
     return int(_lib.load().pnp_conv2d_wino_wgrad_mode(int(mode)))
 
 
+def wino_tile(tile=-1):
+    """largest output tile of the route: 2 = F(2x2, 3x3) only, 4 = F(4x4, 3x3) where its planner takes the layer (36 multiplications per
+    4x4 outputs instead of 64; points (0, +-1, 1/2, -2)); returns the previous value (tile < 2: read only)"""
+    return int(_lib.load().pnp_conv2d_wino_tile(int(tile)))
+
+
 def wino_chosen(g, kind=0):
-    """True: pnp_conv2d_fwd* (kind 0) / pnp_conv2d_dgrad* (kind 1) / pnp_conv2d_wgrad* (kind 2) run this layer (g = the forward geometry)
-    on the Winograd route"""
-    return bool(_lib.load().pnp_conv2d_wino_chosen(ctypes.byref(g), int(kind)))
+    """pnp_conv2d_fwd* (kind 0) / pnp_conv2d_dgrad* (kind 1) / pnp_conv2d_wgrad* (kind 2) of this layer (g = the forward geometry): 0 = the
+    direct kernels, else the output tile edge of the Winograd route (2 or 4) — truthy exactly when the layer is on the route"""
+    return int(_lib.load().pnp_conv2d_wino_chosen(ctypes.byref(g), int(kind)))
 
 
 def _fwd_ws(g, device):

@@ -433,14 +433,30 @@ def wgrad_ring_walk(N, H, W, C, OH, OW, stride, dil, pad_t, pad_l, r, s, c, p_fi
 WINO_BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
 WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
 WINO_AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+# F(4,3) on the interpolation points (0, 1, -1, 1/2, -2, inf): d = 6 inputs, Y = 4 outputs, 36 instead of 144 multiplications per 4x4 output
+# tile in 2-D.  Toom-Cook construction (A^T = E_4^T, G = E_3 with row j divided by N_j = prod_{l != j} (p_j - p_l), B^T = V^-T with row j
+# multiplied by N_j; tools/wino_f43_study.py generates them from the points and measures the float32 error of several point sets: this one
+# lands at the direct fp32 convolution's 3e-6..5e-6 of max|y| on the 256- / 512-channel layers, Lavin & Gray's (0, +-1, +-2) at 1e-5).
+# B^T and A^T are exact in binary; G's thirds and fifteenths are rounded once (the kernels use the same float32 constants).
+WINO4_BT = np.array([[1, -1.5, -2, 1.5, 1, 0], [0, -1, .5, 2.5, 1, 0], [0, 1, -2.5, .5, 1, 0], [0, -2, -1, 2, 1, 0], [0, .5, -1, -.5, 1, 0],
+                     [0, 1, -1.5, -2, 1.5, 1]], np.float64)
+WINO4_G = np.array([[1, 0, 0], [1 / 3, 1 / 3, 1 / 3], [-1 / 3, 1 / 3, -1 / 3], [-16 / 15, -8 / 15, -4 / 15], [1 / 15, -2 / 15, 4 / 15], [0, 0, 1]],
+                   np.float64)
+WINO4_AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, .5, -2, 0], [0, 1, 1, .25, 4, 0], [0, 1, -1, .125, -8, 1]], np.float64)
 
 
-def wino_tiles(N, Ho, Wo, dil):
+def wino_mats(m):
+    """(B^T, G, A^T) of F(m x m, 3x3), m = 2 or 4"""
+    return (WINO_BT, WINO_G, WINO_AT) if m == 2 else (WINO4_BT, WINO4_G, WINO4_AT)
+
+
+def wino_tiles(N, Ho, Wo, dil, m=2):
     """tile enumeration of csrc/conv_wino.hip: a dilation-d stride-1 3x3 convolution is d*d independent dense 3x3 convolutions of the
-    sub-images (a + d u, b + d v); every OUTPUT sub-image is cut into 2x2 tiles.  Returns (Hso, Wso, th, tw, T)."""
+    sub-images (a + d u, b + d v); every OUTPUT sub-image is cut into m x m tiles (m = 2: F(2x2, 3x3), m = 4: F(4x4, 3x3)).
+    Returns (Hso, Wso, th, tw, T)."""
     assert Ho % dil == 0 and Wo % dil == 0
     Hs, Ws = Ho // dil, Wo // dil
-    th, tw = -(-Hs // 2), -(-Ws // 2)
+    th, tw = -(-Hs // m), -(-Ws // m)
     return Hs, Ws, th, tw, N * dil * dil * th * tw
 
 
@@ -456,13 +472,14 @@ def wino_tile_coords(t, dil, th, tw):
     return t // dil, a, b, ti, tj
 
 
-def conv3x3_winograd_np(x, w, dil=1, flip_transpose=False, dtype=np.float32, pad=None):
+def conv3x3_winograd_np(x, w, dil=1, flip_transpose=False, dtype=np.float32, pad=None, m=2):
     """Stride-1 3x3 (dilated) convolution with zero padding `pad` on every side (default dil = TF SAME; 0 = VALID, the model's g10 on its
     mirror-padded input; 2 dil = the data gradient of a VALID convolution) in the four steps of the HIP path, intermediates in `dtype`:
       V[pos][t][c] = (B^T d B)[pos]   input transform of the 4x4 patch of tile t (zeros outside the image)
       U[pos][c][k] = (G g G^T)[pos]   filter transform (flip_transpose: of the data gradient's filter w'[r][s][k][c] = w[2-r][2-s][c][k])
       M[pos] = V[pos] @ U[pos]        16 GEMMs [T x C] x [C x K]
       y tile  = A^T M A               output transform, scattered to the tile's 2x2 pixels (those inside the image)
+    m = 4: F(4x4, 3x3) — 6x6 patches, 36 transform points, 4x4 output tiles, otherwise the same four steps.
     x: [N][H][W][C] numpy, w: [3][3][C][K] numpy."""
     x = np.asarray(x, dtype)
     w = np.asarray(w, dtype)
@@ -476,38 +493,39 @@ def conv3x3_winograd_np(x, w, dil=1, flip_transpose=False, dtype=np.float32, pad
     Ho, Wo = Hi + 2 * pad - 2 * dil, Wi + 2 * pad - 2 * dil
     Hsi, Wsi = Hi // dil, Wi // dil
     K = w.shape[3]
-    Hso, Wso, th, tw, T = wino_tiles(N, Ho, Wo, dil)
-    BT, G, AT = WINO_BT.astype(dtype), WINO_G.astype(dtype), WINO_AT.astype(dtype)
-    V = np.zeros((16, T, C), dtype)
+    Hso, Wso, th, tw, T = wino_tiles(N, Ho, Wo, dil, m)
+    n_ = m + 2
+    BT, G, AT = (a_.astype(dtype) for a_ in wino_mats(m))
+    V = np.zeros((n_ * n_, T, C), dtype)
     for t in range(T):
         n, a, b, ti, tj = wino_tile_coords(t, dil, th, tw)
-        d = np.zeros((4, 4, C), dtype)
-        for i in range(4):
-            for j in range(4):
-                u, v = 2 * ti - ps + i, 2 * tj - ps + j
+        d = np.zeros((n_, n_, C), dtype)
+        for i in range(n_):
+            for j in range(n_):
+                u, v = m * ti - ps + i, m * tj - ps + j
                 if 0 <= u < Hsi and 0 <= v < Wsi:
                     d[i, j] = x[n, a + dil * u, b + dil * v]
         # rows first, then columns (the kernel's order of additions)
         r = np.einsum("ip,pjc->ijc", BT, d).astype(dtype)
-        V[:, t, :] = np.einsum("ipc,jp->ijc", r, BT).astype(dtype).reshape(16, C)
+        V[:, t, :] = np.einsum("ipc,jp->ijc", r, BT).astype(dtype).reshape(n_ * n_, C)
     g1 = np.einsum("ir,rsck->isck", G, w).astype(dtype)
-    U = np.einsum("isck,js->ijck", g1, G).astype(dtype).reshape(16, C, K)
-    Mm = np.stack([V[p] @ U[p] for p in range(16)]).astype(dtype)
+    U = np.einsum("isck,js->ijck", g1, G).astype(dtype).reshape(n_ * n_, C, K)
+    Mm = np.stack([V[p] @ U[p] for p in range(n_ * n_)]).astype(dtype)
     y = np.zeros((N, Ho, Wo, K), dtype)
     for t in range(T):
         n, a, b, ti, tj = wino_tile_coords(t, dil, th, tw)
-        m = Mm[:, t, :].reshape(4, 4, K)
-        r = np.einsum("pi,ijk->pjk", AT, m).astype(dtype)
+        mt = Mm[:, t, :].reshape(n_, n_, K)
+        r = np.einsum("pi,ijk->pjk", AT, mt).astype(dtype)
         o = np.einsum("pjk,qj->pqk", r, AT).astype(dtype)
-        for p in range(2):
-            for q in range(2):
-                u, v = 2 * ti + p, 2 * tj + q
+        for p in range(m):
+            for q in range(m):
+                u, v = m * ti + p, m * tj + q
                 if u < Hso and v < Wso:
                     y[n, a + dil * u, b + dil * v] = o[p, q]
     return y
 
 
-def wgrad3x3_winograd_np(x, dy, dil=1, dtype=np.float32, pad=None, nsplit=1):
+def wgrad3x3_winograd_np(x, dy, dil=1, dtype=np.float32, pad=None, nsplit=1, m=2):
     """Filter gradient of the same convolution the way csrc/conv_wino.hip computes it — the transposition of F(2x2, 3x3):
       V[pos][t][c] = (B^T d B)[pos]                  the forward's input transform
       Y[pos][t][k] = (A y A^T)[pos]                  the 2x2 tile of dy spread to the 16 transform points (zeros for pixels outside the image)
@@ -521,30 +539,32 @@ def wgrad3x3_winograd_np(x, dy, dil=1, dtype=np.float32, pad=None, nsplit=1):
     Ho, Wo, K = dy.shape[1], dy.shape[2], dy.shape[3]
     assert Ho == Hi + 2 * pad - 2 * dil and Wo == Wi + 2 * pad - 2 * dil
     Hsi, Wsi = Hi // dil, Wi // dil
-    Hso, Wso, th, tw, T = wino_tiles(N, Ho, Wo, dil)
-    BT, G, A = WINO_BT.astype(dtype), WINO_G.astype(dtype), WINO_AT.T.astype(dtype)
-    V = np.zeros((16, T, C), dtype)
-    Y = np.zeros((16, T, K), dtype)
+    Hso, Wso, th, tw, T = wino_tiles(N, Ho, Wo, dil, m)
+    n_ = m + 2
+    BT, G, AT = (a_.astype(dtype) for a_ in wino_mats(m))
+    A = np.ascontiguousarray(AT.T)
+    V = np.zeros((n_ * n_, T, C), dtype)
+    Y = np.zeros((n_ * n_, T, K), dtype)
     for t in range(T):
         n, a, b, ti, tj = wino_tile_coords(t, dil, th, tw)
-        d = np.zeros((4, 4, C), dtype)
-        for i in range(4):
-            for j in range(4):
-                u, v = 2 * ti - ps + i, 2 * tj - ps + j
+        d = np.zeros((n_, n_, C), dtype)
+        for i in range(n_):
+            for j in range(n_):
+                u, v = m * ti - ps + i, m * tj - ps + j
                 if 0 <= u < Hsi and 0 <= v < Wsi:
                     d[i, j] = x[n, a + dil * u, b + dil * v]
-        V[:, t, :] = np.einsum("ipc,jp->ijc", np.einsum("ip,pjc->ijc", BT, d).astype(dtype), BT).astype(dtype).reshape(16, C)
-        y = np.zeros((2, 2, K), dtype)
-        for p in range(2):
-            for q in range(2):
-                u, v = 2 * ti + p, 2 * tj + q
+        V[:, t, :] = np.einsum("ipc,jp->ijc", np.einsum("ip,pjc->ijc", BT, d).astype(dtype), BT).astype(dtype).reshape(n_ * n_, C)
+        y = np.zeros((m, m, K), dtype)
+        for p in range(m):
+            for q in range(m):
+                u, v = m * ti + p, m * tj + q
                 if u < Hso and v < Wso:
                     y[p, q] = dy[n, a + dil * u, b + dil * v]
-        Y[:, t, :] = np.einsum("iqk,jq->ijk", np.einsum("ip,pqk->iqk", A, y).astype(dtype), A).astype(dtype).reshape(16, K)
+        Y[:, t, :] = np.einsum("iqk,jq->ijk", np.einsum("ip,pqk->iqk", A, y).astype(dtype), A).astype(dtype).reshape(n_ * n_, K)
     rows = -(-T // nsplit)
-    S = np.zeros((16, C, K), dtype)
+    S = np.zeros((n_ * n_, C, K), dtype)
     for z in range(nsplit):
         sl = slice(z * rows, min((z + 1) * rows, T))
-        S += np.stack([V[p, sl].T @ Y[p, sl] for p in range(16)]).astype(dtype)
-    S = S.reshape(4, 4, C, K)
+        S += np.stack([V[p, sl].T @ Y[p, sl] for p in range(n_ * n_)]).astype(dtype)
+    S = S.reshape(n_, n_, C, K)
     return np.einsum("rjck,js->rsck", np.einsum("ir,ijck->rjck", G, S).astype(dtype), G).astype(dtype)

@@ -142,7 +142,7 @@ def test_every_environment_switch_is_documented():
     pk = os.path.join(ROOT, "medical-cross-modality-domain-adaptation_amd")
     names = set()
     for f in glob.glob(os.path.join(pk, "csrc", "*.hip")) + glob.glob(os.path.join(pk, "csrc", "*.h")):
-        names |= set(re.findall(r'getenv\("(PNP_[A-Z0-9_]+)"\)', open(f).read()))
+        names |= set(re.findall(r'(?:getenv|env_int|env_dbl)\("(PNP_[A-Z0-9_]+)"', open(f).read()))
     for f in glob.glob(os.path.join(pk, "*.py")):
         names |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(PNP_[A-Z0-9_]+)"', open(f).read()))
     assert len(names) > 25, names
@@ -192,8 +192,8 @@ def test_winograd_route_planner_on_the_host(built):
     K, L = importlib.import_module(built.__name__ + ".kernels"), built._lib
     lib = L.load()
     geo = lambda N, H, C, Kf, k=3, stride=1, dil=1, pad="SAME", dt=L.DTYPE_F32: K.conv_geom((N, H, H, C), (k, k, C, Kf), stride, dil, pad, dtype=dt)
-    ch = lambda g: (K.wino_chosen(g, 0), K.wino_chosen(g, 1))
-    prev = K.wino_mode(-1)
+    ch = lambda g: (bool(K.wino_chosen(g, 0)), bool(K.wino_chosen(g, 1)))
+    prev, prev_t = K.wino_mode(-1), K.wino_tile(2)          # F(2x2, 3x3) alone first; F(4x4, 3x3): the next test
     try:
         K.wino_mode(0)
         assert ch(geo(16, 32, 512, 512)) == (False, False)
@@ -247,10 +247,54 @@ def test_winograd_route_planner_on_the_host(built):
             K.wino_wgrad_mode(prev_w)
     finally:
         K.wino_mode(prev)
-    assert K.wino_mode(-1) == prev
+        K.wino_tile(prev_t)
+    assert K.wino_mode(-1) == prev and K.wino_tile(-1) == prev_t
 
 
-def test_winograd_eligibility_and_tile_count_agree_with_the_restatement(built):
+def test_winograd_f4_planner_on_the_host(built):
+    """round 5: the route's second output tile, F(4x4, 3x3) (36 transform points, T = N d^2 ceil(OHs/4) ceil(OWs/4) tiles): which layers
+    take it (pnp_conv2d_wino_chosen returns the tile edge), the fall-back to F(2x2) and to the direct kernels, workspace and partial rows"""
+    import ctypes
+    import importlib
+    K, L = importlib.import_module(built.__name__ + ".kernels"), built._lib
+    lib = L.load()
+    geo = lambda N, H, C, Kf, k=3, stride=1, dil=1, pad="SAME", dt=L.DTYPE_F32: K.conv_geom((N, H, H, C), (k, k, C, Kf), stride, dil, pad, dtype=dt)
+    ch = lambda g: (K.wino_chosen(g, 0), K.wino_chosen(g, 1), K.wino_chosen(g, 2))
+    prev, prev_w, prev_t = K.wino_mode(1), K.wino_wgrad_mode(1), K.wino_tile(4)
+    try:
+        assert K.wino_tile(-1) == 4
+        assert ch(geo(16, 32, 512, 512)) == (4, 4, 4) and ch(geo(16, 32, 512, 512, dil=2)) == (4, 4, 4)
+        assert ch(geo(16, 34, 512, 2560, pad="VALID")) == (4, 4, 4) and ch(geo(16, 32, 256, 256)) == (4, 4, 4)
+        assert ch(geo(16, 32, 128, 256)) == (4, 4, 4)                           # C K / (C + K) = 85: forward and filter gradient of F(4x4)
+        assert ch(geo(16, 32, 128, 128)) == (4, 4, 0)                           # 64: forward / data gradient only (filter gradient: 85)
+        assert ch(geo(16, 256, 64, 64)) == (0, 0, 0) and ch(geo(16, 64, 256, 256, stride=2)) == (0, 0, 0)
+        assert ch(geo(16, 32, 512, 512, dt=L.DTYPE_BF16)) == (0, 0, 0)
+        assert ch(geo(2, 32, 512, 512)) == (4, 4, 4)                            # 128 tiles of 4x4: the floor of F(4x4)
+        assert ch(geo(1, 32, 512, 512)) == (0, 0, 0)                            # 64 tiles of 4x4, 256 of 2x2: below both floors
+        assert ch(geo(1, 45, 512, 512))[0] == 4 and ch(geo(1, 44, 512, 512))[0] == 0       # ragged: 12 x 12 = 144 tiles of 4x4 / 11 x 11 = 121 (484 of 2x2)
+        K.wino_tile(2)
+        assert ch(geo(16, 32, 512, 512)) == (2, 2, 2) and ch(geo(16, 32, 128, 128)) == (0, 0, 0)
+        K.wino_tile(4)
+        # workspace = 36 x (C K + T C + T K) floats, T = tiles of 4x4 outputs
+        for g, T in ((geo(16, 32, 512, 512), 16 * 8 * 8), (geo(16, 32, 512, 512, dil=2), 16 * 4 * 4 * 4), (geo(16, 34, 512, 2560, pad="VALID"), 16 * 8 * 8)):
+            assert int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))) == 36 * 4 * (g.C * g.K + T * g.C + T * g.K), (g.C, g.K)
+        g10 = geo(16, 34, 512, 2560, pad="VALID")
+        assert int(lib.pnp_conv2d_dgrad_workspace_bytes(ctypes.byref(g10))) == 36 * 4 * (2560 * 512 + 16 * 9 * 9 * (2560 + 512))     # 34 x 34 outputs: 9 x 9 tiles
+        assert K.conv_stats_parts(geo(16, 32, 512, 512)) == 1024 // 2 and K.conv_stats_parts(g10) == 1024
+        # filter gradient: V + Y + the 36 [C x K] products; 16 x 36 = 576 workgroups fill a dispatch round un-split
+        g, T = geo(16, 32, 512, 512), 16 * 8 * 8
+        assert int(lib.pnp_conv2d_wgrad_workspace_bytes(ctypes.byref(g))) == 36 * 4 * (T * 512 + T * 512 + 512 * 512)
+        K.wino_mode(2)
+        K.wino_wgrad_mode(2)
+        assert ch(geo(1, 8, 64, 32)) == (4, 4, 4) and ch(geo(16, 256, 32, 16)) == (0, 0, 0)
+    finally:
+        K.wino_mode(prev)
+        K.wino_wgrad_mode(prev_w)
+        K.wino_tile(prev_t)
+
+
+@pytest.mark.parametrize("m", [2, 4])
+def test_winograd_eligibility_and_tile_count_agree_with_the_restatement(built, m):
     """random geometries: the C planner's eligibility (mode 2 = wherever the geometry allows) is exactly the set of conditions the numpy
     restatement needs (stride 1, 3x3, zero padding 0 / dil / 2 dil on both axes, extents divisible by the dilation, C % 32, K % 4, K >= 32,
     fp32), and its workspace is 16 x (C K + T C + T K) floats with the restatement's tile count T"""
@@ -261,7 +305,8 @@ def test_winograd_eligibility_and_tile_count_agree_with_the_restatement(built):
     K, L = importlib.import_module(built.__name__ + ".kernels"), built._lib
     lib = L.load()
     rng = np.random.default_rng(21)
-    prev = K.wino_mode(2)
+    prev, prev_t = K.wino_mode(2), K.wino_tile(m)
+    np_ = (m + 2) ** 2
     try:
         seen = {True: 0, False: 0}
         for _ in range(400):
@@ -279,12 +324,13 @@ def test_winograd_eligibility_and_tile_count_agree_with_the_restatement(built):
             want = (k == 3 and stride == 1 and dil <= 2 and pad % dil == 0 and pad <= 2 * dil and H % dil == 0 and W % dil == 0
                     and g.OH % dil == 0 and g.OW % dil == 0 and C % 32 == 0 and Kf % 4 == 0 and Kf >= 32)
             got = K.wino_chosen(g, 0)
-            assert got == want, (N, H, W, C, Kf, k, stride, dil, pad, got, want)
+            assert got == (m if want else 0), (N, H, W, C, Kf, k, stride, dil, pad, got, want)
             seen[want] += 1
             if want:
-                Tn = T_.wino_tiles(N, g.OH, g.OW, dil)[4]
+                Tn = T_.wino_tiles(N, g.OH, g.OW, dil, m)[4]
                 al = lambda b: (b + 255) // 256 * 256
-                assert int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))) == al(64 * C * Kf) + al(64 * Tn * C) + al(64 * Tn * Kf)
+                assert int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))) == al(4 * np_ * C * Kf) + al(4 * np_ * Tn * C) + al(4 * np_ * Tn * Kf)
         assert seen[True] >= 10 and seen[False] >= 100, seen
     finally:
         K.wino_mode(prev)
+        K.wino_tile(prev_t)

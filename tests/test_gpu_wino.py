@@ -1,5 +1,5 @@
-"""-m gpu: the Winograd F(2x2, 3x3) route of the wide stride-1 3x3 convolutions (csrc/conv_wino.hip): forward, data gradient and filter
-gradient (the transposed algorithm).
+"""-m gpu: the Winograd F(2x2, 3x3) and F(4x4, 3x3) routes of the wide stride-1 3x3 convolutions (csrc/conv_wino.hip): forward, data
+gradient and filter gradient (the transposed algorithm), every test once per output tile (kernels.wino_tile 2 / 4).
 
 Oracle: the float64 convolution (oracle.tf_ops.conv2d / autograd) of the same float32 operands; bar 2e-5 of max|ref| (the direct fp32
 kernels land at 1e-7..5e-6 on the same cases; the Winograd transforms add ~1 ulp in front of and behind the contraction).  Every case
@@ -44,14 +44,20 @@ def _ran(L, fn, cls):
     return out, [r["name"] for r in L.prof_summary()]
 
 
-@pytest.fixture
-def wino():
-    """yields a setter of the route policy; restores the modes in force before the test (forward / data gradient and filter gradient)"""
+@pytest.fixture(params=[2, 4], ids=["F2x2", "F4x4"])
+def wino(request):
+    """yields a setter of the route policy with the output tile of this run in force (wino.tile); restores the modes in force before the
+    test (forward / data gradient, filter gradient, tile)"""
     K = pkg("kernels")
-    prev, prev_w = K.wino_mode(-1), K.wino_wgrad_mode(-1)
-    yield K.wino_mode
+    prev, prev_w, prev_t = K.wino_mode(-1), K.wino_wgrad_mode(-1), K.wino_tile(request.param)
+
+    def setter(mode):
+        return K.wino_mode(mode)
+    setter.tile = request.param
+    yield setter
     K.wino_mode(prev)
     K.wino_wgrad_mode(prev_w)
+    K.wino_tile(prev_t)
 
 
 def _where(err, K_):
@@ -86,11 +92,14 @@ def test_winograd_fwd_dgrad_vs_float64_and_direct(dev, wino, case):
     dx0 = K.conv2d_dgrad(dyd, wd, g)
     assert not any("wino" in n for n in names0), names0
     wino(2)
-    assert K.wino_chosen(g, 0) and K.wino_chosen(g, 1)
+    assert K.wino_chosen(g, 0) == wino.tile and K.wino_chosen(g, 1) == wino.tile
     y1, names1 = _ran(L, lambda: K.conv2d_fwd(xd, wd, g), L.PROF_CONV_FWD)
-    assert sorted(n.split("<")[0] for n in names1) == ["wino_gemm_kernel", "wino_in_kernel", "wino_out_kernel"], names1
+    kb = 0 if wino.tile == 2 else 2          # wino_gemm_kernel<.., 0 / 1>: F(2x2) forward / data gradient, <.., 2 / 3>: F(4x4)
+    want = ["wino_filter_kernel<false, %d>", "wino_gemm_kernel<128, 128, 2, 2, %d>" % kb, "wino_in_kernel<%d>", "wino_out_kernel<%d>"]
+    assert sorted(names1) == [n % wino.tile if "%d" in n else n for n in want], names1
     dx1, names2 = _ran(L, lambda: K.conv2d_dgrad(dyd, wd, g), L.PROF_CONV_DGRAD)
-    assert sorted(n.split("<")[0] for n in names2) == ["wino_gemm_kernel", "wino_in_kernel", "wino_out_kernel"], names2
+    want = ["wino_filter_kernel<true, %d>", "wino_gemm_kernel<128, 128, 2, 2, %d>" % (kb + 1), "wino_in_kernel<%d>", "wino_out_kernel<%d>"]
+    assert sorted(names2) == [n % wino.tile if "%d" in n else n for n in want], names2
     dxr = K.conv2d_dgrad(dyd, wd, g, residual=resd)
     # the filter gradient on the route (its own switch): plain and added into a buffer that already holds a contribution
     wg = torch.from_numpy(w).double().requires_grad_(True)
@@ -99,15 +108,16 @@ def test_winograd_fwd_dgrad_vs_float64_and_direct(dev, wino, case):
     assert not K.wino_chosen(g, 2)
     dw0 = K.conv2d_wgrad(xd, dyd, g)
     K.wino_wgrad_mode(2)
-    assert K.wino_chosen(g, 2)
+    assert K.wino_chosen(g, 2) == wino.tile
     dw1, names3 = _ran(L, lambda: K.conv2d_wgrad(xd, dyd, g), L.PROF_CONV_WGRAD)
-    assert sorted(n.split("<")[0] for n in names3) == ["wino_dy_kernel", "wino_in_kernel", "wino_wgrad_gemm_kernel"], names3
+    assert sorted(names3) == [n % wino.tile for n in ("wino_dy_kernel<%d>", "wino_in_kernel<%d>", "wino_wgrad_gemm_kernel<128, 128, 2, 2, %d>",
+                                                      "wino_wgrad_out_kernel<%d>")], names3
     held = torch.from_numpy(rng.standard_normal(w.shape).astype(np.float32)).to(dev)
     dwa = K.conv2d_wgrad(xd, dyd, g, into=held.clone())
     errs = {"y direct": _rel(y0, yo), "y wino": _rel(y1, yo), "dx direct": _rel(dx0, xg.grad), "dx wino": _rel(dx1, xg.grad),
             "dx+res wino": _rel(dxr, xg.grad + torch.from_numpy(res).double()), "dw direct": _rel(dw0, wg.grad), "dw wino": _rel(dw1, wg.grad),
             "dw+held wino": _rel(dwa, wg.grad + held.cpu().double())}
-    print("wino %s: %s" % (case, {k: "%.2e" % v for k, v in errs.items()}))
+    print("wino F(%dx%d) %s: %s" % (wino.tile, wino.tile, case, {k: "%.2e" % v for k, v in errs.items()}))
     if errs["y wino"] > BAR:
         print("  forward mismatch:", _where(y1.cpu().double() - yo.detach(), Kf))
     if errs["dx wino"] > BAR:
@@ -130,7 +140,7 @@ def test_winograd_epilogues_equal_the_direct_route(dev, wino):
         out = {}
         for mode in (0, 2):
             wino(mode)
-            assert K.wino_chosen(g, 0) == (mode == 2)
+            assert K.wino_chosen(g, 0) == (wino.tile if mode == 2 else 0)
             yd = K.conv2d_fwd(x, w, g, keep_prob=0.75, seed=1234, stream_id=7)
             mm, mv = torch.zeros(Kf, device=dev), torch.ones(Kf, device=dev)
             nparts = K.conv_stats_parts(g)
@@ -151,7 +161,7 @@ def test_winograd_epilogues_equal_the_direct_route(dev, wino):
         yd64 = yd1.double().reshape(-1, Kf)
         errs["mean vs f64"] = float((m1.double() - yd64.mean(0)).abs().max() / yd64.std())
         errs["var vs f64"] = _rel(v1, yd64.var(0, unbiased=False))
-        print("wino epilogues (%d, %d, %d->%d, dil %d): %s" % (N, H, C, Kf, dil, {k: "%.2e" % v for k, v in errs.items()}))
+        print("wino F(%dx%d) epilogues (%d, %d, %d->%d, dil %d): %s" % (wino.tile, wino.tile, N, H, C, Kf, dil, {k: "%.2e" % v for k, v in errs.items()}))
         assert max(errs.values()) < BAR, errs
 
 
@@ -182,8 +192,9 @@ def test_segmenter_step_on_the_winograd_route(dev, wino):
     (l0, g0, w0, n0), (l1, g1, w1, n1) = res[0], res[1]
     assert not any("wino" in n for n in n0)
     assert any(n.startswith("wino_wgrad_gemm_kernel") for n in n1), sorted(set(n1))
-    assert any(n.startswith("wino_gemm_kernel<128, 128, 2, 2, 0>") for n in n1) and any(n.startswith("wino_gemm_kernel<128, 128, 2, 2, 1>") for n in n1), sorted(set(n1))
+    kb = 0 if wino.tile == 2 else 2
+    assert any(n.startswith("wino_gemm_kernel<128, 128, 2, 2, %d>" % kb) for n in n1) and any(n.startswith("wino_gemm_kernel<128, 128, 2, 2, %d>" % (kb + 1)) for n in n1), sorted(set(n1))
     cos = float(torch.nn.functional.cosine_similarity(g0.double().flatten(), g1.double().flatten(), dim=0))
     cw = float(torch.nn.functional.cosine_similarity(w0.double().flatten(), w1.double().flatten(), dim=0))
-    print("segmenter step, Winograd route vs direct: loss %.7f vs %.7f, gradient cosine %.8f, weights-after-Adam cosine %.8f" % (l1, l0, cos, cw))
+    print("segmenter step, Winograd F(%dx%d) route vs direct: loss %.7f vs %.7f, gradient cosine %.8f, weights-after-Adam cosine %.8f" % (wino.tile, wino.tile, l1, l0, cos, cw))
     assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0)) and cos > 0.99999 and cw > 0.999999

@@ -599,30 +599,33 @@ def test_ring_filter_gradient_coordinate_walk():
     assert checked > 50000
 
 
-def test_winograd_restatement_equals_the_direct_convolution():
-    """the tile enumeration (dilation phases, ragged 2x2 tiles, padding 0 / dil / 2 dil), the three transforms and the flipped, transposed
-    filter of the data gradient of csrc/conv_wino.hip, restated in numpy (oracle.tf_ops.conv3x3_winograd_np): equal to tf.nn.conv2d /
-    atrous_conv2d and to autograd's data gradient in float64; in float32 as close to float64 as the direct sum is"""
+@pytest.mark.parametrize("m", [2, 4])
+def test_winograd_restatement_equals_the_direct_convolution(m):
+    """the tile enumeration (dilation phases, ragged m x m tiles, padding 0 / dil / 2 dil), the three transforms and the flipped, transposed
+    filter of the data gradient of csrc/conv_wino.hip, restated in numpy (oracle.tf_ops.conv3x3_winograd_np) for F(2x2, 3x3) and F(4x4, 3x3):
+    equal to tf.nn.conv2d / atrous_conv2d and to autograd's data gradient in float64; in float32 as close to float64 as the direct sum is"""
     rng = np.random.default_rng(11)
+    tol = 1e-12 if m == 2 else 1e-11            # (F(4,3): thirds and fifteenths in G, entries up to 8 in A^T)
     for (N, H, W, C, K, d, pad) in ((2, 8, 8, 4, 5, 1, 1), (1, 6, 10, 3, 4, 2, 2), (2, 5, 7, 4, 4, 1, 1), (1, 12, 4, 2, 3, 2, 2),
-                                    (1, 7, 9, 3, 2, 1, 0), (1, 8, 12, 3, 2, 2, 0), (1, 2, 2, 3, 2, 1, 1)):
+                                    (1, 7, 9, 3, 2, 1, 0), (1, 8, 12, 3, 2, 2, 0), (1, 2, 2, 3, 2, 1, 1), (1, 13, 9, 2, 3, 1, 1)):
         x, w = rng.standard_normal((N, H, W, C)), rng.standard_normal((3, 3, C, K))
         xt = torch.from_numpy(x).requires_grad_(True)
         ref = T.conv2d(xt, torch.from_numpy(w), 1, d, "SAME" if pad == d else "VALID")
-        got = T.conv3x3_winograd_np(x, w, d, dtype=np.float64, pad=pad)
-        assert got.shape == tuple(ref.shape) and np.allclose(got, ref.detach().numpy(), rtol=1e-12, atol=1e-12), (N, H, W, C, K, d, pad)
+        got = T.conv3x3_winograd_np(x, w, d, dtype=np.float64, pad=pad, m=m)
+        assert got.shape == tuple(ref.shape) and np.allclose(got, ref.detach().numpy(), rtol=tol, atol=tol), (N, H, W, C, K, d, pad)
         dy = rng.standard_normal(tuple(ref.shape))
         ref.backward(torch.from_numpy(dy))
-        gd = T.conv3x3_winograd_np(dy, w, d, flip_transpose=True, dtype=np.float64, pad=2 * d - pad)
-        assert gd.shape == x.shape and np.allclose(gd, xt.grad.numpy(), rtol=1e-12, atol=1e-12), (N, H, W, C, K, d, pad)
+        gd = T.conv3x3_winograd_np(dy, w, d, flip_transpose=True, dtype=np.float64, pad=2 * d - pad, m=m)
+        assert gd.shape == x.shape and np.allclose(gd, xt.grad.numpy(), rtol=tol, atol=tol), (N, H, W, C, K, d, pad)
         # the filter gradient: the transposed algorithm (dy tile spread to the transform points, reduction over tiles split 3 ways)
         wt = torch.from_numpy(w).requires_grad_(True)
         T.conv2d(torch.from_numpy(x), wt, 1, d, "SAME" if pad == d else "VALID").backward(torch.from_numpy(dy))
-        gw = T.wgrad3x3_winograd_np(x, dy, d, dtype=np.float64, pad=pad, nsplit=3)
-        assert gw.shape == w.shape and np.allclose(gw, wt.grad.numpy(), rtol=1e-12, atol=1e-11), (N, H, W, C, K, d, pad)
+        gw = T.wgrad3x3_winograd_np(x, dy, d, dtype=np.float64, pad=pad, nsplit=3, m=m)
+        assert gw.shape == w.shape and np.allclose(gw, wt.grad.numpy(), rtol=10 * tol, atol=10 * tol), (N, H, W, C, K, d, pad)
     x = rng.standard_normal((1, 8, 8, 512)).astype(np.float32)
     w = (rng.standard_normal((3, 3, 512, 32)) * 0.02).astype(np.float32)
     ref = T.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), 1, 1, "SAME").numpy()
-    e_w = np.abs(T.conv3x3_winograd_np(x, w, 1, dtype=np.float32) - ref).max() / np.abs(ref).max()
+    e_w = np.abs(T.conv3x3_winograd_np(x, w, 1, dtype=np.float32, m=m) - ref).max() / np.abs(ref).max()
     e_d = np.abs(T.conv2d(torch.from_numpy(x), torch.from_numpy(w), 1, 1, "SAME").numpy() - ref).max() / np.abs(ref).max()
-    assert e_w < 5e-6 and e_w < 4 * e_d + 1e-6, (e_w, e_d)
+    # F(2,3): as close as the direct sum; F(4,3) on the points (0, +-1, 1/2, -2): within 2e-5 of max|y| (tools/wino_f43_study.py: 4e-6 typical)
+    assert (e_w < 5e-6 and e_w < 4 * e_d + 1e-6) if m == 2 else e_w < 2e-5, (e_w, e_d)

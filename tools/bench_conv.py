@@ -17,6 +17,8 @@ if os.environ.get("WINO") is not None:          # route of the wide stride-1 3x3
     K.wino_mode(int(os.environ["WINO"]))
 if os.environ.get("WINO_WGRAD") is not None:    # the same for the filter gradient
     K.wino_wgrad_mode(int(os.environ["WINO_WGRAD"]))
+if os.environ.get("TILE") is not None:          # largest output tile of the route: 2 = F(2x2, 3x3) only, 4 = F(4x4, 3x3) first
+    K.wino_tile(int(os.environ["TILE"]))
 SKIP_WGRAD = bool(os.environ.get("SKIP_WGRAD"))
 LAYERS = [  # name, H, C, K, R, dil, padding, count in segmenter fwd
     ("g1 3->16", 256, 3, 16, 3, 1, "SAME", 1),
@@ -70,7 +72,7 @@ def main():
     only = os.environ.get("ONLY")
     for name, H, C, Kc, R, dil, padding, cnt, *rest in LAYERS:
         stride = rest[0] if rest else 1
-        if only and only not in name:
+        if only and not any(o in name for o in only.split(",")):
             continue
         x = torch.randn((B, H, H, C), device=dev)
         w = torch.randn((R, R, C, Kc), device=dev) * 0.05
