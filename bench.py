@@ -47,6 +47,21 @@ GAN_NETCFG = {"mr_front_trainable": False, "joint_trainable": False, "ct_front_t
               "m_cls_trainable": True}
 
 
+# algorithmic convolution flops (2*N*OH*OW*R*S*C*K, forward + data gradient + filter gradient) per slice of one step
+ALG_GFLOP_PER_SLICE = {"joint": 399.8 + 256.2, "segmenter": 248.95}
+
+
+def wino_alg_factor(name):
+    """a Winograd GEMM row counts the flops it EXECUTES; the convolution's algorithmic flops are 9 M^2 / (M + 2)^2 times that
+    (F(2x2, 3x3): 2.25, F(4x4, 3x3): 4; exact for full tiles).  Symbols: wino_gemm_kernel<.., 0 / 1> F(2x2), <.., 2 / 3> F(4x4);
+    wino_wgrad_gemm_kernel<.., TILE>."""
+    if name.startswith("wino_gemm_kernel"):
+        return 4.0 if name.rstrip(">").split(",")[-1].strip() in ("2", "3") else 2.25
+    if name.startswith("wino_wgrad_gemm_kernel"):
+        return 4.0 if name.rstrip(">").split(",")[-1].strip() == "4" else 2.25
+    return 1.0
+
+
 def blob_labels(rng, B):
     yy, xx = np.mgrid[0:256, 0:256]
     lab = np.zeros((B, 256, 256), np.int64)
@@ -189,18 +204,18 @@ def compact_record(res):
     if "roofline" in res:
         r = res["roofline"]
         out["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
-                                                 "launches", "avg_launch_ms", "share_of_conv_time", "algorithmic_gflop_per_launch",
-                                                 "algorithmic_mbytes_per_launch")}
-    for k in ("roofline_all_mfma_convs", "segmenter_step", "joint_step"):
+                                                 "launches", "avg_launch_ms", "share_of_conv_time", "flops_counted", "gflop_per_launch",
+                                                 "achieved_algorithmic", "algorithmic_mbytes_per_launch")}
+    for k in ("roofline_all_mfma_convs", "step_algorithmic", "segmenter_step", "joint_step", "bf16_step"):
         if k in res:
-            out[k] = {a: b for a, b in res[k].items() if a not in ("workload", "unit", "steps", "warmup")}
+            out[k] = {a: b for a, b in res[k].items() if a not in ("workload", "unit", "steps", "warmup", "peak", "probed_steps")}
     if "cpu_baseline" in res:
         out["cpu_baseline"] = {k: v for k, v in res["cpu_baseline"].items() if not k.startswith("sample_B")}
     if "kernels_file" in res:
         out["kernels_file"] = res["kernels_file"]
     out = _r(out)
-    for drop in (("cpu_baseline", "cpu_model"), ("roofline", "algorithmic_mbytes_per_launch"), ("roofline", "traffic_source"), ("config", "comm"),
-                 ("kernels_file",), ("cpu_baseline", "sample")):
+    for drop in (("cpu_baseline", "sample"), ("cpu_baseline", "cpu_model"), ("roofline", "algorithmic_mbytes_per_launch"), ("roofline", "traffic_source"),
+                 ("roofline_all_mfma_convs", "launches_per_step"), ("kernels_file",), ("config", "comm")):
         if len(json.dumps(out)) < MAX_LINE:
             break
         d = out
@@ -264,14 +279,18 @@ def roofline_records(rows, peak):
             gbs = r["bytes"] / (r["ms"] * 1e-3) / 1e9
             out.append({"kernel": r["name"], "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                         "traffic": traffic, "traffic_source": src, "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
-                        "share_of_conv_time": r["ms"] / tot_ms, "algorithmic_gflop_per_launch": 0.0,
+                        "share_of_conv_time": r["ms"] / tot_ms, "flops_counted": "none", "gflop_per_launch": 0.0,
                         "algorithmic_mbytes_per_launch": r["bytes"] / r["launches"] / 1e6})
             continue
         ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        wf = wino_alg_factor(r["name"])
         out.append({"kernel": r["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "traffic": traffic, "traffic_source": src, "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
                     "share_of_conv_time": r["ms"] / tot_ms,
-                    "algorithmic_gflop_per_launch": r["flops"] / r["launches"] / 1e9,
+                    # direct kernels: executed = algorithmic (2*N*OH*OW*R*S*C*K); Winograd GEMMs execute 2.25x / 4x fewer
+                    "flops_counted": "executed" if wf != 1.0 else "algorithmic",
+                    "gflop_per_launch": r["flops"] / r["launches"] / 1e9,
+                    "achieved_algorithmic": ach * wf,
                     "algorithmic_mbytes_per_launch": r["bytes"] / r["launches"] / 1e6})
     return out
 
@@ -461,6 +480,20 @@ def main():
         sub = {"workload": names[other][1], "value": world * B * sub_steps / el2, "unit": "slices/s", "ms_per_step": 1e3 * el2 / sub_steps,
                "steps": sub_steps, "warmup": sub_warm, "final_loss": loss2}
 
+    # BASELINE configs[4] arithmetic (bf16 MFMA operands, fp32 accumulation / master weights / BN) on the headline workload, as a
+    # sub-record of the driver's own line: same step definition, 2 warm-up + 10 timed steps
+    sub_bf16 = None
+    if not args.no_sub and args.dtype == "f32" and args.workload == "joint":
+        Fn.set_conv_dtype("bf16")
+        try:
+            nb = 10
+            el3, loss3 = timed_loop(make_joint(), 2, nb, world, dev, None)
+            sub_bf16 = {"workload": "BASELINE configs[4] arithmetic on the joint step: bf16 MFMA conv operands (resident bf16 activations / filter shadows), "
+                                    "fp32 accumulation, master weights and BN; B=%d/GPU" % B,
+                        "value": world * B * nb / el3, "unit": "slices/s", "ms_per_step": 1e3 * el3 / nb, "steps": nb, "warmup": 2, "final_loss": loss3}
+        finally:
+            Fn.set_conv_dtype("f32")
+
     if rank == 0:
         res = {
             "metric": names[args.workload][0],
@@ -481,16 +514,27 @@ def main():
                                         "launch stream around every launch of the symbol in the first %d steps of the timed region; `traffic` = HBM-side "
                                         "bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, separate passes; "
                                         "`traffic_source` names the file), null if absent.  Symbols of the Winograd route (csrc/conv_wino.hip): `wino_gemm_kernel` / "
-                                        "`wino_wgrad_gemm_kernel` are priced at the flops they EXECUTE (2*16*T*C*K, T = tiles = pixels/4: 2.25x fewer than the "
-                                        "convolution's 2*N*OH*OW*9*C*K), their transform kernels appear as HBM-bound rows (bytes / duration against 8 TB/s)" % PROBE_STEPS)
+                                        "`wino_wgrad_gemm_kernel` are priced at the flops they EXECUTE (`flops_counted`: 2*P^2*T*C*K, T = tiles of MxM outputs, "
+                                        "P = M + 2: 2.25x (F(2x2)) / 4x (F(4x4)) fewer than the convolution's 2*N*OH*OW*9*C*K — `achieved_algorithmic` is the "
+                                        "same launch priced at SURVEY 8(d)'s convolution flops), their transform kernels appear as HBM-bound rows (bytes / "
+                                        "duration against 8 TB/s).  `step_algorithmic`: SURVEY 8(d) flops of the whole step / the step's wall time" % PROBE_STEPS)
                 res["roofline_kernels"] = recs
                 fl, ms = sum(r["flops"] for r in rows), sum(r["ms"] for r in rows)
+                # `achieved`: flops the kernels EXECUTE / all convolution kernel time (Winograd transforms included: time, no flops);
+                # `achieved_algorithmic`: SURVEY.md §8(d) convolution flops of the step / the same time — comparable across rounds whatever
+                # the route (it exceeds the fp32 MFMA peak when the Winograd routes skip enough multiplications)
+                alg = ALG_GFLOP_PER_SLICE[args.workload] * B * min(PROBE_STEPS, args.steps) * 1e9
                 res["roofline_all_mfma_convs"] = {"achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "frac": fl / (ms * 1e-3) / 1e12 / peak,
+                                                  "achieved_algorithmic": alg / (ms * 1e-3) / 1e12,
                                                   "unit": "TFLOP/s", "ms_per_step": ms / min(PROBE_STEPS, args.steps),
                                                   "launches_per_step": sum(r["launches"] for r in rows) / min(PROBE_STEPS, args.steps),
                                                   "probed_steps": min(PROBE_STEPS, args.steps)}
+        tfl = ALG_GFLOP_PER_SLICE[args.workload] * B * 1e-3                      # TFLOP per step per GPU
+        res["step_algorithmic"] = {"tflop_per_step": tfl, "achieved": tfl / (el / args.steps), "frac_of_mfma_peak": tfl / (el / args.steps) / peak}
         if sub is not None:
             res["segmenter_step" if other == "segmenter" else "joint_step"] = sub
+        if sub_bf16 is not None:
+            res["bf16_step"] = sub_bf16
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps, args.cpu_warmup)
             if args.cpu_small_batch and args.cpu_small_batch != args.cpu_batch:

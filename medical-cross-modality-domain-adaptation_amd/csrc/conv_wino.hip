@@ -850,7 +850,7 @@ int plan_tile(int dtype, int R, int S, int stride, int pad_mode, int dil, int pa
     const int mode = wgrad ? wino_wgrad_mode() : wino_mode();
     if (mode <= 0 || wino_mode() <= 0) return 0;              // PNP_WINOGRAD=0 switches the whole route off
     static const double thr2 = env_dbl("PNP_WINOGRAD_MIN", 85.0), thr2w = env_dbl("PNP_WINOGRAD_WGRAD_MIN", 120.0);
-    static const double thr4 = env_dbl("PNP_WINOGRAD4_MIN", 60.0), thr4w = env_dbl("PNP_WINOGRAD4_WGRAD_MIN", 85.0);
+    static const double thr4 = env_dbl("PNP_WINOGRAD4_MIN", 60.0), thr4w = env_dbl("PNP_WINOGRAD4_WGRAD_MIN", 60.0);
     static const int tmin2 = env_int("PNP_WINOGRAD_TMIN", 512), tmin4 = env_int("PNP_WINOGRAD4_TMIN", 128);
     const double ck = (double)C * K / ((double)C + K);
     for (int m = wino_tile_max(); m >= 2; m -= 2) {
