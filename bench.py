@@ -166,8 +166,10 @@ def cpu_baseline(workload, Bc=16, timed_steps=3, warm=1):
     med = float(np.median(times[warm:]))
     return {"value": Bc / med, "unit": "slices/s", "cores": ncores, "cpu_model": cpu_model(), "kind": "port", "batch": Bc,
             "s_per_step": med,
-            "sample": "%s, B=%d per domain, %d warm-up + %d timed steps, median %.2f s/step (all: %s)"
-                      % (what, Bc, warm, timed_steps, med, " ".join("%.1f" % t for t in times))}
+            # `sample`: what was timed, short enough for the driver's line; `sample_detail` (side file only): the port and every step time
+            "sample": "CPU oracle %s step, B=%d, %d warm-up + %d timed steps, median %.1f s/step" % (workload, Bc, warm, timed_steps, med),
+            "sample_detail": "%s, B=%d per domain, %d warm-up + %d timed steps, median %.2f s/step (all: %s)"
+                             % (what, Bc, warm, timed_steps, med, " ".join("%.1f" % t for t in times))}
 
 
 def _r(v, nd=4):
@@ -210,12 +212,13 @@ def compact_record(res):
         if k in res:
             out[k] = {a: b for a, b in res[k].items() if a not in ("workload", "unit", "steps", "warmup", "peak", "probed_steps")}
     if "cpu_baseline" in res:
-        out["cpu_baseline"] = {k: v for k, v in res["cpu_baseline"].items() if not k.startswith("sample_B")}
+        out["cpu_baseline"] = {k: v for k, v in res["cpu_baseline"].items() if not k.startswith("sample_")}
     if "kernels_file" in res:
         out["kernels_file"] = res["kernels_file"]
     out = _r(out)
-    for drop in (("cpu_baseline", "sample"), ("cpu_baseline", "cpu_model"), ("roofline", "algorithmic_mbytes_per_launch"), ("roofline", "traffic_source"),
-                 ("roofline_all_mfma_convs", "launches_per_step"), ("kernels_file",), ("config", "comm")):
+    for drop in (("cpu_baseline", "cpu_model"), ("roofline", "algorithmic_mbytes_per_launch"), ("roofline", "traffic_source"), ("kernels_file",),
+                 ("roofline_all_mfma_convs", "launches_per_step"), ("bf16_step", "final_loss"), ("segmenter_step", "final_loss"), ("config", "comm"),
+                 ("cpu_baseline", "sample")):
         if len(json.dumps(out)) < MAX_LINE:
             break
         d = out
@@ -540,7 +543,7 @@ def main():
             if args.cpu_small_batch and args.cpu_small_batch != args.cpu_batch:
                 small = cpu_baseline(args.workload, args.cpu_small_batch, 2, 1)
                 cb["value_B%d" % args.cpu_small_batch] = small["value"]
-                cb["sample_B%d" % args.cpu_small_batch] = small["sample"]
+                cb["sample_B%d" % args.cpu_small_batch] = small["sample_detail"]
             res["cpu_baseline"] = cb
         # the per-symbol table and the full-precision record: side file (and stderr); the LAST stdout line is the compact record
         try:

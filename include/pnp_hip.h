@@ -124,6 +124,18 @@ int32_t pnp_conv2d_wino_mode(int32_t mode);
  * profiles/r05_wino_f43_tolerance.txt).  tile = 2: F(2x2) only; 4 (the default, environment PNP_WINOGRAD_TILE): F(4x4) where its planner
  * takes the layer, else F(2x2), else the direct kernels; tile < 2: read only.  Returns the previous value. */
 int32_t pnp_conv2d_wino_tile(int32_t tile);
+/* Transformed-filter cache of the route.  U = G g G^T (36 C K floats per filter and pass) only changes when the filter does: the caller
+ * lends one buffer per (filter, pass) and reports weight writes; a launch whose filter has a valid entry skips wino_filter_kernel (the
+ * frozen source segmenter / shared half of adversarial.py:839-882 never pay it again, a trained layer once per update instead of once per
+ * pass).  pnp_conv2d_wino_filter_bytes(C, K): size of an entry that serves either tile (0: this shape never takes the route).
+ * pnp_conv2d_wino_filter_bind(w, kind, U, bytes): kind 0 forward / 1 data gradient; U = null withdraws the entry, w = null all of them;
+ * the buffer must outlive the binding.  pnp_weights_changed(lo, hi): the floats in [lo, hi) were (or are queued to be) written —
+ * entries of filters inside are stale; lo = null: every entry.  Launches recorded into a hipGraph never touch the cache.
+ * pnp_conv2d_wino_filter_stats: transforms skipped / run into an entry since the last reset. */
+size_t pnp_conv2d_wino_filter_bytes(int32_t C, int32_t K);
+int pnp_conv2d_wino_filter_bind(const float* w, int32_t kind, float* U, size_t bytes);
+void pnp_weights_changed(const void* lo, const void* hi);
+void pnp_conv2d_wino_filter_stats(int64_t* hits, int64_t* fills, int32_t reset);
 /* the filter gradient (pnp_conv2d_wgrad / _wgrad_acc, given pnp_conv2d_wgrad_workspace_bytes) has its own switch (PNP_WINOGRAD_WGRAD,
  * same values); pnp_conv2d_wino_chosen(g, 2) tells its route */
 int32_t pnp_conv2d_wino_wgrad_mode(int32_t mode);

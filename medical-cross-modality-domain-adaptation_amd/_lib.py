@@ -78,6 +78,10 @@ PROTOTYPES = {
     "pnp_conv2d_wino_mode": (c_int32, [c_int32]),
     "pnp_conv2d_wino_wgrad_mode": (c_int32, [c_int32]),
     "pnp_conv2d_wino_tile": (c_int32, [c_int32]),
+    "pnp_conv2d_wino_filter_bytes": (c_size_t, [c_int32, c_int32]),
+    "pnp_conv2d_wino_filter_bind": (c_int, [c_void_p, c_int32, c_void_p, c_size_t]),
+    "pnp_weights_changed": (None, [c_void_p, c_void_p]),
+    "pnp_conv2d_wino_filter_stats": (None, [POINTER(c_int64), POINTER(c_int64), c_int32]),
     "pnp_conv2d_fwd_naive": (c_int, [_F, _F, _F, _G, c_void_p]),
     "pnp_dropout": (c_int, [_F, _F, c_size_t, c_float, c_uint64, c_uint32, c_void_p]),
     "pnp_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),

@@ -470,9 +470,10 @@ class RMSPropOptimizer(object):
         self.ms = torch.ones_like(store.arena)
         self.l2, self.mask = l2_table, mask
         self._mask_host = mask.detach().cpu().numpy() if mask is not None else None
+        self._ranges = store.written_ranges(self._mask_host) if store.arena.is_cuda else None      # what a step writes (kernels.weights_changed)
 
     def step(self):
-        K.rmsprop_step(self.store.arena, self.store.grad_arena, self.ms, self.l2, self.mask, self.lr, self.decay, self.eps)
+        K.rmsprop_step(self.store.arena, self.store.grad_arena, self.ms, self.l2, self.mask, self.lr, self.decay, self.eps, ranges=self._ranges)
 
     # the slot and the learning rate are TF variables in the reference, i.e. part of every checkpoint (tf.train.Saver)
     def _mine(self, v):
@@ -549,6 +550,7 @@ class Trainer(object):
         self.gen_optimizer = RMSPropOptimizer(st, lr, l2_gen, m_gen, **self.opt_kwargs)
         # clip_op: every cls variable whose name contains "Variable" (conv / FC weights, not BN) to [-0.03, 0.03]
         self.clip_mask = st.chunk_table(lambda v: 1 if ("cls" in v.name and "Variable" in v.name) else 0, np.uint8)
+        self._clip_ranges = st.written_ranges(self.clip_mask.cpu().numpy()) if st.arena.is_cuda else None
         return self.dis_optimizer, self.gen_optimizer
 
     def save_checkpoint(self, output_path):
@@ -596,7 +598,9 @@ class Trainer(object):
         if self.dis_optimizer is None:
             self._get_optimizer()
         self._cap = None
-        cap = {"dropout": float(dropout), "mr": tuple(mr_batch.shape), "ct": tuple(ct_batch.shape)}
+        # by-value arguments frozen into the recordings: the RMSProp learning rates (train() decays them, restore_optimizer may replace them)
+        cap = {"dropout": float(dropout), "mr": tuple(mr_batch.shape), "ct": tuple(ct_batch.shape),
+               "lr": (float(self.dis_optimizer.lr), float(self.gen_optimizer.lr))}
         g0 = self.global_step
         cap["dis"] = CapturedStep(lambda m, c: self.dis_step(m, c, dropout, 0), [mr_batch, ct_batch])
         cap["gen"] = CapturedStep(lambda c: self.gen_step(c, dropout, 0), [ct_batch])
@@ -607,6 +611,13 @@ class Trainer(object):
     def _captured(self, which, dropout, shapes):
         cap = getattr(self, "_cap", None)
         if cap is None or cap["dropout"] != float(dropout) or any(cap[k] != tuple(s) for k, s in shapes.items()):
+            return None
+        if cap["lr"] != (float(self.dis_optimizer.lr), float(self.gen_optimizer.lr)):
+            # a replay would apply the learning rate of the recording: run eagerly from here on (capture_steps() again to re-record)
+            if not cap.get("warned"):
+                cap["warned"] = True
+                logging.warning("captured GAN steps were recorded with learning rates %s, now %s: running eagerly (call capture_steps again to re-record)"
+                                % (cap["lr"], (self.dis_optimizer.lr, self.gen_optimizer.lr)))
             return None
         return cap[which]
 
@@ -621,7 +632,7 @@ class Trainer(object):
         if self.reducer is not None:
             self.reducer.allreduce()
         self.dis_optimizer.step()
-        K.clip(self.net.store.arena, self.clip_mask, -0.03, 0.03)
+        K.clip(self.net.store.arena, self.clip_mask, -0.03, 0.03, ranges=self._clip_ranges)
         self.global_step += 1
         return loss
 

@@ -32,6 +32,8 @@
 // filter gradient alike (tools/wino_f43_study.py -> profiles/r05_wino_f43_tolerance.txt; oracle/tf_ops.py WINO4_* are the matrices).
 // B^T and A^T are exact in binary on these points; G has thirds and fifteenths (rounded once, as float32 constants).
 #include <atomic>
+#include <map>
+#include <mutex>
 #include "conv_common.h"
 #include "conv_mma.h"
 
@@ -122,6 +124,7 @@ struct WinoInArgs {
     WinoGeom g;
     int C;
     unsigned x_bytes;
+    int xcd;
 };
 
 template <int M>
@@ -132,7 +135,10 @@ __global__ void __launch_bounds__(NT) wino_in_kernel(WinoInArgs a) {
     const size_t plane = (size_t)a.g.T * a.C;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
     const size_t gs = (size_t)gridDim.x * NT;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += gs) {
+    // neighbouring tiles share 2 of their P patch rows / columns: consecutive logical blocks on ONE XCD, so that the overlap is an L2 hit
+    // (hardware order = block id modulo 8 XCDs: the 8 L2s each fetched the halo — 60 MB read for a 33.5 MB input, r05 counters)
+    const int lb = a.xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    for (size_t i = (size_t)lb * NT + threadIdx.x; i < nvec; i += gs) {
         const int t = (int)(i / C4);
         const int c = (int)(i - (size_t)t * C4) * 4;
         int n, pa, pb, ti, tj;
@@ -280,9 +286,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) wino_gemm_kernel(WinoGemmArgs g) 
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nblk = g.nblk_m * g.nblk_n;
-    const int pos = blockIdx.x / nblk;
-    int bid = blockIdx.x - pos * nblk;
-    if (g.xcd_swizzle) bid = xcd_remap(bid, nblk);
+    // xcd_swizzle 2: consecutive logical ids over the WHOLE grid land on one XCD, i.e. an XCD works through whole transform points: U[pos]
+    // and V[pos] come into ONE L2 (round 4's mapping, 1 = within a point, gave every XCD one pixel tile of every point: each of the 8
+    // L2s read all of U — counter figure 380 MB per 512->512 launch against 113 MB of operands, profiles/r05_pmc_counters_layer512.json)
+    const int gid = g.xcd_swizzle >= 2 ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int pos = gid / nblk;
+    int bid = gid - pos * nblk;
+    if (g.xcd_swizzle == 1) bid = xcd_remap(bid, nblk);
     int mt, nt;
     tile_coords(bid, g.nblk_m, g.nblk_n, g.gn, mt, nt);
     const int m0 = mt * BM, n0 = nt * BN;
@@ -761,6 +771,10 @@ __global__ void __launch_bounds__(NT) wino_wgrad_out_kernel(const float* __restr
 int env_int(const char* name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; }
 double env_dbl(const char* name, double dflt) { return getenv(name) ? atof(getenv(name)) : dflt; }
 
+int env_xcd_in() {
+    static const int v = env_int("PNP_WINO_XCD_IN", 1);
+    return v;
+}
 std::atomic<int> g_wino_wgrad_mode{-1};    // the filter gradient's own switch (PNP_WINOGRAD_WGRAD): 0 never / 1 planner / 2 wherever eligible
 int wino_wgrad_mode() {
     int m = g_wino_wgrad_mode.load(std::memory_order_relaxed);
@@ -791,14 +805,69 @@ int wino_tile_max() {
     return m;
 }
 
-// reduction split of the filter gradient's GEMMs: enough workgroups for >= 1 dispatch round (512 slots), >= 8 stages each
+// ---- transformed-filter cache (pnp_conv2d_wino_filter_bind / pnp_weights_changed) -----------------------------------------------------
+// U = G g G^T only changes when the filter does: the caller lends one buffer per (filter, pass) and tells the library which weights a
+// kernel or a host-side load has written; a launch whose filter has a valid entry skips the transform kernel (frozen layers — the whole
+// source segmenter and the shared half in the adaptation phase, adversarial.py:839-882 — never pay it again; a trained layer pays it once
+// per update instead of once per pass).  Entries are keyed by (filter address, pass); an entry is valid for the tile / shape / stream it
+// was filled for.  A launch recorded into a hipGraph never reads or fills an entry (a replay could not see a later invalidation): it
+// transforms into its workspace like an un-cached launch.
+struct UEntry {
+    float* U;
+    size_t bytes;
+    bool valid;
+    int tile, C, K;
+    hipStream_t st;
+};
+std::mutex g_umx;
+std::map<std::pair<const void*, int>, UEntry> g_ucache;
+std::atomic<long long> g_ucache_hits{0}, g_ucache_fills{0};
+
+// the buffer to transform into / read from for this launch, and whether the transform kernel has to run
+float* filter_slot(const float* w, int kind, int tile, int C, int K, size_t need, float* ws_u, hipStream_t st, bool* run) {
+    *run = true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return ws_u;
+    }
+    std::lock_guard<std::mutex> lk(g_umx);
+    auto it = g_ucache.find({(const void*)w, kind});
+    if (it == g_ucache.end() || it->second.bytes < need) return ws_u;
+    UEntry& e = it->second;
+    if (e.valid && e.tile == tile && e.C == C && e.K == K && e.st == st) {
+        *run = false;
+        g_ucache_hits.fetch_add(1, std::memory_order_relaxed);
+    } else {
+        e.valid = true; e.tile = tile; e.C = C; e.K = K; e.st = st;
+        g_ucache_fills.fetch_add(1, std::memory_order_relaxed);
+    }
+    return e.U;
+}
+
+// reduction split of the filter gradient's GEMMs.  256 CUs hold two workgroups each; a CU that gets r workgroups of s stages runs them in
+// pairs (2 (s + 3) per pair: ~3 stages of prologue + epilogue per workgroup) and a last, lone one at ~1.7x the speed of a paired one:
+// pick the split that minimises floor(r / 2) x 2 (s + 3) + (r odd) x 1.18 (s + 3), r = ceil(workgroups / 256), with >= 8 stages per
+// workgroup.  512->512 at B = 16, F(4x4): 36 x 16 = 576 workgroups of 32 stages (r = 3; r05 counters: matrix pipe busy 0.58) -> two-way
+// split, r = 5; F(2x2): 256 workgroups of 128 stages -> two-way split (r = 2), as measured in round 4
 int wgrad_split(int T, int C, int K, int npos, int* chunks_per_split) {
     const int nblk = pnp_cdiv(C, 128) * pnp_cdiv(K, 128) * npos;
     const int nchunks = pnp_cdiv(T, BK);
-    int ns = pnp_cdiv(512, nblk);
-    if (ns > nchunks / 8) ns = nchunks / 8;
-    if (ns < 1) ns = 1;
-    *chunks_per_split = pnp_cdiv(nchunks, ns);
+    static const int fixed = env_int("PNP_WINO_WGRAD_SPLIT", 0);
+    int best = 1;
+    double best_cost = 1e30;
+    for (int ns = 1; ns <= 16; ++ns) {
+        const int cps = pnp_cdiv(nchunks, ns);
+        if (ns > 1 && cps < 8) break;
+        if (pnp_cdiv(nchunks, cps) != ns) continue;             // (the same number of splits as a smaller ns)
+        const int r = pnp_cdiv((long long)nblk * ns, 256);
+        // + every split's partials: npos C K floats written here and read by the 6x6 -> 3x3 kernel at ~5 TB/s, in the same unit (one
+        // stage of a paired workgroup's half = 1.7 us)
+        const double cost = ((r / 2) * 2.0 + (r & 1) * 1.18) * (cps + 3.0) + ns * 9.4e-7 * npos * (double)C * K;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = ns; }
+    }
+    if (fixed > 0 && pnp_cdiv(nchunks, pnp_cdiv(nchunks, fixed)) == fixed) best = fixed;
+    *chunks_per_split = pnp_cdiv(nchunks, best);
     return pnp_cdiv(nchunks, *chunks_per_split);
 }
 
@@ -852,12 +921,20 @@ int plan_tile(int dtype, int R, int S, int stride, int pad_mode, int dil, int pa
     static const double thr2 = env_dbl("PNP_WINOGRAD_MIN", 85.0), thr2w = env_dbl("PNP_WINOGRAD_WGRAD_MIN", 120.0);
     static const double thr4 = env_dbl("PNP_WINOGRAD4_MIN", 60.0), thr4w = env_dbl("PNP_WINOGRAD4_WGRAD_MIN", 60.0);
     static const int tmin2 = env_int("PNP_WINOGRAD_TMIN", 512), tmin4 = env_int("PNP_WINOGRAD4_TMIN", 128);
+    static const int wgmin = env_int("PNP_WINOGRAD_WGMIN", 256);
     const double ck = (double)C * K / ((double)C + K);
     for (int m = wino_tile_max(); m >= 2; m -= 2) {
         if (!eligible_dims(dtype, R, S, stride, pad_mode, dil, pad_t, pad_l, H, W, OH, OW, N, C, K, m)) continue;
         if (mode >= 2) return m;
         const WinoGeom w = make_wgeom(N, H, W, OH, OW, dil, pad_t, m);
-        if (ck >= (m == 4 ? (wgrad ? thr4w : thr4) : (wgrad ? thr2w : thr2)) && w.T >= (m == 4 ? tmin4 : tmin2)) return m;
+        if (ck < (m == 4 ? (wgrad ? thr4w : thr4) : (wgrad ? thr2w : thr2)) || w.T < (m == 4 ? tmin4 : tmin2)) continue;
+        // forward / data gradient: the GEMMs' workgroups (P^2 points x 128-tile blocks x 128-filter blocks) must cover the chip once
+        // (256 CUs) — below that the direct kernel (or F(2x2): 4x the tiles) is faster: profiles/r05_wino_thresholds.txt, B = 2 and 4 per GPU.
+        // (filter gradient: its workgroup count does not depend on the tile count; the reduction is split to fill the chip)
+        // Near the break-even (C K / (C + K) < 85: 128 -> 128) two rounds: g4 128->128 @32^2 0.050 / 0.058 ms against the direct 0.048 / 0.052.
+        const long long nwg = (long long)(m + 2) * (m + 2) * pnp_cdiv(w.T, 128) * pnp_cdiv(K, 128);
+        if (!wgrad && nwg < (ck < 85.0 ? 2 * wgmin : wgmin)) continue;
+        return m;
     }
     return 0;
 }
@@ -908,11 +985,12 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
         return PNP_EWORKSPACE;
     }
     PNP_REQUIRE(a.y_h == nullptr && a.o_s == 0 && a.ups == 1, "launch_wino: unsupported epilogue");
-    float* U = (float*)ws;
+    bool run_filter;
+    float* U = filter_slot(a.w, flip_transpose ? 1 : 0, M, a.C, a.K, (size_t)NP * a.C * a.K * 4, (float*)ws, st, &run_filter);
     float* V = (float*)((char*)ws + ub);
     float* Mm = (float*)((char*)ws + ub + vb);
     const int cls = prof_class(kind);
-    {
+    if (run_filter) {
         dim3 grid((unsigned)pnp_cdiv(a.K, 32), (unsigned)pnp_cdiv(a.C, 32));
         PnpProfScope ps(cls, st, 0.0, 4.0 * (9.0 + NP) * a.C * a.K, "wino_filter_kernel<%s, %d>", flip_transpose ? "true" : "false", M);
         if (flip_transpose) hipLaunchKernelGGL((wino_filter_kernel<true, M>), grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
@@ -921,7 +999,7 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
     }
     {
         WinoInArgs ia{};
-        ia.x = a.x; ia.V = V; ia.g = w; ia.C = a.C; ia.x_bytes = a.x_bytes;
+        ia.x = a.x; ia.V = V; ia.g = w; ia.C = a.C; ia.x_bytes = a.x_bytes; ia.xcd = a.xcd_swizzle ? env_xcd_in() : 0;
         const size_t nvec = (size_t)w.T * (a.C / 4);
         long long nb = (long long)((nvec + NT - 1) / NT);
         if (nb > 65536) nb = 65536;
@@ -933,7 +1011,8 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
         WinoGemmArgs ga{};
         ga.V = V; ga.U = U; ga.Mm = Mm; ga.T = w.T; ga.C = a.C; ga.K = a.K;
         ga.nblk_m = pnp_cdiv(w.T, 128); ga.nblk_n = pnp_cdiv(a.K, 128);
-        ga.gn = a.gn; ga.xcd_swizzle = a.xcd_swizzle;
+        static const int xcd_mode = env_int("PNP_WINO_XCD", 2);
+        ga.gn = a.gn; ga.xcd_swizzle = a.xcd_swizzle ? xcd_mode : 0;
         dim3 grid((unsigned)(ga.nblk_m * ga.nblk_n * NP));
         const double fl = 2.0 * NP * (double)w.T * a.C * a.K;
         const double by = 4.0 * NP * ((double)w.T * a.C + (double)a.C * a.K + (double)w.T * a.K);
@@ -1000,7 +1079,7 @@ static int launch_wino_wgrad_m(const ConvArgs& a, float* dw, int accumulate, voi
     float* S = (float*)((char*)ws + vb + yb);
     {
         WinoInArgs ia{};
-        ia.x = a.x; ia.V = V; ia.g = w; ia.C = a.C; ia.x_bytes = a.x_bytes;
+        ia.x = a.x; ia.V = V; ia.g = w; ia.C = a.C; ia.x_bytes = a.x_bytes; ia.xcd = a.xcd_swizzle ? env_xcd_in() : 0;
         long long nb = (long long)(((size_t)w.T * (a.C / 4) + NT - 1) / NT);
         if (nb > 65536) nb = 65536;
         PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)a.N * a.H * a.W * a.C + (double)NP * w.T * a.C), "wino_in_kernel<%d>", M);
@@ -1064,4 +1143,43 @@ extern "C" int32_t pnp_conv2d_wino_tile(int32_t tile) {
     const int prev = wino_tile_max();
     if (tile >= 2) g_wino_tile.store(tile >= 4 ? 4 : 2, std::memory_order_relaxed);
     return prev;
+}
+
+// ---- transformed-filter cache: the caller's side -----------------------------------------------------------------------------------------
+// bytes of one (filter, pass) entry that serves either output tile: 36 C K floats; 0: this filter shape never takes the route
+extern "C" size_t pnp_conv2d_wino_filter_bytes(int32_t C, int32_t K) {
+    if (C <= 0 || K < 32 || (C % 32) != 0 || (K % 4) != 0) return 0;
+    return (size_t)36 * C * K * sizeof(float);
+}
+// lend (U != null) or withdraw (U == null) the buffer of filter w's pass (kind 0: forward, 1: data gradient); w == null withdraws every
+// entry.  The buffer must stay allocated until it is withdrawn; a new binding starts invalid.
+extern "C" int pnp_conv2d_wino_filter_bind(const float* w, int32_t kind, float* U, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_umx);
+    if (!w) {
+        g_ucache.clear();
+        return PNP_OK;
+    }
+    PNP_REQUIRE(kind == 0 || kind == 1, "pnp_conv2d_wino_filter_bind: kind must be 0 (forward) or 1 (data gradient)");
+    if (!U) {
+        g_ucache.erase({(const void*)w, (int)kind});
+        return PNP_OK;
+    }
+    PNP_REQUIRE(bytes > 0 && ((uintptr_t)U & 15) == 0, "pnp_conv2d_wino_filter_bind: empty or misaligned buffer");
+    g_ucache[{(const void*)w, (int)kind}] = UEntry{U, bytes, false, 0, 0, 0, nullptr};
+    return PNP_OK;
+}
+// the weights in [lo, hi) were written (optimiser / clip kernel queued, host-side load): their entries are stale.  lo == null: all.
+extern "C" void pnp_weights_changed(const void* lo, const void* hi) {
+    std::lock_guard<std::mutex> lk(g_umx);
+    for (auto& kv : g_ucache)
+        if (!lo || ((const char*)kv.first.first >= (const char*)lo && (const char*)kv.first.first < (const char*)hi)) kv.second.valid = false;
+}
+// (hits, fills) since the last call with reset != 0 — tests and the bench's launch accounting
+extern "C" void pnp_conv2d_wino_filter_stats(int64_t* hits, int64_t* fills, int32_t reset) {
+    if (hits) *hits = g_ucache_hits.load(std::memory_order_relaxed);
+    if (fills) *fills = g_ucache_fills.load(std::memory_order_relaxed);
+    if (reset) {
+        g_ucache_hits.store(0, std::memory_order_relaxed);
+        g_ucache_fills.store(0, std::memory_order_relaxed);
+    }
 }

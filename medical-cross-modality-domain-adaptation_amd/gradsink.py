@@ -52,15 +52,26 @@ class Sink(object):
 
 
 _SINKS = {}     # data_ptr of the parameter -> Sink
+_READY = [0]    # sinks with a `ready` hook set (kept by set_ready / register / lookup): has_ready_hooks() is asked per filter gradient
 
 
 def has_ready_hooks():
-    """does any sink announce completed gradients to a data-parallel reducer (then gradients must complete on the compute stream)"""
-    return any(s.ready is not None for s in _SINKS.values())
+    """does any LIVE sink announce completed gradients to a data-parallel reducer (then gradients must complete on the compute stream).
+    O(1) without data parallelism; with hooks set, sinks whose store is gone are pruned first so that a dead data-parallel store cannot
+    switch the side-stream overlap off for the rest of the process"""
+    if _READY[0] <= 0:
+        return False
+    for k in [k for k, s in _SINKS.items() if s.ready is not None and s.param() is None]:
+        del _SINKS[k]
+        _READY[0] -= 1
+    return _READY[0] > 0
 
 
 def register(param):
     """param: a leaf tensor whose .grad is (a view of) the buffer the kernels may add into"""
+    old = _SINKS.get(param.data_ptr())
+    if old is not None and old.ready is not None:
+        _READY[0] -= 1
     s = Sink(param)
     _SINKS[param.data_ptr()] = s
     return s
@@ -77,7 +88,8 @@ def lookup(t):
     # 1x1 convolutions [1, 1, D, 1])
     if p is None or p.grad is None or p.data_ptr() != t.data_ptr() or p.numel() != t.numel():
         if p is None:
-            _SINKS.pop(t.data_ptr(), None)          # the store that owned this address is gone
+            if _SINKS.pop(t.data_ptr(), None) is not None and s.ready is not None:          # the store that owned this address is gone
+                _READY[0] -= 1
         return None
     return s
 
@@ -108,6 +120,7 @@ def done(s):
 def set_ready(param, fn):
     s = _SINKS.get(param.data_ptr())
     if s is not None and s.param() is param:
+        _READY[0] += (fn is not None) - (s.ready is not None)
         s.ready = fn
         return True
     return False

@@ -5,6 +5,8 @@ arithmetic result comes from libpnp_hip.so.  Tensors are NHWC float32, filters H
 reference's layouts (layers.py).  Each function names the reference op it stands for.
 """
 import ctypes
+import os
+import weakref
 
 import torch
 
@@ -97,6 +99,7 @@ def conv2d_fwd(x, w, g, keep_prob=1.0, seed=0, stream_id=0, out=None, naive=Fals
     else:
         nbytes = lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))      # > 0 only for layers with too few output tiles
         ws = workspace(nbytes, x.device) if nbytes else None
+        _wino_u(w, g, 0)
         check(lib.pnp_conv2d_fwd_ws(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id),
                                     ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
                                     _stream()), "pnp_conv2d_fwd")
@@ -131,6 +134,54 @@ def wino_chosen(g, kind=0):
     return int(_lib.load().pnp_conv2d_wino_chosen(ctypes.byref(g), int(kind)))
 
 
+# ---- transformed-filter cache of the Winograd route (pnp_conv2d_wino_filter_bind) ------------------------------------------------------
+# U = G g G^T changes only when the filter does.  Filters OWNED BY A VariableStore (variables.py marks their tensors `_pnp_var`) get one
+# buffer per pass, lent to the library; the library skips wino_filter_kernel while the entry is valid.  Validity: the library drops an
+# entry when weights_changed() names its address range (optimisers, clip, host-side loads); here an entry is tied to the tensor OBJECT it
+# was made for (weakref: a new tensor at a recycled address starts over) and to its torch version counter (an in-place torch op on the
+# filter or on the arena it is a view of).  Ad-hoc filters (tests, tools) are never cached.  PNP_WINOGRAD_UCACHE=0: off.
+U_CACHE = os.environ.get("PNP_WINOGRAD_UCACHE", "1") != "0"
+_u_cache = {}
+
+
+def _wino_u(w, g, kind):
+    if not U_CACHE or not getattr(w, "_pnp_var", False):
+        return
+    key = (w.data_ptr(), kind)
+    ent = _u_cache.get(key)
+    if ent is not None and ent[0]() is w:
+        if ent[2] != w._version:             # written by a torch op since the entry was filled
+            if ent[1] is not None:
+                _lib.load().pnp_weights_changed(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(w.data_ptr() + 4 * w.numel()))
+            ent[2] = w._version
+        return
+    lib = _lib.load()
+    U = None
+    if g.R == 3 and g.S == 3 and wino_chosen(g, kind):          # (decided once per filter and pass: a later policy change runs un-cached)
+        nbytes = int(lib.pnp_conv2d_wino_filter_bytes(int(w.shape[2]), int(w.shape[3])))
+        if nbytes:
+            U = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+            check(lib.pnp_conv2d_wino_filter_bind(ctypes.c_void_p(w.data_ptr()), int(kind), ctypes.c_void_p(U.data_ptr()), nbytes),
+                  "pnp_conv2d_wino_filter_bind")
+    if ent is not None and ent[1] is not None and U is None:
+        lib.pnp_conv2d_wino_filter_bind(ctypes.c_void_p(w.data_ptr()), int(kind), None, 0)
+    _u_cache[key] = [weakref.ref(w), U, w._version]
+
+
+def wino_u_cache_clear():
+    """withdraw every transformed-filter buffer (tests; a store that goes away)"""
+    if _u_cache:
+        _lib.load().pnp_conv2d_wino_filter_bind(None, 0, None, 0)
+        _u_cache.clear()
+
+
+def wino_u_cache_stats(reset=False):
+    """(filter transforms skipped, transforms run into a cache entry) since the last reset"""
+    h, f = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.load().pnp_conv2d_wino_filter_stats(ctypes.byref(h), ctypes.byref(f), 1 if reset else 0)
+    return int(h.value), int(f.value)
+
+
 def _fwd_ws(g, device):
     nbytes = _lib.load().pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))
     if not nbytes:
@@ -146,6 +197,7 @@ def conv2d_fwd_stats(x, w, g, shift, keep_prob=1.0, seed=0, stream_id=0):
     y = torch.empty((g.N, g.OH, g.OW, g.K), dtype=torch.float32, device=x.device)
     parts = workspace(nparts * 2 * g.K * 4, x.device, slot="stats")
     wsp, wsn = _fwd_ws(g, x.device)
+    _wino_u(w, g, 0)
     check(lib.pnp_conv2d_fwd_stats_ws(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _p(shift),
                                       ctypes.c_void_p(parts.data_ptr()), parts.numel(), wsp, wsn, _stream()), "pnp_conv2d_fwd_stats_ws")
     return y, (parts, nparts)
@@ -177,6 +229,7 @@ def conv2d_fwd_bn(x, w, g, scale_shift, shortcut=None, alpha=0.2, keep_prob=1.0,
     y = torch.empty((g.N, g.OH, g.OW, g.K), dtype=torch.float32, device=x.device)
     cs = shortcut.shape[-1] if shortcut is not None else 0
     wsp, wsn = _fwd_ws(g, x.device)
+    _wino_u(w, g, 0)
     check(lib.pnp_conv2d_fwd_bn_ws(_p(x), _p(w), _p(y), ctypes.byref(g), float(keep_prob), int(seed), int(stream_id), _p(scale_shift[0]),
                                    _p(scale_shift[1]), _p(shortcut), cs, float(alpha), wsp, wsn, _stream()), "pnp_conv2d_fwd_bn_ws")
     return y
@@ -208,10 +261,24 @@ _filter_cache = {}
 CAST_COUNT = [0]          # on-demand casts since the last reset (tests / profiling: how many producers still lack a bf16 output)
 
 
-def weights_changed():
+PINNED = [0]              # live CapturedStep objects: their hipGraphs hold the ADDRESSES of filter shadows — nothing may be freed under them
+
+
+def weights_changed(ranges=None):
+    """weights were (or are queued to be) written.  ranges: [(first byte address, end address), ...] of what changed — the library drops
+    the transformed filters (Winograd route) of exactly those; None: everything.  The bf16 shadows follow one global epoch."""
     _WEIGHT_EPOCH[0] += 1
-    if len(_filter_cache) > 1024:          # shadows of filters of stores that no longer exist (test suites): start over
+    if len(_filter_cache) > 1024 and not PINNED[0]:      # shadows of filters of stores that no longer exist (test suites): start over
         _filter_cache.clear()
+    if _u_cache:
+        lib = _lib.load()
+        if ranges is None and len(_u_cache) > 512 and not PINNED[0]:     # buffers of stores that no longer exist (test suites): start over
+            wino_u_cache_clear()
+        elif ranges is None:
+            lib.pnp_weights_changed(None, None)
+        else:
+            for lo, hi in ranges:
+                lib.pnp_weights_changed(ctypes.c_void_p(lo), ctypes.c_void_p(hi))
 
 
 class HalfOnly(object):
@@ -231,7 +298,9 @@ def bf16_of(t):
     if isinstance(t, HalfOnly):
         return t.h
     h = getattr(t, "_pnp_h", None)
-    if h is not None and h[1] == t._version and h[0].shape == t.shape:
+    # (while a hipGraph is being recorded a cached shadow would leave the cast OUT of the graph: a replay on new input data would then
+    # read the warm-up's copy — cast inside the recording instead)
+    if h is not None and h[1] == t._version and h[0].shape == t.shape and not torch.cuda.is_current_stream_capturing():
         return h[0]
     CAST_COUNT[0] += 1
     hh = cast_bf16(t)
@@ -249,14 +318,17 @@ def filter_shadows(w):
     """(w_io, w_oi) of an fp32 filter [R,S,C,K], refreshed when the weight epoch has moved"""
     key = (w.data_ptr(), tuple(w.shape))
     ent = _filter_cache.get(key)
-    if ent is None or ent[0] != _WEIGHT_EPOCH[0]:
+    # valid: same weight epoch (kernels that write weights), same torch version counter (an in-place torch op on the filter or the arena
+    # it is a view of), same owner object (a new tensor on a recycled address is another filter)
+    owner = w._base if w._base is not None else w
+    if ent is None or ent[0] != _WEIGHT_EPOCH[0] or ent[3] != w._version or ent[4]() is not owner:
         if ent is None:
             w_io, w_oi = filter_bf16(w)
         else:                   # refresh in place: same buffers, no allocation in the steady state
             w_io, w_oi = ent[1], ent[2]
             R, S, C, Kc = w.shape
             check(_lib.load().pnp_filter_bf16(_p(w), _ph(w_io), _ph(w_oi), R, S, C, Kc, _stream()), "pnp_filter_bf16")
-        ent = (_WEIGHT_EPOCH[0], w_io, w_oi)
+        ent = (_WEIGHT_EPOCH[0], w_io, w_oi, w._version, weakref.ref(owner))
         _filter_cache[key] = ent
     return ent[1], ent[2]
 
@@ -327,6 +399,7 @@ def conv2d_dgrad(dy, w, g, residual=None):
     dx = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dy.device)
     nbytes = lib.pnp_conv2d_dgrad_workspace_bytes(ctypes.byref(g))
     ws = workspace(nbytes, dy.device)
+    _wino_u(w, g, 1)
     if residual is not None:
         if tuple(residual.shape) != tuple(dx.shape):
             raise ValueError("conv2d_dgrad: residual %s does not match dx %s" % (tuple(residual.shape), tuple(dx.shape)))
@@ -603,9 +676,10 @@ def bn_from_moments(mom, world):
 
 
 def _bumps_weights(fn):
-    """a kernel that writes the weight arena: the filters' bf16 shadows are stale afterwards"""
+    """a kernel that writes the weight arena: the filters' bf16 shadows and transformed filters are stale afterwards.
+    ranges=[(lo, hi), ...]: byte-address ranges of the weights this call writes (an optimiser over a var_list: the chunks its mask selects)"""
     def wrapped(*a, **k):
-        weights_changed()
+        weights_changed(k.pop("ranges", None))
         return fn(*a, **k)
     wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
     return wrapped

@@ -24,6 +24,12 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import kernels as K
+import weakref
+
+
+def _unpin():
+    K.PINNED[0] -= 1
 
 
 class CapturedStep(object):
@@ -57,6 +63,8 @@ class CapturedStep(object):
             if adam is not None:
                 adam.t = t0                              # recording executes nothing: the counter moved, the weights did not
         self.replays = 0
+        K.PINNED[0] += 1                                  # the graph holds addresses of cached filter shadows: nothing may be freed under it
+        weakref.finalize(self, _unpin)
 
     def _lr_t(self):
         a = self.adam
@@ -80,4 +88,4 @@ class CapturedStep(object):
         self._pre(seed)
         self.graph.replay()
         self.replays += 1
-        return self.out
+        return self.out.clone()          # (the static output tensor is overwritten by the next replay: callers may keep what they get)

@@ -186,11 +186,28 @@ class VariableStore(object):
             t.grad = self.grad_arena[v.offset:v.offset + v.numel].view(v.shape)
             v.tensor = t
             gradsink.register(t)        # kernels may add this variable's gradient straight into its slot
+        for v in self.vars.values():    # store-owned filters: the Winograd route may keep their transformed copies (kernels._wino_u)
+            if v.tensor.dim() == 4 and v.tensor.is_cuda:
+                v.tensor._pnp_var = True
         self.finalized = True
 
     # ---- helpers for the optimisers ---------------------------------------------------------------
     def trainable(self):
         return [v for v in self.vars.values() if v.trainable]
+
+    def written_ranges(self, mask_host=None):
+        """byte-address ranges [(lo, hi), ...] of the trainable arena an optimiser with this per-chunk mask writes (None: all of it)"""
+        base = self.arena.data_ptr()
+        if mask_host is None:
+            return [(base, base + 4 * self.arena.numel())]
+        out, start = [], None
+        for i, m in enumerate(list(mask_host) + [0]):
+            if m and start is None:
+                start = i
+            elif not m and start is not None:
+                out.append((base + 4 * start * OPT_CHUNK, base + 4 * i * OPT_CHUNK))
+                start = None
+        return out
 
     def chunk_table(self, fn, dtype):
         """per-chunk table over the trainable arena: value fn(var) for every chunk the variable covers"""

@@ -198,3 +198,79 @@ def test_segmenter_step_on_the_winograd_route(dev, wino):
     cw = float(torch.nn.functional.cosine_similarity(w0.double().flatten(), w1.double().flatten(), dim=0))
     print("segmenter step, Winograd F(%dx%d) route vs direct: loss %.7f vs %.7f, gradient cosine %.8f, weights-after-Adam cosine %.8f" % (wino.tile, wino.tile, l1, l0, cos, cw))
     assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0)) and cos > 0.99999 and cw > 0.999999
+
+
+def test_transformed_filter_cache(dev, wino):
+    """pnp_conv2d_wino_filter_bind / pnp_weights_changed: a store-owned filter is transformed once per weight change, not once per launch —
+    same bits as the un-cached launch; a write reported by range, a write by a torch op (version counter) and a new tensor object on the same
+    address each invalidate the entry; an unrelated range does not; ad-hoc filters are never cached"""
+    K, L = pkg("kernels"), pkg("_lib")
+    rng = np.random.default_rng(17)
+    N, H, C, Kf = 2, 16, 64, 96
+    x = torch.from_numpy(rng.standard_normal((N, H, H, C)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy(rng.standard_normal((N, H, H, Kf)).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.standard_normal((3, 3, C, Kf)) * 0.05).astype(np.float32)).to(dev)
+    g = K.conv_geom(tuple(x.shape), tuple(w.shape), 1, 1, "SAME")
+    wino(2)
+    K.wino_u_cache_clear()
+    K.wino_u_cache_stats(reset=True)
+    y_ref, dx_ref = K.conv2d_fwd(x, w, g), K.conv2d_dgrad(dy, w, g)                 # ad-hoc filter: no entry
+    assert K.wino_u_cache_stats() == (0, 0)
+    w._pnp_var = True                                                                # what VariableStore.finalize does for its filters
+    for i in range(3):
+        assert torch.equal(K.conv2d_fwd(x, w, g), y_ref) and torch.equal(K.conv2d_dgrad(dy, w, g), dx_ref)
+    assert K.wino_u_cache_stats(reset=True) == (4, 2), "one fill per pass, then hits"
+    lo = w.data_ptr()
+    K.weights_changed([(lo + 4 * w.numel(), lo + 8 * w.numel())])                   # somebody else's weights
+    assert torch.equal(K.conv2d_fwd(x, w, g), y_ref) and K.wino_u_cache_stats(reset=True) == (1, 0)
+    K.axpby(w, w, 1.0, 1.0)                                                          # w <- 2 w through a raw kernel: reported by range
+    K.weights_changed([(lo, lo + 4 * w.numel())])
+    y2 = K.conv2d_fwd(x, w, g)
+    assert K.wino_u_cache_stats(reset=True) == (0, 1) and _rel(y2, 2 * y_ref.double()) < 1e-6
+    w.mul_(0.5)                                                                      # a torch op: the version counter moves
+    assert torch.equal(K.conv2d_fwd(x, w, g), y_ref) and K.wino_u_cache_stats(reset=True) == (0, 1)
+    assert _rel(K.conv2d_dgrad(dy, w, g), dx_ref.double()) == 0.0                    # (the data-gradient entry was dropped by the range above)
+    K.weights_changed()                                                              # everything
+    assert torch.equal(K.conv2d_fwd(x, w, g), y_ref) and K.wino_u_cache_stats(reset=True)[1] == 1
+    K.wino_u_cache_clear()
+
+
+def test_joint_steps_with_and_without_the_filter_cache(dev, wino):
+    """one discriminator + one generator update (adversarial.py:839-882) with the transformed-filter cache on and off: identical losses and
+    weights (the cache only skips launches), and with it on the frozen layers' transforms are skipped from the second pass on"""
+    adv, K = pkg("adversarial"), pkg("kernels")
+    if wino.tile == 2:
+        pytest.skip("one tile is enough here")
+    B = 2
+    rng = np.random.default_rng(4)
+    mr = torch.from_numpy(rng.standard_normal((B, 256, 256, 3)).astype(np.float32)).to(dev)
+    ct = torch.from_numpy(rng.standard_normal((B, 256, 256, 3)).astype(np.float32)).to(dev)
+    wino(2)
+    K.wino_wgrad_mode(2)
+    out = {}
+    prev = K.U_CACHE
+    try:
+        for on in (False, True):
+            K.U_CACHE = on
+            K.wino_u_cache_clear()
+            K.wino_u_cache_stats(reset=True)
+            net = adv.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, seed=0,
+                               cost_kwargs={"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.3},
+                               network_config={"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True, "cls_trainable": True,
+                                               "m_cls_trainable": True})
+            tr = adv.Trainer(net, None, None, None, None, num_cls=5, batch_size=B, opt_kwargs={"learning_rate": 3e-4},
+                             train_config={"dis_sub_iter": 1, "gen_sub_iter": 1})
+            tr._get_optimizer()
+            losses = []
+            for i in range(2):
+                losses.append(float(tr.dis_step(mr, ct, 0.75, 2 * i + 1)))
+                losses.append(float(tr.gen_step(ct, 0.75, 2 * i + 2)))
+            torch.cuda.synchronize()
+            out[on] = (losses, net.store.arena.clone(), K.wino_u_cache_stats(reset=True))
+    finally:
+        K.U_CACHE = prev
+        K.wino_u_cache_clear()
+    (l0, a0, s0), (l1, a1, s1) = out[False], out[True]
+    print("joint steps: filter-transform cache off %s / on %s (hits, fills); losses %s" % (s0, s1, l1))
+    assert s0 == (0, 0) and s1[0] > s1[1] > 0
+    assert l0 == l1 and torch.equal(a0, a1)

@@ -629,3 +629,22 @@ def test_winograd_restatement_equals_the_direct_convolution(m):
     e_d = np.abs(T.conv2d(torch.from_numpy(x), torch.from_numpy(w), 1, 1, "SAME").numpy() - ref).max() / np.abs(ref).max()
     # F(2,3): as close as the direct sum; F(4,3) on the points (0, +-1, 1/2, -2): within 2e-5 of max|y| (tools/wino_f43_study.py: 4e-6 typical)
     assert (e_w < 5e-6 and e_w < 4 * e_d + 1e-6) if m == 2 else e_w < 2e-5, (e_w, e_d)
+
+
+def test_written_ranges_of_an_optimiser_mask():
+    """VariableStore.written_ranges: the byte ranges kernels.weights_changed hands to pnp_weights_changed — maximal runs of selected
+    chunks of the trainable arena (an optimiser over a var_list writes exactly those)"""
+    V = pkg("variables")
+    L = pkg("_lib")
+    st = V.VariableStore(device="cpu", seed=0)
+    for i, n in enumerate((10, 3 * L.OPT_CHUNK, 5, L.OPT_CHUNK + 1)):
+        st.get("v%d" % i, (n,), init=0.0)
+    st.finalize()
+    base, ch = st.arena.data_ptr(), 4 * L.OPT_CHUNK
+    assert st.written_ranges(None) == [(base, base + 4 * st.arena.numel())]
+    nch = st.arena.numel() // L.OPT_CHUNK
+    assert nch == 1 + 3 + 1 + 2
+    mask = st.chunk_table(lambda v: 1 if v.name in ("v1", "v3") else 0, np.uint8).numpy()
+    assert list(mask) == [0, 1, 1, 1, 0, 1, 1]
+    assert st.written_ranges(mask) == [(base + ch, base + 4 * ch), (base + 5 * ch, base + 7 * ch)]
+    assert st.written_ranges(np.zeros(nch, np.uint8)) == []

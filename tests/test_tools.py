@@ -82,6 +82,7 @@ def test_bench_last_line_is_compact_whatever_the_kernel_count():
              "flops": 8.64e10 * (10 + i) / (1 + i), "bytes": 1.08e8 * (10 + i)} for i in range(60)]
     recs = bench.roofline_records(rows, bench.PEAK_FP32_MFMA_TFLOPS)
     assert len(recs) == 60
+    short_sample = "CPU oracle joint step, B=16, 1 warm-up + 3 timed steps, median 65.6 s/step"
     long_sample = "oracle.nets_adv.joint_train_step (torch-CPU fp32 port of adversarial.py:839-882: 1 dis + clip + 1 gen), B=16 per domain, " \
                   "1 warm-up + 3 timed steps, median 65.61 s/step (all: 70.12, 65.61, 65.40, 66.02)"
     res = {"metric": "training slices/sec (256x256x3, B=16 per GPU) joint segmenter+GAN step (1 dis update on B MR + B CT, clip, 1 gen update on B CT)",
@@ -96,10 +97,13 @@ def test_bench_last_line_is_compact_whatever_the_kernel_count():
            "roofline": dict(recs[0]), "roofline_note": "x" * 700, "roofline_kernels": recs,
            "roofline_all_mfma_convs": {"achieved": 128.6, "peak": 157.3, "frac": 0.8175, "unit": "TFLOP/s", "ms_per_step": 81.2,
                                        "launches_per_step": 560.0, "probed_steps": 2},
+           "step_algorithmic": {"tflop_per_step": 10.496, "achieved": 153.4123, "frac_of_mfma_peak": 0.97528},
            "segmenter_step": {"workload": "BASELINE configs[1]: ...", "value": 463.0, "unit": "slices/s", "ms_per_step": 34.5, "steps": 10,
                               "warmup": 2, "final_loss": 1.5},
+           "bf16_step": {"workload": "BASELINE configs[4] arithmetic on the joint step: ...", "value": 463.0123, "unit": "slices/s", "ms_per_step": 34.5678,
+                         "steps": 10, "warmup": 2, "final_loss": 0.51234},
            "cpu_baseline": {"value": 0.2441, "unit": "slices/s", "cores": 128, "cpu_model": "AMD EPYC 9575F 64-Core Processor", "kind": "port",
-                            "batch": 16, "s_per_step": 65.61, "sample": long_sample, "value_B2": 0.1266, "sample_B2": long_sample},
+                            "batch": 16, "s_per_step": 65.61, "sample": short_sample, "sample_detail": long_sample, "value_B2": 0.1266, "sample_B2": long_sample},
            "kernels_file": "gpurun_out/bench_kernels_joint_f32_n8.json"}
     assert len(json.dumps(res)) > 20000                      # what round 3 printed
     rec = bench.compact_record(res)
@@ -115,6 +119,8 @@ def test_bench_last_line_is_compact_whatever_the_kernel_count():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in back["cpu_baseline"], k
     assert "B=16" in back["cpu_baseline"]["sample"] and back["cpu_baseline"]["value_B2"] == 0.1266 and "sample_B2" not in back["cpu_baseline"]
+    assert "sample_detail" not in back["cpu_baseline"]
+    assert back["bf16_step"]["value"] == 463.0 and back["segmenter_step"]["value"] == 463.0 and back["step_algorithmic"]["achieved"] == 153.4
     assert abs(back["value"] - 166.7) < 0.05 and back["roofline"]["frac"] == float("%.4g" % recs[0]["frac"])
     assert back["config"]["comm"]["dis_step_exposed_ms"] == 0.41 and "launch_order" not in json.dumps(back)
 
