@@ -230,6 +230,7 @@ def test_transformed_filter_cache(dev, wino):
     w.mul_(0.5)                                                                      # a torch op: the version counter moves
     assert torch.equal(K.conv2d_fwd(x, w, g), y_ref) and K.wino_u_cache_stats(reset=True) == (0, 1)
     assert _rel(K.conv2d_dgrad(dy, w, g), dx_ref.double()) == 0.0                    # (the data-gradient entry was dropped by the range above)
+    K.wino_u_cache_stats(reset=True)
     K.weights_changed()                                                              # everything
     assert torch.equal(K.conv2d_fwd(x, w, g), y_ref) and K.wino_u_cache_stats(reset=True)[1] == 1
     K.wino_u_cache_clear()

@@ -20,6 +20,7 @@ if os.environ.get("WINO_WGRAD") is not None:    # the same for the filter gradie
 if os.environ.get("TILE") is not None:          # largest output tile of the route: 2 = F(2x2, 3x3) only, 4 = F(4x4, 3x3) first
     K.wino_tile(int(os.environ["TILE"]))
 SKIP_WGRAD = bool(os.environ.get("SKIP_WGRAD"))
+PROF = bool(os.environ.get("PROF"))             # after each layer's line: one more pass of each kind with the library's per-launch HIP events, per kernel symbol
 LAYERS = [  # name, H, C, K, R, dil, padding, count in segmenter fwd
     ("g1 3->16", 256, 3, 16, 3, 1, "SAME", 1),
     ("g1 16->16", 256, 16, 16, 3, 1, "SAME", 2),
@@ -88,6 +89,19 @@ def main():
         print("%-18s %9.2f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f%s" % (name, flop / 1e9, tf, flop / tf / 1e9, td, flop / td / 1e9, tw,
                                                                      flop / tw / 1e9, "  [winograd fwd/dgrad/wgrad: %d/%d/%d]" % (K.wino_chosen(g, 0), K.wino_chosen(g, 1), K.wino_chosen(g, 2))
                                                                      if (K.wino_chosen(g, 0) or K.wino_chosen(g, 1) or K.wino_chosen(g, 2)) else ""))
+        if PROF:
+            for kind, cls, fn in (("fwd", L.PROF_CONV_FWD, lambda: K.conv2d_fwd(x, w, g)), ("dgrad", L.PROF_CONV_DGRAD, lambda: K.conv2d_dgrad(dy, w, g)),
+                                  ("wgrad", L.PROF_CONV_WGRAD, lambda: K.conv2d_wgrad(x, dy, g))):
+                L.prof_summary()
+                L.prof_enable(cls)
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                L.prof_enable(0)
+                for r in L.prof_summary():
+                    us = 1e3 * r["ms"] / max(r["launches"], 1)
+                    print("      %-5s %-46s %8.1f us  %s" % (kind, r["name"], us, ("%6.1f TF/s executed" % (r["flops"] / r["launches"] / us / 1e6)) if r["flops"] > 0
+                                                              else ("%6.2f TB/s" % (r["bytes"] / r["launches"] / us / 1e6))))
         tot["fwd"] += tf * cnt
         tot["dgrad"] += td * cnt
         tot["wgrad"] += tw * cnt
