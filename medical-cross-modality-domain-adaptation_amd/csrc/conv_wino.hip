@@ -706,6 +706,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) wino_wgrad_gemm_kernel(WinoWgradG
     wgrad_epilogue<TM, TN>(e, acc, g.S + ((size_t)z * g.npos + pos) * g.C * g.K, m0, n0, wm0, wn0, lane);
 }
 
+// S[0] += sum_{z >= 1} S[z], one thread per float4 of the npos x C x K products: the many-way splits of the narrow layers (128->128 at
+// 128^2: 14 splits of a single 128 x 128 tile per point) summed at full width — wino_wgrad_out_kernel's own loop over the splits runs
+// on C K / 4 threads only (16 workgroups for that layer: 117 us at 0.3 TB/s, profiles/r05_wino_per_kernel_layers_F4x4_B16.txt)
+__global__ void __launch_bounds__(NT) wino_splitsum_kernel(float* __restrict__ S, size_t nvec, int nsplit) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= nvec) return;
+    f32x4 v = ld4(S + i * 4);
+    for (int z = 1; z < nsplit; ++z) v += ld4(S + ((size_t)z * nvec + i) * 4);       // fixed order: deterministic
+    st4(S + i * 4, v);
+}
+
 // dW[r][s][c][k] (+)= sum_ij G[i][r] G[j][s] sum_z S[z][P i + j][c][k]: one thread = one channel x 4 filters
 template <int M>
 __global__ void __launch_bounds__(NT) wino_wgrad_out_kernel(const float* __restrict__ S, float* __restrict__ dw, int C, int K, int nsplit,
@@ -1107,10 +1118,18 @@ static int launch_wino_wgrad_m(const ConvArgs& a, float* dw, int accumulate, voi
         hipLaunchKernelGGL((wino_wgrad_gemm_kernel<128, 128, 2, 2, M>), grid, dim3(NTHREADS), 0, st, ga);
         PNP_CHECK_LAUNCH("wino_wgrad_gemm_kernel");
     }
+    int ns_out = ns;
+    if (ns > 2 && (size_t)a.C * (a.K / 4) < (size_t)NT * 512) {       // few (channel, filter) vectors, many splits: sum the splits at full width first
+        const size_t nv = (size_t)NP * a.C * (a.K / 4);
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)ns + 1.0) * NP * a.C * a.K, "wino_splitsum_kernel");
+        hipLaunchKernelGGL(wino_splitsum_kernel, dim3((unsigned)((nv + NT - 1) / NT)), dim3(NT), 0, st, S, nv, ns);
+        PNP_CHECK_LAUNCH("wino_splitsum_kernel");
+        ns_out = 1;
+    }
     {
         const size_t nvec = (size_t)a.C * (a.K / 4);
-        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)ns * NP + 9.0 * (1 + (accumulate != 0))) * a.C * a.K, "wino_wgrad_out_kernel<%d>", M);
-        hipLaunchKernelGGL(wino_wgrad_out_kernel<M>, dim3((unsigned)((nvec + NT - 1) / NT)), dim3(NT), 0, st, (const float*)S, dw, a.C, a.K, ns, accumulate);
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)ns_out * NP + 9.0 * (1 + (accumulate != 0))) * a.C * a.K, "wino_wgrad_out_kernel<%d>", M);
+        hipLaunchKernelGGL(wino_wgrad_out_kernel<M>, dim3((unsigned)((nvec + NT - 1) / NT)), dim3(NT), 0, st, (const float*)S, dw, a.C, a.K, ns_out, accumulate);
         PNP_CHECK_LAUNCH("wino_wgrad_out_kernel");
     }
     return PNP_OK;

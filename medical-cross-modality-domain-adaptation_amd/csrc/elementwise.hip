@@ -3,6 +3,8 @@
 // Reference call sites: layers.py:95-100 (batch_norm), 145-189 (residual_block / DR_block tails),
 // 102-103 (max_pool2d), ops.py:3-27 (PS), adversarial.py:325-335 (critic input), layers.py:25,74,93 (dropout).
 // All tensors are [P][C] fp32 with C contiguous; every kernel moves 16 B per lane where C % 4 == 0.
+#include <atomic>
+#include <mutex>
 #include "pnp_common.h"
 
 namespace {
@@ -44,11 +46,26 @@ struct ColArgs {
     int C;
     int rows_per_block;
     float eps, alpha;
+    // one-launch combine (round 5): tick != null -> the LAST workgroup of every slab of COLRED_SLAB partial rows sums its slab (double,
+    // fixed order), and the last of those sums the slabs and writes the results — no colreduce_compact / colreduce_final launch.
+    // tick: nslab slab counters + 1 top counter, zero on entry and left zero (self-resetting)
+    unsigned* tick;
+    int nslab;
+    float* o0;           // KIND0: mean ; KIND1: dbeta
+    float* o1;           // KIND0: var  ; KIND1: dgamma
+    float* acc0;         // KIND1: += (gradient arena slots), nullable
+    float* acc1;
+    float* mm;           // KIND0: moving mean / variance update, nullable
+    float* mv;
+    float decay;
 };
+
+constexpr int COLRED_SLAB = 128;
 
 template <int KIND>
 __global__ void __launch_bounds__(NT) colreduce_kernel(ColArgs a) {
     __shared__ float red[NT * 8];
+    __shared__ int s_last;
     const int C4 = a.C >> 2;
     const int rpi = NT / C4;                 // rows per iteration (C4 <= 256 guaranteed by the host)
     const int t = threadIdx.x;
@@ -127,6 +144,113 @@ __global__ void __launch_bounds__(NT) colreduce_kernel(ColArgs a) {
         st4(w0, a0);
         st4(w1, a1);
     }
+    if (!a.tick) return;
+    // ---- one-launch combine.  Release: the partial row is visible device-wide before the ticket is taken; acquire: the last taker sees
+    // every row of its slab.  Summation orders are fixed (rows of a slab by (row lane, stride), slabs in order): deterministic whichever
+    // workgroup happens to be last.
+    const int nblk = (int)gridDim.x;
+    const int slab = blockIdx.x / COLRED_SLAB;
+    const int b0 = slab * COLRED_SLAB;
+    const int b1 = (b0 + COLRED_SLAB < nblk) ? b0 + COLRED_SLAB : nblk;
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_last = (atomicAdd(&a.tick[slab], 1u) == (unsigned)(b1 - b0 - 1));
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double* dred = reinterpret_cast<double*>(red);          // NT x 4 doubles (the float scratch, reused): two passes, q0 then q1
+    double d0[4] = {0, 0, 0, 0}, d1[4] = {0, 0, 0, 0};
+    if (active) {
+        for (int b = b0 + rsub; b < b1; b += rpi) {
+            const f32x4 v0 = ld4(a.ws + ((size_t)b * 2 + 0) * a.C + cg * 4), v1 = ld4(a.ws + ((size_t)b * 2 + 1) * a.C + cg * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                d0[e] += (double)v0[e];
+                d1[e] += (double)v1[e];
+            }
+        }
+    }
+    double t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dred[t * 4 + e] = q == 0 ? d0[e] : d1[e];
+        __syncthreads();
+        if (t < C4) {
+            for (int j = 0; j < rpi; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) (q == 0 ? t0 : t1)[e] += dred[(j * C4 + t) * 4 + e];
+        }
+    }
+    // the slab's sum as a (high, low) pair of floats over its own first two rows (colreduce_compact_kernel's layout): only this workgroup
+    // reads or writes them from here on (a slab of one row keeps the high part only: its low part is exactly zero)
+    if (t < C4) {
+        f32x4 h0, h1, l0, l1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h0[e] = (float)t0[e];
+            h1[e] = (float)t1[e];
+            l0[e] = (fabsf(h0[e]) <= 3.4e38f) ? (float)(t0[e] - (double)h0[e]) : 0.f;
+            l1[e] = (fabsf(h1[e]) <= 3.4e38f) ? (float)(t1[e] - (double)h1[e]) : 0.f;
+        }
+        st4(a.ws + ((size_t)b0 * 2 + 0) * a.C + t * 4, h0);
+        st4(a.ws + ((size_t)b0 * 2 + 1) * a.C + t * 4, h1);
+        if (b1 - b0 > 1) {
+            st4(a.ws + ((size_t)(b0 + 1) * 2 + 0) * a.C + t * 4, l0);
+            st4(a.ws + ((size_t)(b0 + 1) * 2 + 1) * a.C + t * 4, l1);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) {
+        a.tick[slab] = 0u;                                   // every workgroup of the slab has taken its ticket: re-arm
+        s_last = (atomicAdd(&a.tick[a.nslab], 1u) == (unsigned)(a.nslab - 1));
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (t == 0) a.tick[a.nslab] = 0u;
+    if (t >= C4) return;
+    double f0[4] = {0, 0, 0, 0}, f1[4] = {0, 0, 0, 0};
+    for (int sl = 0; sl < a.nslab; ++sl) {
+        const int r0s = sl * COLRED_SLAB;
+        const int nrow = (r0s + 1 < nblk) ? 2 : 1;
+        for (int j = 0; j < nrow; ++j) {
+            const f32x4 v0 = ld4(a.ws + ((size_t)(r0s + j) * 2 + 0) * a.C + t * 4), v1 = ld4(a.ws + ((size_t)(r0s + j) * 2 + 1) * a.C + t * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f0[e] += (double)v0[e];
+                f1[e] += (double)v1[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = t * 4 + e;
+        if constexpr (KIND == 0) {
+            const double inv = 1.0 / (double)a.P;
+            const double md = f0[e] * inv;
+            double var = f1[e] * inv - md * md;
+            if (var < 0.0) var = 0.0;
+            const float meanf = (float)((double)a.x[c] + md), varf = (float)var;
+            a.o0[c] = meanf;
+            a.o1[c] = varf;
+            if (a.mm) {
+                const float one_minus = 1.0f - a.decay;
+                const float bessel = a.P > 1 ? (float)((double)a.P / (double)(a.P - 1)) : 1.0f;
+                a.mm[c] -= (a.mm[c] - meanf) * one_minus;
+                a.mv[c] -= (a.mv[c] - varf * bessel) * one_minus;
+            }
+        } else {
+            a.o0[c] = (float)f0[e];
+            a.o1[c] = (float)f1[e];
+            if (a.acc0) {
+                a.acc0[c] += (float)f0[e];
+                a.acc1[c] += (float)f1[e];
+            }
+        }
+    }
 }
 
 // scalar fallback for C % 4 != 0 or C > 1024: one thread per channel per block-slab
@@ -167,7 +291,6 @@ __global__ void colreduce_scalar_kernel(ColArgs a) {
 // slab s = partials [s*SLAB, (s+1)*SLAB) (the last slab takes the remainder) is summed in double and written back over its own first two
 // partials as a (high, low) pair of floats, which together carry the double sum to 48 bits.  Only this workgroup ever reads those two
 // rows of its 32 channels, so there is no race; the summation order is fixed => deterministic.  The partial list is consumed.
-constexpr int COLRED_SLAB = 128;
 __global__ void __launch_bounds__(1024) colreduce_compact_kernel(float* __restrict__ ws, int nblk, int nslab, int C) {
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -285,6 +408,38 @@ int colreduce_plan(long long P, int C, int* nblk, int* rpb) {
     return 0;
 }
 
+// Ticket counters of the one-launch combine: a library-owned, zero-initialised device buffer of TICKET_SLOTS x TICKET_STRIDE counters,
+// handed out round-robin (a slot is busy for the lifetime of ONE launch and re-arms itself: two launches share a slot only if
+// TICKET_SLOTS launches are in flight at once).  Allocated at the first un-captured use (hipMalloc is not legal inside a stream
+// capture: a recording that comes first falls back to the separate combine launches).  PNP_BN_ONE_LAUNCH=0: off.
+constexpr int TICKET_SLOTS = 512, TICKET_STRIDE = 32;
+unsigned* ticket_slot(hipStream_t st, int nslab) {
+    static const int on = getenv("PNP_BN_ONE_LAUNCH") ? atoi(getenv("PNP_BN_ONE_LAUNCH")) : 1;
+    if (!on || nslab + 1 > TICKET_STRIDE) return nullptr;
+    static std::atomic<unsigned*> buf{nullptr};
+    static std::atomic<unsigned> seq{0};
+    static std::mutex mx;
+    unsigned* b = buf.load(std::memory_order_acquire);
+    if (!b) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> lk(mx);
+        b = buf.load(std::memory_order_acquire);
+        if (!b) {
+            if (hipMalloc((void**)&b, sizeof(unsigned) * TICKET_SLOTS * TICKET_STRIDE) != hipSuccess ||
+                hipMemset(b, 0, sizeof(unsigned) * TICKET_SLOTS * TICKET_STRIDE) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            buf.store(b, std::memory_order_release);
+        }
+    }
+    return b + (size_t)(seq.fetch_add(1, std::memory_order_relaxed) % TICKET_SLOTS) * TICKET_STRIDE;
+}
+
 template <int KIND>
 int run_colreduce(ColArgs a, float* o0, float* o1, void* ws, size_t ws_bytes, hipStream_t st, const char* who, float* mm = nullptr,
                   float* mv = nullptr, float decay = 0.f, float* acc0 = nullptr, float* acc1 = nullptr) {
@@ -298,7 +453,14 @@ int run_colreduce(ColArgs a, float* o0, float* o1, void* ws, size_t ws_bytes, hi
     a.ws = (float*)ws;
     a.rows_per_block = rpb;
     if ((a.C & 3) == 0 && a.C <= 1024) {
+        a.nslab = pnp_cdiv(nblk, COLRED_SLAB);
+        a.tick = ticket_slot(st, a.nslab);
+        a.o0 = o0; a.o1 = o1; a.acc0 = acc0; a.acc1 = acc1; a.mm = mm; a.mv = mv; a.decay = decay;
         hipLaunchKernelGGL(colreduce_kernel<KIND>, dim3(nblk), dim3(NT), 0, st, a);
+        if (a.tick) {
+            PNP_CHECK_LAUNCH(who);
+            return PNP_OK;
+        }
     } else {
         hipLaunchKernelGGL(colreduce_scalar_kernel<KIND>, dim3(nblk, pnp_cdiv(a.C, 64)), dim3(64), 0, st, a);
     }

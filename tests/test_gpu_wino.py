@@ -110,8 +110,9 @@ def test_winograd_fwd_dgrad_vs_float64_and_direct(dev, wino, case):
     K.wino_wgrad_mode(2)
     assert K.wino_chosen(g, 2) == wino.tile
     dw1, names3 = _ran(L, lambda: K.conv2d_wgrad(xd, dyd, g), L.PROF_CONV_WGRAD)
-    assert sorted(names3) == [n % wino.tile for n in ("wino_dy_kernel<%d>", "wino_in_kernel<%d>", "wino_wgrad_gemm_kernel<128, 128, 2, 2, %d>",
-                                                      "wino_wgrad_out_kernel<%d>")], names3
+    # (+ wino_splitsum_kernel where a narrow layer's reduction is split many ways)
+    assert sorted(n for n in names3 if n != "wino_splitsum_kernel") == [n % wino.tile for n in (
+        "wino_dy_kernel<%d>", "wino_in_kernel<%d>", "wino_wgrad_gemm_kernel<128, 128, 2, 2, %d>", "wino_wgrad_out_kernel<%d>")], names3
     held = torch.from_numpy(rng.standard_normal(w.shape).astype(np.float32)).to(dev)
     dwa = K.conv2d_wgrad(xd, dyd, g, into=held.clone())
     errs = {"y direct": _rel(y0, yo), "y wino": _rel(y1, yo), "dx direct": _rel(dx0, xg.grad), "dx wino": _rel(dx1, xg.grad),
@@ -274,4 +275,6 @@ def test_joint_steps_with_and_without_the_filter_cache(dev, wino):
     (l0, a0, s0), (l1, a1, s1) = out[False], out[True]
     print("joint steps: filter-transform cache off %s / on %s (hits, fills); losses %s" % (s0, s1, l1))
     assert s0 == (0, 0) and s1[0] > s1[1] > 0
-    assert l0 == l1 and torch.equal(a0, a1)
+    # (bit-for-bit, NaN == NaN: with the reference's stddev-.01 init and un-calibrated moving statistics the CT front's update overflows
+    # in both runs alike — what is compared here is cached against un-cached, not the health of an untrained network)
+    assert l0 == l1 and bool(((a0 == a1) | (torch.isnan(a0) & torch.isnan(a1))).all())
