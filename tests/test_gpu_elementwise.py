@@ -120,39 +120,18 @@ def test_bn_reductions_with_long_partial_lists(dev, P, C):
 
 
 def test_one_launch_combine_rearms_its_tickets(dev):
-    """round 5: the column reductions sum their partial rows inside the reduction launch (last workgroup of a slab, then last slab;
-    tickets in a library-owned counter buffer that every launch leaves zeroed).  700 launches of mixed shapes — more than the buffer has
-    slots — must each finish (outputs pre-poisoned with NaN) with bit-identical results per shape: a counter left armed would make a
-    later launch on its slot finish early (a wrong sum) or never (NaN)"""
-    K, L = pkg("kernels"), pkg("_lib")
-    import ctypes
-    lib = L.load()
-    rng = np.random.default_rng(9)
-    shapes = [(40000, 512), (16384, 64), (300, 32), (65536, 128)]            # 625 / 256 / 5 / 1024 partial rows: 5 / 2 / 1 / 8 slabs
-    data, first = {}, {}
-    for (P, C) in shapes:
-        x = torch.from_numpy((rng.standard_normal((P, C)) + 0.3).astype(np.float32)).to(dev)
-        d = torch.from_numpy(rng.standard_normal((P, C)).astype(np.float32)).to(dev)
-        data[(P, C)] = (x, d, torch.ones(C, device=dev), torch.zeros(C, device=dev))
-    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
-    for it in range(700):
-        P, C = shapes[it % len(shapes)]
-        x, d, gamma, beta = data[(P, C)]
-        mean = torch.full((C,), float("nan"), device=dev)
-        var = torch.full((C,), float("nan"), device=dev)
-        L.check(lib.pnp_bn_stats(K._p(x), K._p(mean), K._p(var), P, C, ctypes.c_void_p(ws.data_ptr()), ws.numel(), K._stream()), "pnp_bn_stats")
-        dg = torch.full((C,), float("nan"), device=dev)
-        db = torch.full((C,), float("nan"), device=dev)
-        L.check(lib.pnp_bn_bwd_reduce(K._p(d), None, K._p(x), K._p(mean), K._p(var), K._p(gamma), K._p(beta), K._p(dg), K._p(db), P, C, 1e-3, 0.2,
-                                      ctypes.c_void_p(ws.data_ptr()), ws.numel(), K._stream()), "pnp_bn_bwd_reduce")
-        got = torch.stack([mean, var, dg, db])
-        assert bool(torch.isfinite(got).all()), (it, P, C)
-        if (P, C) in first:
-            assert torch.equal(got, first[(P, C)]), (it, P, C)
-        else:
-            first[(P, C)] = got
-            x64 = x.double()
-            assert float((mean.double() - x64.mean(0)).abs().max()) < 1e-6 and float((var.double() - x64.var(0, unbiased=False)).abs().max()) < 1e-5
+    """round 5 (opt-in, PNP_BN_ONE_LAUNCH=1 — off by default: slower, profiles/r05_bn_one_launch_ab.txt): the column reductions sum their
+    partial rows inside the reduction launch (last workgroup of a slab, then last slab; tickets in a library-owned counter buffer that
+    every launch leaves zeroed).  In a process of its own with the switch on (the library reads it once): 700 launches of mixed shapes —
+    more than the buffer has slots — must each finish (outputs pre-poisoned with NaN) with bit-identical results per shape and the
+    float64 statistics: a counter left armed would make a later launch on its slot finish early (a wrong sum) or never (NaN)"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PNP_BN_ONE_LAUNCH="1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "bn_ticket_worker.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TICKETS OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_bn_statistics_of_an_overflowing_tensor_stay_infinite_not_nan(dev):
