@@ -932,10 +932,15 @@ int plan_tile(int dtype, int R, int S, int stride, int pad_mode, int dil, int pa
     static const double thr2 = env_dbl("PNP_WINOGRAD_MIN", 85.0), thr2w = env_dbl("PNP_WINOGRAD_WGRAD_MIN", 120.0);
     static const double thr4 = env_dbl("PNP_WINOGRAD4_MIN", 60.0), thr4w = env_dbl("PNP_WINOGRAD4_WGRAD_MIN", 60.0);
     static const int tmin2 = env_int("PNP_WINOGRAD_TMIN", 512), tmin4 = env_int("PNP_WINOGRAD4_TMIN", 128);
-    static const int wgmin = env_int("PNP_WINOGRAD_WGMIN", 256);
+    static const int wgmin = env_int("PNP_WINOGRAD_WGMIN", 256), c4max = env_int("PNP_WINOGRAD4_CMAX", 1024);
     const double ck = (double)C * K / ((double)C + K);
     for (int m = wino_tile_max(); m >= 2; m -= 2) {
         if (!eligible_dims(dtype, R, S, stride, pad_mode, dil, pad_t, pad_l, H, W, OH, OW, N, C, K, m)) continue;
+        // F(4x4)'s rounding error grows with the reduction length (the GEMMs accumulate in the transform domain, where the output transform's
+        // 8 x 8 coefficients meet cancelling sums): 512-channel reductions 3e-6..8e-6 of max|ref|, group_10's data gradient (2 560 channels)
+        // 1.7e-5 (teacher-forced, profiles/r05_pytest_gpu.log) — too close to the 2e-5 adoption bar: reductions over > 1 024 channels stay
+        // on F(2x2) (1e-6), at 1.80 instead of 1.39 ms for that one launch per generator step
+        if (m == 4 && !wgrad && C > c4max) continue;
         if (mode >= 2) return m;
         const WinoGeom w = make_wgeom(N, H, W, OH, OW, dil, pad_t, m);
         if (ck < (m == 4 ? (wgrad ? thr4w : thr4) : (wgrad ? thr2w : thr2)) || w.T < (m == 4 ? tmin4 : tmin2)) continue;
@@ -943,7 +948,7 @@ int plan_tile(int dtype, int R, int S, int stride, int pad_mode, int dil, int pa
         // (256 CUs) — below that the direct kernel (or F(2x2): 4x the tiles) is faster: profiles/r05_wino_thresholds.txt, B = 2 and 4 per GPU.
         // (filter gradient: its workgroup count does not depend on the tile count; the reduction is split to fill the chip)
         // Near the break-even (C K / (C + K) < 85: 128 -> 128) two rounds: g4 128->128 @32^2 0.050 / 0.058 ms against the direct 0.048 / 0.052.
-        const long long nwg = (long long)(m + 2) * (m + 2) * pnp_cdiv(w.T, 128) * pnp_cdiv(K, 128);
+        const long long nwg = (long long)(m + 2) * (m + 2) * pnp_cdiv(w.T, 128) * pnp_cdiv(K, K <= 64 ? 64 : 128);
         if (!wgrad && nwg < (ck < 85.0 ? 2 * wgmin : wgmin)) continue;
         return m;
     }
@@ -1021,15 +1026,19 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
     {
         WinoGemmArgs ga{};
         ga.V = V; ga.U = U; ga.Mm = Mm; ga.T = w.T; ga.C = a.C; ga.K = a.K;
-        ga.nblk_m = pnp_cdiv(w.T, 128); ga.nblk_n = pnp_cdiv(a.K, 128);
+        const bool narrow = a.K <= 64;                 // 64 filters: a 128 x 64 tile (a 128-wide one would be half empty)
+        ga.nblk_m = pnp_cdiv(w.T, 128); ga.nblk_n = pnp_cdiv(a.K, narrow ? 64 : 128);
         static const int xcd_mode = env_int("PNP_WINO_XCD", 2);
         ga.gn = a.gn; ga.xcd_swizzle = a.xcd_swizzle ? xcd_mode : 0;
         dim3 grid((unsigned)(ga.nblk_m * ga.nblk_n * NP));
         const double fl = 2.0 * NP * (double)w.T * a.C * a.K;
         const double by = 4.0 * NP * ((double)w.T * a.C + (double)a.C * a.K + (double)w.T * a.K);
         constexpr int KB = M == 4 ? 2 : 0;            // symbol: <.., 0 / 1> F(2x2) forward / data gradient, <.., 2 / 3> F(4x4)
-        PnpProfScope ps(cls, st, fl, by, "wino_gemm_kernel<128, 128, 2, 2, %d>", KB + (kind != 0));
-        if (kind == 0) hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, KB>), grid, dim3(NTHREADS), 0, st, ga);
+        PnpProfScope ps(cls, st, fl, by, "wino_gemm_kernel<128, %d, 2, 2, %d>", narrow ? 64 : 128, KB + (kind != 0));
+        if (narrow) {
+            if (kind == 0) hipLaunchKernelGGL((wino_gemm_kernel<128, 64, 2, 2, KB>), grid, dim3(NTHREADS), 0, st, ga);
+            else hipLaunchKernelGGL((wino_gemm_kernel<128, 64, 2, 2, KB + 1>), grid, dim3(NTHREADS), 0, st, ga);
+        } else if (kind == 0) hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, KB>), grid, dim3(NTHREADS), 0, st, ga);
         else hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, KB + 1>), grid, dim3(NTHREADS), 0, st, ga);
         PNP_CHECK_LAUNCH("wino_gemm_kernel");
     }
