@@ -933,6 +933,7 @@ int plan_tile(int dtype, int R, int S, int stride, int pad_mode, int dil, int pa
     static const double thr4 = env_dbl("PNP_WINOGRAD4_MIN", 60.0), thr4w = env_dbl("PNP_WINOGRAD4_WGRAD_MIN", 60.0);
     static const int tmin2 = env_int("PNP_WINOGRAD_TMIN", 512), tmin4 = env_int("PNP_WINOGRAD4_TMIN", 128);
     static const int wgmin = env_int("PNP_WINOGRAD_WGMIN", 256), c4max = env_int("PNP_WINOGRAD4_CMAX", 1024);
+    static const double thr4lo = env_dbl("PNP_WINOGRAD4_LOW", 32.0);
     const double ck = (double)C * K / ((double)C + K);
     for (int m = wino_tile_max(); m >= 2; m -= 2) {
         if (!eligible_dims(dtype, R, S, stride, pad_mode, dil, pad_t, pad_l, H, W, OH, OW, N, C, K, m)) continue;
@@ -943,12 +944,22 @@ int plan_tile(int dtype, int R, int S, int stride, int pad_mode, int dil, int pa
         if (m == 4 && !wgrad && C > c4max) continue;
         if (mode >= 2) return m;
         const WinoGeom w = make_wgeom(N, H, W, OH, OW, dil, pad_t, m);
-        if (ck < (m == 4 ? (wgrad ? thr4w : thr4) : (wgrad ? thr2w : thr2)) || w.T < (m == 4 ? tmin4 : tmin2)) continue;
-        // forward / data gradient: the GEMMs' workgroups (P^2 points x 128-tile blocks x 128-filter blocks) must cover the chip once
-        // (256 CUs) — below that the direct kernel (or F(2x2): 4x the tiles) is faster: profiles/r05_wino_thresholds.txt, B = 2 and 4 per GPU.
-        // (filter gradient: its workgroup count does not depend on the tile count; the reduction is split to fill the chip)
-        // Near the break-even (C K / (C + K) < 85: 128 -> 128) two rounds: g4 128->128 @32^2 0.050 / 0.058 ms against the direct 0.048 / 0.052.
+        if (w.T < (m == 4 ? tmin4 : tmin2)) continue;
         const long long nwg = (long long)(m + 2) * (m + 2) * pnp_cdiv(w.T, 128) * pnp_cdiv(K, K <= 64 ? 64 : 128);
+        const double thr = m == 4 ? (wgrad ? thr4w : thr4) : (wgrad ? thr2w : thr2);
+        if (ck < thr) {
+            // F(4x4) below its break-even, measured at B = 16 with the 128 x 64 GEMM tile (profiles/r05_wino_thresholds.txt, part 3):
+            //  * forward / data gradient of the 64-channel layers only on the large maps (>= 4 096 GEMM workgroups): cls1 64->64 @256^2
+            //    0.679 -> 0.618 / 0.665 -> 0.625 ms, cls2 64->128 @128^2 0.298 -> 0.266 / 0.300 -> 0.254; g3 64->64 @64^2 and g4 64->128 @32^2 lose
+            //  * filter gradient down to 64 -> 64 unless the maps are so large that transforming x and dy costs more than the contraction saves
+            //    (T > 32 768 tiles: cls1 64->64 @256^2 0.825 -> 0.933): cls2 64->128 0.387 -> 0.291, g3 64->64 0.114 -> 0.079, g4 64->128 0.065 -> 0.055
+            if (m != 4 || ck < thr4lo) continue;
+            if (wgrad ? w.T > 32768 : nwg < 4096) continue;
+        }
+        // forward / data gradient: the GEMMs' workgroups (P^2 points x 128-tile blocks x filter blocks) must cover the chip once (256 CUs)
+        // — below that the direct kernel (or F(2x2): 4x the tiles) is faster: profiles/r05_wino_thresholds.txt, B = 2 and 4 per GPU.
+        // Near the break-even (C K / (C + K) < 85: 128 -> 128) two rounds: g4 128->128 @32^2 0.050 / 0.058 ms against the direct 0.048 / 0.052.
+        // (filter gradient: its workgroup count does not depend on the tile count; the reduction is split to fill the chip)
         if (!wgrad && nwg < (ck < 85.0 ? 2 * wgmin : wgmin)) continue;
         return m;
     }

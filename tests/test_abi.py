@@ -269,8 +269,11 @@ def test_winograd_f4_planner_on_the_host(built):
         assert ch(geo(16, 32, 128, 256)) == (4, 4, 4)
         assert ch(geo(16, 32, 128, 128)) == (0, 0, 4)                           # C K / (C + K) = 64 >= 60, but 36 x 8 x 1 = 288 workgroups of 4 stages: only the filter gradient pays
         assert ch(geo(16, 128, 128, 128)) == (4, 4, 4)                          # the critics' 128 -> 128 at 128^2: 4 608 workgroups
-        assert ch(geo(16, 128, 64, 128)) == (0, 0, 0)                           # 42.7
-        assert ch(geo(16, 256, 64, 64)) == (0, 0, 0) and ch(geo(16, 64, 256, 256, stride=2)) == (0, 0, 0)
+        assert ch(geo(16, 128, 64, 128)) == (4, 4, 4)                           # 42.7, >= 32 on a large map: 4 608 workgroups, 16 384 tiles
+        assert ch(geo(16, 32, 64, 128)) == (0, 0, 4)                            # the same layer at 32^2 (288 workgroups): only its filter gradient
+        assert ch(geo(16, 256, 64, 64)) == (4, 4, 0)                            # cls1 64 -> 64 @256^2: 128 x 64 GEMM tiles; 65 536 tiles: filter gradient direct
+        assert ch(geo(16, 64, 64, 64)) == (0, 0, 4) and ch(geo(16, 256, 32, 64)) == (0, 0, 0)        # 64 -> 64 @64^2; 32 -> 64 (21.3)
+        assert ch(geo(16, 64, 256, 256, stride=2)) == (0, 0, 0)
         assert ch(geo(16, 32, 512, 512, dt=L.DTYPE_BF16)) == (0, 0, 0)
         assert ch(geo(2, 32, 512, 512)) == (2, 2, 4)                            # B = 2 per GPU: 36 x 1 x 4 = 144 workgroups do not cover the chip -> F(2x2) (16 x 4 x 4 = 256); filter gradient F(4x4)
         assert ch(geo(4, 32, 512, 512)) == (4, 4, 4) and ch(geo(2, 34, 512, 2560, pad="VALID")) == (4, 2, 4) and ch(geo(2, 32, 256, 256)) == (0, 0, 4)
