@@ -486,7 +486,7 @@ def main():
     # BASELINE configs[4] arithmetic (bf16 MFMA operands, fp32 accumulation / master weights / BN) on the headline workload, as a
     # sub-record of the driver's own line: same step definition, 2 warm-up + 10 timed steps
     sub_bf16 = None
-    if not args.no_sub and args.dtype == "f32" and args.workload == "joint":
+    if not args.no_sub and args.dtype == "f32" and args.workload == "joint" and world == 1:      # (N = 1 only: the scaling runs stay what they were)
         Fn.set_conv_dtype("bf16")
         try:
             nb = 10

@@ -272,7 +272,7 @@ def weights_changed(ranges=None):
         _filter_cache.clear()
     if _u_cache:
         lib = _lib.load()
-        if ranges is None and len(_u_cache) > 512 and not PINNED[0]:     # buffers of stores that no longer exist (test suites): start over
+        if ranges is None and len(_u_cache) > 4096 and not PINNED[0]:    # buffers of stores that no longer exist (test suites): start over
             wino_u_cache_clear()
         elif ranges is None:
             lib.pnp_weights_changed(None, None)
