@@ -334,8 +334,9 @@ int pnp_fill(float* p, size_t n, float value, void* stream);
  * (nullable) receive the same values rounded to bf16 (nearest-even) from the same epilogue.  Arithmetic: exactly "both operands of
  * every product rounded to bf16, products summed in fp32" — what PNP_DTYPE_BF16 means for the staged-rounding kernels too.
  * pnp_conv2d_bf16r_served(g, kind) (kind 0 forward, 1 data gradient): 1 when these kernels serve the geometry (zero padding, 3x3 /
- * forward 5x5, reduction channels % 32 == 0, output channels % 64 == 0, >= 4096 output pixels, stride-1 data gradients); everything
- * else stays on the fp32-storage entry points above. */
+ * forward 5x5, reduction channels % 32 == 0, output channels % 64 == 0, >= 4096 output pixels; data gradients of stride 1 directly, of
+ * strided layers one launch per stride phase with the phase's sub-filter read out of the full shadow); everything else stays on the
+ * fp32-storage entry points above. */
 int pnp_cast_bf16(const float* x, void* y_bf16, size_t n, void* stream);
 int pnp_filter_bf16(const float* w, void* w_io /*nullable*/, void* w_oi /*nullable*/, int32_t R, int32_t S, int32_t C, int32_t K,
                     void* stream);

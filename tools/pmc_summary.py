@@ -93,7 +93,8 @@ def main():
                     e[name + "_avg"] = round(avg(s[name]), 1)
         kernels[k] = e
     with open(out, "w") as fh:
-        json.dump({"note": NOTE, "kernels": kernels}, fh, indent=1)
+        note = NOTE + ("  " + os.environ["PMC_NOTE"] if os.environ.get("PMC_NOTE") else "")
+        json.dump({"note": note, "kernels": kernels}, fh, indent=1)
     print("wrote %s (%d kernels)" % (out, len(kernels)))
 
 
