@@ -36,6 +36,8 @@ for sc in weak strong; do
   bt=2; [ $sc = strong ] && bt=16
   PNP_DIST_BACKEND=gloo PNP_SAME_DEVICE=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 8 --batch $bt --steps 2 --warmup 1 --no-cpu-baseline --scaling $sc > $O/dp8_same_device_$sc.json 2> $O/dp8_same_device_$sc.err; echo "dp8 $sc rc=$?"; tail -c 300 $O/dp8_same_device_$sc.json
 done
+# per-GPU batch sweep (strong-scaling operating points): eager / captured wall time against the sum of kernel durations, launches per step
+R=$R bash tools/batch_sweep.sh f32 > $O/batch_sweep.log 2>&1; tail -8 $O/batch_sweep.log
 fi
 if [[ $PART == *B* ]]; then
 timeout 1150 python -m pytest tests -m gpu -q -s --durations=15 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
