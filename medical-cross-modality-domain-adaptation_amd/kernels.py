@@ -144,11 +144,28 @@ U_CACHE = os.environ.get("PNP_WINOGRAD_UCACHE", "1") != "0"
 _u_cache = {}
 
 
+def _u_drop(key, ref=None):
+    """withdraw the binding of `key` (its filter tensor died, or an ad-hoc filter now sits on its address)"""
+    ent = _u_cache.get(key)
+    if ent is None or (ref is not None and ent[0] is not ref):
+        return
+    del _u_cache[key]
+    if ent[1] is not None:
+        try:
+            _lib.load().pnp_conv2d_wino_filter_bind(ctypes.c_void_p(key[0]), int(key[1]), None, 0)
+        except Exception:          # interpreter shutdown: the library may be gone already
+            pass
+
+
 def _wino_u(w, g, kind):
-    if not U_CACHE or not getattr(w, "_pnp_var", False):
+    if not U_CACHE:
         return
     key = (w.data_ptr(), kind)
     ent = _u_cache.get(key)
+    if not getattr(w, "_pnp_var", False):
+        if ent is not None:                  # an ad-hoc filter on the address of a cached one: the library must not serve the old U
+            _u_drop(key)
+        return
     if ent is not None and ent[0]() is w:
         if ent[2] != w._version:             # written by a torch op since the entry was filled
             if ent[1] is not None:
@@ -156,6 +173,8 @@ def _wino_u(w, g, kind):
             ent[2] = w._version
         return
     lib = _lib.load()
+    if ent is not None:
+        _u_drop(key)
     U = None
     if g.R == 3 and g.S == 3 and wino_chosen(g, kind):          # (decided once per filter and pass: a later policy change runs un-cached)
         nbytes = int(lib.pnp_conv2d_wino_filter_bytes(int(w.shape[2]), int(w.shape[3])))
@@ -163,9 +182,9 @@ def _wino_u(w, g, kind):
             U = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
             check(lib.pnp_conv2d_wino_filter_bind(ctypes.c_void_p(w.data_ptr()), int(kind), ctypes.c_void_p(U.data_ptr()), nbytes),
                   "pnp_conv2d_wino_filter_bind")
-    if ent is not None and ent[1] is not None and U is None:
-        lib.pnp_conv2d_wino_filter_bind(ctypes.c_void_p(w.data_ptr()), int(kind), None, 0)
-    _u_cache[key] = [weakref.ref(w), U, w._version]
+    # the binding goes when the tensor object does (CPython frees it, and with it the arena it may keep alive, deterministically): nothing
+    # allocated later on the same address can meet a valid entry
+    _u_cache[key] = [weakref.ref(w, lambda r, k=key: _u_drop(k, r)), U, w._version]
 
 
 def wino_u_cache_clear():

@@ -238,6 +238,18 @@ def test_transformed_filter_cache(dev, wino):
     K.wino_u_cache_stats(reset=True)
     K.weights_changed()                                                              # everything
     assert torch.equal(K.conv2d_fwd(x, w, g), y_ref) and K.wino_u_cache_stats(reset=True)[1] == 1
+    # a binding goes when its filter tensor does: an ad-hoc filter that lands on the recycled address (the caching allocator hands the
+    # block straight back) is transformed afresh — never served the dead filter's U
+    addr = w.data_ptr()
+    del w
+    assert not any(k[0] == addr for k in K._u_cache)
+    w3 = torch.from_numpy((rng.standard_normal((3, 3, C, Kf)) * 0.05).astype(np.float32)).to(dev)
+    y3 = K.conv2d_fwd(x, w3, g)
+    wino(0)
+    y3d = K.conv2d_fwd(x, w3, g)
+    wino(2)
+    print("recycled address: %s; new filter on the route vs direct %.2e" % (w3.data_ptr() == addr, _rel(y3, y3d)))
+    assert K.wino_u_cache_stats(reset=True) == (0, 0) and _rel(y3, y3d) < BAR
     K.wino_u_cache_clear()
 
 
