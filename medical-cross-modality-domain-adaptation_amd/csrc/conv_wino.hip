@@ -271,6 +271,8 @@ struct WinoGemmArgs {
     float* Mm;
     int T, C, K;
     int nblk_m, nblk_n, gn, xcd_swizzle;
+    int npos;        // transform points (16 / 36)
+    int whole;       // V and U of ALL points fit 31-bit byte offsets: one buffer descriptor per operand for the launch (needed for > 1 tile per workgroup)
 };
 
 template <int BM, int BN, int WM, int WN, int KIND>
@@ -286,46 +288,56 @@ __global__ void __launch_bounds__(NTHREADS, 2) wino_gemm_kernel(WinoGemmArgs g) 
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nblk = g.nblk_m * g.nblk_n;
-    // xcd_swizzle 2: consecutive logical ids over the WHOLE grid land on one XCD, i.e. an XCD works through whole transform points: U[pos]
-    // and V[pos] come into ONE L2 (round 4's mapping, 1 = within a point, gave every XCD one pixel tile of every point: each of the 8
-    // L2s read all of U — counter figure 380 MB per 512->512 launch against 113 MB of operands, profiles/r05_pmc_counters_layer512.json)
-    const int gid = g.xcd_swizzle >= 2 ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    const int pos = gid / nblk;
-    int bid = gid - pos * nblk;
-    if (g.xcd_swizzle == 1) bid = xcd_remap(bid, nblk);
-    int mt, nt;
-    tile_coords(bid, g.nblk_m, g.nblk_n, g.gn, mt, nt);
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
-
-    const float* Ap = g.V + (size_t)pos * g.T * g.C;
-    const float* Bp = g.U + (size_t)pos * g.C * g.K;
-    float* Op = g.Mm + (size_t)pos * g.T * g.K;
-
-    const int kg = t & 7, mrow = t >> 3;
-    unsigned abase[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int m = m0 + mrow + 32 * i;
-        abase[i] = (m < g.T) ? (unsigned)((m * g.C + 4 * kg) * 4) : OOB2;
+    const int ntiles = nblk * g.npos;
+    // Which tiles this workgroup works through.  Hardware places workgroup b on XCD b % 8; with xcd_swizzle every XCD owns a CONTIGUOUS
+    // range of the logical tile ids (xcd_remap's partition), i.e. whole transform points: U[pos] and V[pos] come into ONE L2 (round 4's
+    // mapping gave every XCD one pixel tile of every point and each of the 8 L2s read all of U — counter figure 380 MB per 512->512 launch
+    // against 113 MB of operands, profiles/r05_pmc_counters_layer512_before_xcd.json).  Round 5, second half: the launch is PERSISTENT when
+    // there are more tiles than workgroup slots (grid = 512 = 2 per CU): workgroup j of an XCD takes tiles j, j + 64, j + 128 ... of its
+    // XCD's range and carries the software pipeline ACROSS tiles — the last stage of a tile fetches the first stage of the next one, so a
+    // workgroup leaves its main loop only for the stores of a finished tile (a 16-stage tile used to pay ~2 stages of launch + first-load
+    // latency + epilogue, during which the co-resident workgroup alone cannot keep the matrix pipe busy).
+    int base = 0, cnt = ntiles, first = (int)blockIdx.x, step = (int)gridDim.x;
+    if (g.xcd_swizzle) {
+        const int NX = 8, x = (int)blockIdx.x % NX, q = ntiles / NX, r = ntiles % NX;
+        base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        cnt = q + (x < r ? 1 : 0);
+        first = (int)blockIdx.x / NX;
+        step = ((int)gridDim.x - x + NX - 1) / NX;
     }
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+    const int kg = t & 7, mrow = t >> 3;
     const int bcol = t % C4, brow = t / C4;
-    unsigned boff[NPB];
-#pragma unroll
-    for (int i = 0; i < NPB; ++i)
-        boff[i] = (n0 + 4 * bcol < g.K) ? (unsigned)(((brow + RPB * i) * g.K + n0 + 4 * bcol) * 4) : OOB2;
+    // ONE descriptor per operand for the whole launch when all transform points fit 31-bit byte offsets (g.whole: the host checks), the
+    // point's plane offset inside the per-row offsets; else (one tile per workgroup only) a descriptor per point
+    const size_t planeV = (size_t)g.T * g.C, planeU = (size_t)g.C * g.K;
 
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(Ap, (unsigned)((size_t)g.T * g.C * 4));
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(Bp, (unsigned)((size_t)g.C * g.K * 4));
-    f32x4 areg[NR], breg[NPB];
-    auto gload = [&](int cc) {
-        const int sa = cc * (BK * 4);
-        const int sb = (cc * BK * g.K) * 4;
+    // row / column byte offsets of tile `gid` (out of range: OOB2 — reads return 0)
+    auto setup = [&](int gid, unsigned* ab, unsigned* bo, int& pos, int& m0, int& n0) {
+        pos = gid / nblk;
+        int mt, nt;
+        tile_coords(gid - pos * nblk, g.nblk_m, g.nblk_n, g.gn, mt, nt);
+        m0 = mt * BM;
+        n0 = nt * BN;
+        const unsigned pv = g.whole ? (unsigned)(pos * planeV) : 0u, pu = g.whole ? (unsigned)(pos * planeU) : 0u;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) areg[i] = bload4s(rx, abase[i], sa);
+        for (int i = 0; i < NR; ++i) {
+            const int m = m0 + mrow + 32 * i;
+            ab[i] = (m < g.T) ? (pv + (unsigned)(m * g.C + 4 * kg)) * 4u : OOB2;
+        }
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) breg[i] = bload4s(rw, boff[i], sb);
+        for (int i = 0; i < NPB; ++i)
+            bo[i] = (n0 + 4 * bcol < g.K) ? (pu + (unsigned)((brow + RPB * i) * g.K + n0 + 4 * bcol)) * 4u : OOB2;
     };
+
+    unsigned abase[NR], boff[NPB], abase_n[NR], boff_n[NPB];
+    int pos, m0, n0, pos_n = 0, m0_n = 0, n0_n = 0;
+    if (first >= cnt) return;
+    setup(base + first, abase, boff, pos, m0, n0);
+    const __amdgpu_buffer_rsrc_t rx = g.whole ? make_rsrc(g.V, (unsigned)(planeV * g.npos * 4)) : make_rsrc(g.V + (size_t)pos * planeV, (unsigned)(planeV * 4));
+    const __amdgpu_buffer_rsrc_t rw = g.whole ? make_rsrc(g.U, (unsigned)(planeU * g.npos * 4)) : make_rsrc(g.U + (size_t)pos * planeU, (unsigned)(planeU * 4));
+
+    f32x4 areg[NR], breg[NPB];
     auto lstore = [&](float* An, float* Bn) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) *reinterpret_cast<f32x4*>(An + (mrow + 32 * i) * LDA + 4 * kg) = areg[i];
@@ -336,44 +348,70 @@ __global__ void __launch_bounds__(NTHREADS, 2) wino_gemm_kernel(WinoGemmArgs g) 
     Acc<TM, TN> acc;
     acc.zero();
     const int ncc = g.C / BK;
+    ConvArgs e{};            // plain [T][K] rows of a transform point: conv_epilogue with every feature off
+    e.M = g.T;
+    e.K = g.K;
+    e.nsplit = 1;
 
-    gload(0);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) areg[i] = bload4s(rx, abase[i], 0);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) breg[i] = bload4s(rw, boff[i], 0);
     lstore(lds, lds + 2 * ASZ);
     __syncthreads();
     Frag<TM, TN, true, LDA, LDB> f0, f1;
     f0.load(lds, lds + 2 * ASZ, 0, wm0, wn0, lane);
-    for (int cc = 0; cc < ncc; ++cc) {
-        const int cur = cc & 1;
-        const float* As = lds + cur * ASZ;
-        const float* Bs = lds + 2 * ASZ + cur * BSZ;
-        float* An = lds + (cur ^ 1) * ASZ;
-        float* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
-        const int nxt = (cc + 1 < ncc) ? cc + 1 : cc;        // past the end: the last group again (valid addresses, a buffer nobody reads)
-        // ---- slice 0
-        f1.load(As, Bs, 1, wm0, wn0, lane);
-        gload(nxt);
-        f0.mma(acc);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    int sidx = 0;            // stages done by this workgroup: the LDS double buffer alternates across tile boundaries too
+    for (int local = first; local < cnt; local += step) {
+        const bool more = local + step < cnt;
+        if (more) setup(base + local + step, abase_n, boff_n, pos_n, m0_n, n0_n);
+        else {
 #pragma unroll
-        for (int i = 0; i < 4 * TM * TN; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            for (int i = 0; i < NR; ++i) abase_n[i] = OOB2;
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) boff_n[i] = OOB2;
         }
-        PNP_SCHED_FENCE();
-        PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
-        PNP_SLICE2(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), lstore(An, Bn), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
-        PNP_LAST_SLICE(f1.mma(acc), lstore(An, Bn), 4 * TM * TN)
-        __syncthreads();
-        f0.load(An, Bn, 0, wm0, wn0, lane);
+        for (int cc = 0; cc < ncc; ++cc, ++sidx) {
+            const int cur = sidx & 1;
+            const float* As = lds + cur * ASZ;
+            const float* Bs = lds + 2 * ASZ + cur * BSZ;
+            float* An = lds + (cur ^ 1) * ASZ;
+            float* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
+            // the stage fetched under this one: the next reduction group of this tile, or — under the last stage — group 0 of the NEXT tile
+            // (no next tile: out-of-range offsets, the loads return zeros into a buffer nobody reads)
+            const bool lastst = cc + 1 >= ncc;
+            const int sa = lastst ? 0 : (cc + 1) * (BK * 4);
+            const int sb = lastst ? 0 : ((cc + 1) * BK * g.K) * 4;
+            // ---- slice 0
+            f1.load(As, Bs, 1, wm0, wn0, lane);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) areg[i] = bload4s(rx, lastst ? abase_n[i] : abase[i], sa);
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) breg[i] = bload4s(rw, lastst ? boff_n[i] : boff[i], sb);
+            f0.mma(acc);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i = 0; i < 4 * TM * TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            PNP_SCHED_FENCE();
+            PNP_SLICE(f0.load(As, Bs, 2, wm0, wn0, lane), f1.mma(acc), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
+            PNP_SLICE2(f1.load(As, Bs, 3, wm0, wn0, lane), f0.mma(acc), lstore(An, Bn), 4 * TM * TN, (TM + 4 * TN + 4 * TM * TN - 1) / (4 * TM * TN))
+            PNP_LAST_SLICE(f1.mma(acc), lstore(An, Bn), 4 * TM * TN)
+            __syncthreads();
+            f0.load(An, Bn, 0, wm0, wn0, lane);
+        }
+        conv_epilogue<TM, TN>(e, acc, g.Mm + (size_t)pos * g.T * g.K, m0, n0, wm0, wn0, lane, 0);
+        if (!more) break;
+        acc.zero();
+#pragma unroll
+        for (int i = 0; i < NR; ++i) abase[i] = abase_n[i];
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) boff[i] = boff_n[i];
+        pos = pos_n; m0 = m0_n; n0 = n0_n;
     }
-
-    // plain [T][K] rows of this transform point: conv_epilogue with every feature off
-    ConvArgs e{};
-    e.M = g.T;
-    e.K = g.K;
-    e.nsplit = 1;
-    conv_epilogue<TM, TN>(e, acc, Op, m0, n0, wm0, wn0, lane, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1039,9 +1077,13 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
         ga.V = V; ga.U = U; ga.Mm = Mm; ga.T = w.T; ga.C = a.C; ga.K = a.K;
         const bool narrow = a.K <= 64;                 // 64 filters: a 128 x 64 tile (a 128-wide one would be half empty)
         ga.nblk_m = pnp_cdiv(w.T, 128); ga.nblk_n = pnp_cdiv(a.K, narrow ? 64 : 128);
-        static const int xcd_mode = env_int("PNP_WINO_XCD", 2);
-        ga.gn = a.gn; ga.xcd_swizzle = a.xcd_swizzle ? xcd_mode : 0;
-        dim3 grid((unsigned)(ga.nblk_m * ga.nblk_n * NP));
+        static const int xcd_mode = env_int("PNP_WINO_XCD", 2), persist = env_int("PNP_WINO_PERSIST", 1);
+        ga.gn = a.gn; ga.xcd_swizzle = (a.xcd_swizzle && xcd_mode) ? 2 : 0;
+        ga.npos = NP;
+        const long long ntiles = (long long)ga.nblk_m * ga.nblk_n * NP;
+        ga.whole = ((double)NP * w.T * a.C * 4.0 < 2147483648.0 && (double)NP * a.C * a.K * 4.0 < 2147483648.0) ? 1 : 0;
+        // persistent launch (2 workgroups per CU work through the tiles, pipelined across tile boundaries) when there are more tiles than slots
+        dim3 grid((unsigned)((persist && ga.whole && ntiles > 512) ? 512 : ntiles));
         const double fl = 2.0 * NP * (double)w.T * a.C * a.K;
         const double by = 4.0 * NP * ((double)w.T * a.C + (double)a.C * a.K + (double)w.T * a.K);
         constexpr int KB = M == 4 ? 2 : 0;            // symbol: <.., 0 / 1> F(2x2) forward / data gradient, <.., 2 / 3> F(4x4)
