@@ -273,6 +273,18 @@ struct WinoGemmArgs {
     int nblk_m, nblk_n, gn, xcd_swizzle;
     int npos;        // transform points (16 / 36)
     int whole;       // V and U of ALL points fit 31-bit byte offsets: one buffer descriptor per operand for the launch (needed for > 1 tile per workgroup)
+    // tail split of a persistent launch (GemmPlan): every XCD owns P tiles; its 64 workgroups take the first F = 64 * floor(P / 64) as whole
+    // tiles, the remaining R = P - F tiles are cut into s pieces of the reduction each (R s <= 64: one piece per workgroup), piece 0 goes to
+    // M like a whole tile, pieces 1 .. s-1 to Px[((xcd R + tail tile) (s - 1) + piece - 1)][BM][BN]; the output transform sums them
+    int tail_F, tail_R, tail_s;
+    float* Px;
+};
+
+// The plan of one GEMM launch of the route, shared by the workspace query, the launch and the output transform.
+struct GemmPlan {
+    int grid;                 // workgroups
+    int P, F, R, s;           // per XCD: tiles, whole-round tiles, tail tiles, pieces per tail tile (s == 1: no split)
+    size_t px_bytes;          // partial products of the pieces 1 .. s-1
 };
 
 template <int BM, int BN, int WM, int WN, int KIND>
@@ -333,6 +345,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) wino_gemm_kernel(WinoGemmArgs g) 
     unsigned abase[NR], boff[NPB], abase_n[NR], boff_n[NPB];
     int pos, m0, n0, pos_n = 0, m0_n = 0, n0_n = 0;
     if (first >= cnt) return;
+    const int ncc = g.C / BK;
+    // the items of this workgroup: whole tiles first, local, local + step, ... (below `whole_end`), then at most one item of the tail
+    // (tail_s > 1: piece `first / tail_R` of tail tile `first % tail_R`, ncc / tail_s stages; else the whole tail tile `first`)
+    const int split = (g.tail_s > 1) ? g.tail_s : 1;
+    const int whole_end = (split > 1) ? g.tail_F : cnt;
+    const bool has_tail = split > 1 && first < g.tail_R * split;
+    const int tail_tile = has_tail ? g.tail_F + first % g.tail_R : 0, tail_piece = has_tail ? first / g.tail_R : 0;
+    const int cpp = ncc / split;                       // stages of a piece
     setup(base + first, abase, boff, pos, m0, n0);
     const __amdgpu_buffer_rsrc_t rx = g.whole ? make_rsrc(g.V, (unsigned)(planeV * g.npos * 4)) : make_rsrc(g.V + (size_t)pos * planeV, (unsigned)(planeV * 4));
     const __amdgpu_buffer_rsrc_t rw = g.whole ? make_rsrc(g.U, (unsigned)(planeU * g.npos * 4)) : make_rsrc(g.U + (size_t)pos * planeU, (unsigned)(planeU * 4));
@@ -347,7 +367,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) wino_gemm_kernel(WinoGemmArgs g) 
 
     Acc<TM, TN> acc;
     acc.zero();
-    const int ncc = g.C / BK;
     ConvArgs e{};            // plain [T][K] rows of a transform point: conv_epilogue with every feature off
     e.M = g.T;
     e.K = g.K;
@@ -362,26 +381,37 @@ __global__ void __launch_bounds__(NTHREADS, 2) wino_gemm_kernel(WinoGemmArgs g) 
     Frag<TM, TN, true, LDA, LDB> f0, f1;
     f0.load(lds, lds + 2 * ASZ, 0, wm0, wn0, lane);
     int sidx = 0;            // stages done by this workgroup: the LDS double buffer alternates across tile boundaries too
-    for (int local = first; local < cnt; local += step) {
-        const bool more = local + step < cnt;
-        if (more) setup(base + local + step, abase_n, boff_n, pos_n, m0_n, n0_n);
-        else {
+    int local = first;
+    bool in_tail = false;    // the current item is this workgroup's piece of a tail tile
+    for (;;) {
+        // the item after this one: the next whole tile, else the tail item, else nothing
+        const int nl = local + step;
+        const bool next_whole = !in_tail && nl < whole_end;
+        const bool next_tail = !in_tail && !next_whole && has_tail;
+        const bool more = next_whole || next_tail;
+        int cc0_n = 0;
+        if (more) {
+            setup(base + (next_whole ? nl : tail_tile), abase_n, boff_n, pos_n, m0_n, n0_n);
+            cc0_n = next_tail ? tail_piece * cpp : 0;
+        } else {
 #pragma unroll
             for (int i = 0; i < NR; ++i) abase_n[i] = OOB2;
 #pragma unroll
             for (int i = 0; i < NPB; ++i) boff_n[i] = OOB2;
         }
-        for (int cc = 0; cc < ncc; ++cc, ++sidx) {
+        const int cc_begin = in_tail ? tail_piece * cpp : 0, cc_end = in_tail ? cc_begin + cpp : ncc;
+        for (int cc = cc_begin; cc < cc_end; ++cc, ++sidx) {
             const int cur = sidx & 1;
             const float* As = lds + cur * ASZ;
             const float* Bs = lds + 2 * ASZ + cur * BSZ;
             float* An = lds + (cur ^ 1) * ASZ;
             float* Bn = lds + 2 * ASZ + (cur ^ 1) * BSZ;
-            // the stage fetched under this one: the next reduction group of this tile, or — under the last stage — group 0 of the NEXT tile
-            // (no next tile: out-of-range offsets, the loads return zeros into a buffer nobody reads)
-            const bool lastst = cc + 1 >= ncc;
-            const int sa = lastst ? 0 : (cc + 1) * (BK * 4);
-            const int sb = lastst ? 0 : ((cc + 1) * BK * g.K) * 4;
+            // the stage fetched under this one: the next reduction group of this item, or — under its last stage — the first group of the
+            // NEXT item (no next item: out-of-range offsets, the loads return zeros into a buffer nobody reads)
+            const bool lastst = cc + 1 >= cc_end;
+            const int cn = lastst ? cc0_n : cc + 1;
+            const int sa = cn * (BK * 4);
+            const int sb = (cn * BK * g.K) * 4;
             // ---- slice 0
             f1.load(As, Bs, 1, wm0, wn0, lane);
 #pragma unroll
@@ -403,7 +433,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) wino_gemm_kernel(WinoGemmArgs g) 
             __syncthreads();
             f0.load(An, Bn, 0, wm0, wn0, lane);
         }
-        conv_epilogue<TM, TN>(e, acc, g.Mm + (size_t)pos * g.T * g.K, m0, n0, wm0, wn0, lane, 0);
+        if (in_tail && tail_piece > 0) {
+            // a later piece of a split tile: its partial product as a dense [BM][BN] tile of Px (rows past T are not written, columns past K
+            // are never read)
+            const int x = g.xcd_swizzle ? (int)blockIdx.x % 8 : 0;
+            ConvArgs ep{};
+            ep.M = (g.T - m0 < BM) ? g.T - m0 : BM;
+            ep.K = BN;
+            ep.nsplit = 1;
+            float* dst = g.Px + ((size_t)(x * g.tail_R + (tail_tile - g.tail_F)) * (split - 1) + (tail_piece - 1)) * (BM * BN);
+            conv_epilogue<TM, TN>(ep, acc, dst, 0, 0, wm0, wn0, lane, 0);
+        } else {
+            conv_epilogue<TM, TN>(e, acc, g.Mm + (size_t)pos * g.T * g.K, m0, n0, wm0, wn0, lane, 0);
+        }
         if (!more) break;
         acc.zero();
 #pragma unroll
@@ -411,6 +453,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) wino_gemm_kernel(WinoGemmArgs g) 
 #pragma unroll
         for (int i = 0; i < NPB; ++i) boff[i] = boff_n[i];
         pos = pos_n; m0 = m0_n; n0 = n0_n;
+        if (next_tail) in_tail = true;
+        else local = nl;
     }
 }
 
@@ -439,6 +483,11 @@ struct WinoOutArgs {
     const float* ep_res;
     int ep_cs;
     float ep_alpha;
+    // tail split of the GEMM launch that produced Mm (GemmPlan; tail_s <= 1: none): tile (row block, filter block) of point pos has logical
+    // id pos nblk + tile_index; ids are dealt to the 8 XCDs in contiguous ranges of tail_P; within a range the ids >= tail_F were cut into
+    // tail_s pieces whose partial products 1 .. tail_s-1 sit in Px as dense [128][tail_bn] tiles
+    const float* Px;
+    int tail_P, tail_F, tail_R, tail_s, tail_bn, nblk_m, nblk_n, gn;
 };
 
 template <int M>
@@ -477,6 +526,35 @@ __global__ void __launch_bounds__(NT) wino_out_kernel(WinoOutArgs a) {
             for (int p = 0; p < P; ++p)
 #pragma unroll
                 for (int q = 0; q < P; ++q) m[p][q] = ld4(src + (size_t)(P * p + q) * plane);
+            if (a.tail_s > 1) {
+                // which of this (row block, filter block)'s P^2 tiles were split: inverse of tile_coords, then the id walks the XCD ranges
+                const int mt = t >> 7, nt = k / a.tail_bn;
+                int bid;
+                if (a.gn <= 0 || a.gn >= a.nblk_n) bid = mt * a.nblk_n + nt;
+                else {
+                    const int sc = nt / a.gn, left = a.nblk_n - sc * a.gn;
+                    const int width = left < a.gn ? left : a.gn;
+                    bid = sc * (a.nblk_m * a.gn) + mt * width + (nt - sc * a.gn);
+                }
+                const int nblk = a.nblk_m * a.nblk_n;
+                int x = bid / a.tail_P, local = bid - x * a.tail_P;
+                const size_t tsz = (size_t)128 * a.tail_bn;
+                const size_t inner = (size_t)(t & 127) * a.tail_bn + (k - nt * a.tail_bn);
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        if (local >= a.tail_F) {
+                            const float* px = a.Px + (size_t)(x * a.tail_R + local - a.tail_F) * (a.tail_s - 1) * tsz + inner;
+                            for (int pc = 0; pc < a.tail_s - 1; ++pc) m[p][q] += ld4(px + pc * tsz);      // fixed order: deterministic
+                        }
+                        local += nblk;
+                        if (local >= a.tail_P) {
+                            local -= a.tail_P;
+                            ++x;
+                        }
+                    }
+            }
             // rows (A^T m), then columns ((A^T m) A)
             f32x4 o[M][M];
             if constexpr (M == 2) {
@@ -1022,9 +1100,38 @@ bool wino_eligible(const pnp_conv_geom* g) {
 int wino_tile(const pnp_conv_geom* g) { return plan_tile(g, false); }
 bool wino_chosen(const pnp_conv_geom* g) { return plan_tile(g, false) != 0; }
 
+// One plan per GEMM launch of forward / data gradient, shared by the workspace query, the launch and the output transform.
+// Persistent (grid = 512 = 2 workgroups per CU, 64 per XCD) when there are more tiles than slots and every transform point fits 31-bit
+// offsets.  Tail split: an XCD's P tiles are F = 64 floor(P / 64) whole rounds + R tail tiles; without a split R of the 64 workgroups
+// run one tile more than the rest (512->512 at B = 16: P = 144 = 2 rounds + 16, i.e. a makespan of 3 tiles for 2.25 tiles of work per
+// workgroup); cutting each tail tile into s pieces of the reduction (s R <= 64, >= 2 stages per piece) hands every workgroup 1 / s of a tile
+// instead.  Pieces 1 .. s-1 leave their partial products in Px, summed by the output transform in a fixed order.
+static GemmPlan gemm_plan(int T, int C, int K, int NP, bool xcd) {
+    static const int persist = env_int("PNP_WINO_PERSIST", 1), split_on = env_int("PNP_WINO_TAILSPLIT", 1);
+    GemmPlan p{};
+    const int bn = K <= 64 ? 64 : 128;
+    const long long ntiles = (long long)NP * pnp_cdiv(T, 128) * pnp_cdiv(K, bn);
+    const bool whole = (double)NP * T * C * 4.0 < 2147483648.0 && (double)NP * C * K * 4.0 < 2147483648.0;
+    p.grid = (int)ntiles;
+    p.P = (int)ntiles; p.F = (int)ntiles; p.R = 0; p.s = 1; p.px_bytes = 0;
+    if (!(persist && whole && ntiles > 512)) return p;
+    p.grid = 512;
+    if (!(xcd && split_on) || (ntiles % 8) != 0) return p;
+    const int P = (int)(ntiles / 8), F = (P / 64) * 64, R = P - F, ncc = C / BK;
+    p.P = P; p.F = F; p.R = R;
+    if (R == 0) return p;
+    for (int c = 8; c >= 2; c >>= 1)
+        if (c * R <= 64 && (ncc % c) == 0 && ncc / c >= 2) {
+            p.s = c;
+            break;
+        }
+    if (p.s > 1) p.px_bytes = al256((size_t)8 * R * (p.s - 1) * 128 * bn * 4);
+    return p;
+}
+
 static size_t fwd_ws_bytes(const WinoGeom& w, int C, int K) {
     const size_t np = (size_t)(w.m + 2) * (w.m + 2);
-    return al256(np * C * K * 4) + al256(np * w.T * C * 4) + al256(np * w.T * K * 4);
+    return al256(np * C * K * 4) + al256(np * w.T * C * 4) + al256(np * w.T * K * 4) + gemm_plan(w.T, C, K, (int)np, true).px_bytes;
 }
 
 size_t wino_workspace_bytes(const pnp_conv_geom* g) {
@@ -1045,8 +1152,11 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
     constexpr int NP = (M + 2) * (M + 2);
     const WinoGeom w = make_wgeom(a.N, a.H, a.W, a.OH, a.OW, a.dil, a.pad_t, M);
     const size_t ub = al256((size_t)NP * a.C * a.K * 4), vb = al256((size_t)NP * w.T * a.C * 4), mb = al256((size_t)NP * w.T * a.K * 4);
-    if (!ws || ws_bytes < ub + vb + mb) {
-        pnp_set_error("launch_wino: workspace too small (%zu < %zu)", ws_bytes, ub + vb + mb);
+    static const int xcd_mode = env_int("PNP_WINO_XCD", 2);
+    const bool xcd = a.xcd_swizzle && xcd_mode;
+    const GemmPlan plan = gemm_plan(w.T, a.C, a.K, NP, xcd);
+    if (!ws || ws_bytes < ub + vb + mb + plan.px_bytes) {
+        pnp_set_error("launch_wino: workspace too small (%zu < %zu)", ws_bytes, ub + vb + mb + plan.px_bytes);
         return PNP_EWORKSPACE;
     }
     PNP_REQUIRE(a.y_h == nullptr && a.o_s == 0 && a.ups == 1, "launch_wino: unsupported epilogue");
@@ -1054,6 +1164,7 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
     float* U = filter_slot(a.w, flip_transpose ? 1 : 0, M, a.C, a.K, (size_t)NP * a.C * a.K * 4, (float*)ws, st, &run_filter);
     float* V = (float*)((char*)ws + ub);
     float* Mm = (float*)((char*)ws + ub + vb);
+    float* Px = (float*)((char*)ws + ub + vb + mb);
     const int cls = prof_class(kind);
     if (run_filter) {
         dim3 grid((unsigned)pnp_cdiv(a.K, 32), (unsigned)pnp_cdiv(a.C, 32));
@@ -1077,13 +1188,11 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
         ga.V = V; ga.U = U; ga.Mm = Mm; ga.T = w.T; ga.C = a.C; ga.K = a.K;
         const bool narrow = a.K <= 64;                 // 64 filters: a 128 x 64 tile (a 128-wide one would be half empty)
         ga.nblk_m = pnp_cdiv(w.T, 128); ga.nblk_n = pnp_cdiv(a.K, narrow ? 64 : 128);
-        static const int xcd_mode = env_int("PNP_WINO_XCD", 2), persist = env_int("PNP_WINO_PERSIST", 1);
-        ga.gn = a.gn; ga.xcd_swizzle = (a.xcd_swizzle && xcd_mode) ? 2 : 0;
+        ga.gn = a.gn; ga.xcd_swizzle = xcd ? 2 : 0;
         ga.npos = NP;
-        const long long ntiles = (long long)ga.nblk_m * ga.nblk_n * NP;
         ga.whole = ((double)NP * w.T * a.C * 4.0 < 2147483648.0 && (double)NP * a.C * a.K * 4.0 < 2147483648.0) ? 1 : 0;
-        // persistent launch (2 workgroups per CU work through the tiles, pipelined across tile boundaries) when there are more tiles than slots
-        dim3 grid((unsigned)((persist && ga.whole && ntiles > 512) ? 512 : ntiles));
+        ga.tail_F = plan.F; ga.tail_R = plan.R; ga.tail_s = plan.s; ga.Px = Px;
+        dim3 grid((unsigned)plan.grid);
         const double fl = 2.0 * NP * (double)w.T * a.C * a.K;
         const double by = 4.0 * NP * ((double)w.T * a.C + (double)a.C * a.K + (double)w.T * a.K);
         constexpr int KB = M == 4 ? 2 : 0;            // symbol: <.., 0 / 1> F(2x2) forward / data gradient, <.., 2 / 3> F(4x4)
@@ -1104,6 +1213,8 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
         oa.sp = a.sp; oa.drop_sid = a.drop_sid;
         oa.res_add = a.res_add; oa.stat_ws = a.stat_ws; oa.stat_shift = a.stat_shift;
         oa.ep_scale = a.ep_scale; oa.ep_shift = a.ep_shift; oa.ep_res = a.ep_res; oa.ep_cs = a.ep_cs; oa.ep_alpha = a.ep_alpha;
+        oa.Px = Px; oa.tail_P = plan.P; oa.tail_F = plan.F; oa.tail_R = plan.R; oa.tail_s = plan.s; oa.tail_bn = a.K <= 64 ? 64 : 128;
+        oa.nblk_m = pnp_cdiv(w.T, 128); oa.nblk_n = pnp_cdiv(a.K, oa.tail_bn); oa.gn = a.gn;
         dim3 grid((unsigned)nblk, (unsigned)pnp_cdiv(a.K / 4, NT));
         PnpProfScope ps(cls, st, 0.0, 4.0 * ((double)NP * w.T * a.K + (double)a.M * a.K), "wino_out_kernel<%d>", M);
         hipLaunchKernelGGL(wino_out_kernel<M>, grid, dim3(NT), 0, st, oa);
