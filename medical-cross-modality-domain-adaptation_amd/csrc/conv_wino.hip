@@ -1107,7 +1107,11 @@ bool wino_chosen(const pnp_conv_geom* g) { return plan_tile(g, false) != 0; }
 // workgroup); cutting each tail tile into s pieces of the reduction (s R <= 64, >= 2 stages per piece) hands every workgroup 1 / s of a tile
 // instead.  Pieces 1 .. s-1 leave their partial products in Px, summed by the output transform in a fixed order.
 static GemmPlan gemm_plan(int T, int C, int K, int NP, bool xcd) {
-    static const int persist = env_int("PNP_WINO_PERSIST", 1), split_on = env_int("PNP_WINO_TAILSPLIT", 1);
+    // (the tail split is OFF by default: measured within one run, tools/experiments/r5_run9.sh — the GEMMs gain 4-16 % (512->512 163 ->
+    // 156 us, 256->256 59.7 -> 49.9, 256->512 data gradient 106.5 -> 88.4) but the output transform pays for finding and summing the pieces
+    // (512->512 20.0 -> 26.0 us, g10 95 -> 113): joint step 248.6 -> 249.5 slices/s, inside the noise.  Kept, parity-tested, as the measured
+    // answer to "balance the 2.25 tiles per workgroup": a lone workgroup on a CU already runs its extra tile at nearly twice the speed)
+    static const int persist = env_int("PNP_WINO_PERSIST", 1), split_on = env_int("PNP_WINO_TAILSPLIT", 0);
     GemmPlan p{};
     const int bn = K <= 64 ? 64 : 128;
     const long long ntiles = (long long)NP * pnp_cdiv(T, 128) * pnp_cdiv(K, bn);

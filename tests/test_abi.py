@@ -282,15 +282,10 @@ def test_winograd_f4_planner_on_the_host(built):
         K.wino_tile(2)
         assert ch(geo(16, 32, 512, 512)) == (2, 2, 2) and ch(geo(16, 32, 128, 128)) == (0, 0, 0)
         K.wino_tile(4)
-        # workspace = 36 x (C K + T C + T K) floats, T = tiles of 4x4 outputs, + the partial products of the GEMM's tail split: a persistent
-        # launch deals 1152 (5760) tiles to 8 XCDs x 64 workgroups = 2 (11) whole rounds + 16 tail tiles per XCD, each cut into 4 pieces of
-        # the 16-stage reduction; pieces 1-3 leave dense 128 x 128 tiles
-        px = 8 * 16 * 3 * 128 * 128 * 4
+        # workspace = 36 x (C K + T C + T K) floats, T = tiles of 4x4 outputs (+ the partial tiles of the GEMM's tail split when
+        # PNP_WINO_TAILSPLIT=1: tests/wino_split_worker.py)
         for g, T in ((geo(16, 32, 512, 512), 16 * 8 * 8), (geo(16, 32, 512, 512, dil=2), 16 * 4 * 4 * 4), (geo(16, 34, 512, 2560, pad="VALID"), 16 * 8 * 8)):
-            assert int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))) == 36 * 4 * (g.C * g.K + T * g.C + T * g.K) + px, (g.C, g.K)
-        assert int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(geo(16, 32, 256, 256)))) == 36 * 4 * (256 * 256 + 2 * 1024 * 256) + 8 * 8 * 3 * 128 * 128 * 4    # 72 per XCD: 8 tail tiles x 4 pieces (8 stages: not 8)
-        assert int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(geo(8, 32, 512, 512)))) == 36 * 4 * (512 * 512 + 2 * 512 * 512) + 8 * 8 * 7 * 128 * 128 * 4    # 72 per XCD, 16 stages: 8 pieces of 2
-        assert int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(geo(16, 128, 128, 128)))) == 36 * 4 * (128 * 128 + 2 * 16384 * 128)      # 576 per XCD = 9 whole rounds: nothing to split
+            assert int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))) == 36 * 4 * (g.C * g.K + T * g.C + T * g.K), (g.C, g.K)
         g10 = geo(16, 34, 512, 2560, pad="VALID")
         assert int(lib.pnp_conv2d_dgrad_workspace_bytes(ctypes.byref(g10))) == 16 * 4 * (2560 * 512 + 16 * 17 * 17 * (2560 + 512))    # F(2x2): 34 x 34 outputs, 17 x 17 tiles
         assert K.conv_stats_parts(geo(16, 32, 512, 512)) == 1024 // 2 and K.conv_stats_parts(g10) == 1024

@@ -294,3 +294,19 @@ def test_joint_steps_with_and_without_the_filter_cache(dev, wino):
     # (bit-for-bit, NaN == NaN: with the reference's stddev-.01 init and un-calibrated moving statistics the CT front's update overflows
     # in both runs alike — what is compared here is cached against un-cached, not the health of an untrained network)
     assert l0 == l1 and bool(((a0 == a1) | (torch.isnan(a0) & torch.isnan(a1))).all())
+
+
+@pytest.mark.parametrize("split", ["0", "1"], ids=["persistent", "persistent+tail-split"])
+def test_persistent_gemm_and_its_tail_split(dev, split):
+    """round 5: with more tiles than workgroup slots the route's GEMM launch is persistent (the software pipeline runs across tile
+    boundaries); PNP_WINO_TAILSPLIT=1 (read once by the library: a process of its own) additionally cuts every XCD's tail tiles into
+    pieces of the reduction whose partial products the output transform sums.  BASELINE-batch layers, forward and data gradient against
+    the direct kernels, and the workspace sizes of both plans (tests/wino_split_worker.py)"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PNP_WINO_TAILSPLIT=split)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "wino_split_worker.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and "SPLIT WORKER OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
