@@ -122,7 +122,7 @@ def test_bn_reductions_with_long_partial_lists(dev, P, C):
 def test_one_launch_combine_rearms_its_tickets(dev):
     """round 5 (opt-in, PNP_BN_ONE_LAUNCH=1 — off by default: slower, profiles/r05_bn_one_launch_ab.txt): the column reductions sum their
     partial rows inside the reduction launch (last workgroup of a slab, then last slab; tickets in a library-owned counter buffer that
-    every launch leaves zeroed).  In a process of its own with the switch on (the library reads it once): 700 launches of mixed shapes —
+    every launch leaves zeroed).  In a process of its own with the switch on (the library reads it once): 640 launches of mixed shapes —
     more than the buffer has slots — must each finish (outputs pre-poisoned with NaN) with bit-identical results per shape and the
     float64 statistics: a counter left armed would make a later launch on its slot finish early (a wrong sum) or never (NaN)"""
     import os
