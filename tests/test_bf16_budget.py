@@ -1,6 +1,6 @@
-"""not gpu: tolerance budget for BASELINE config 5 (bf16 MFMA operands, fp32 accumulation; not built yet — DESIGN.md §8): the CPU oracle
+"""not gpu: tolerance budget for BASELINE config 5 (bf16 MFMA operands, fp32 accumulation: csrc/conv_bf16.hip / conv_bf16r.hip): the CPU oracle
 with both operands of every convolution rounded to bfloat16, against the fp32 oracle, on a B=1 slice with He-scaled random filters
-in inference mode.  The numbers bound what a bf16 conv path can be held to ("tolerance-checked Dice vs fp32")."""
+in inference mode.  The numbers bound what the bf16 conv path is held to by tests/test_gpu_bf16.py ("tolerance-checked Dice vs fp32")."""
 import numpy as np
 import torch
 
