@@ -145,7 +145,7 @@ def test_every_kernel_of_every_adaptation_unit_teacher_forced_B16(dev):
         # Direct kernels + F(2x2) (every kernel at 1e-6..3e-6 of max|ref|): round 3-5 measured hip median 5.6e-3 / max 1.5e-2 / min cosine
         # 0.999976 against cpu-fp32 6.0e-3 / 1.2e-2 / 0.999959 -> 1.5 x the oracle's median.  F(4x4) (round 5's default; its GEMMs
         # accumulate in the transform domain: every kernel at 3e-6..8e-6, g10's data gradient 1.7e-5 — inside north_star's 1e-4 and the
-        # 2e-5 adoption bar of tools/wino_f43_study.py) measured 9.3e-3 / 1.75e-2 / 0.999907: 1.56 x the oracle's median -> held to 2 x, and
+        # 2e-5 adoption bar of tools/wino_f43_study.py) measured 9.3e-3 / 1.75e-2 / 0.999907 (9.7e-3 / 1.84e-2 / 0.999898 once the 64-channel layers joined the route): 1.56-1.63 x the oracle's median -> held to 2 x, and
         # stated as such in README / DESIGN (PNP_WINOGRAD_TILE=2 restores the tighter arithmetic at 0.86 x the speed).
         # This is THE whole-step statement for the generator path: the float32-vs-float32 band of test_joint_step_B16_vs_float32_oracle is
         # two such distances added.
