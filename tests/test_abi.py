@@ -344,3 +344,36 @@ def test_winograd_eligibility_and_tile_count_agree_with_the_restatement(built, m
     finally:
         K.wino_mode(prev)
         K.wino_tile(prev_t)
+
+
+def test_tail_split_plan_through_the_workspace_query(built):
+    """PNP_WINO_TAILSPLIT=1 (off by default; read once by the library, hence a process of its own): a persistent GEMM launch of the
+    Winograd route deals tiles / 8 to each XCD = whole rounds of 64 workgroups + R tail tiles, cuts every tail tile into the largest
+    s in {8, 4, 2} pieces with s R <= 64, s | stages, >= 2 stages per piece, and asks for 8 R (s - 1) dense 128 x 128 partial tiles on top
+    of the route's workspace; launches of <= 512 tiles or with a tile count that is no multiple of 8 are never split"""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, importlib, sys
+sys.path.insert(0, %r)
+K = importlib.import_module("medical-cross-modality-domain-adaptation_amd.kernels")
+L = importlib.import_module("medical-cross-modality-domain-adaptation_amd._lib")
+lib = L.load()
+K.wino_mode(2); K.wino_tile(4)
+tile = 128 * 128 * 4
+for (N, H, C, Kf, pad, extra) in ((16, 32, 512, 512, "SAME", 8 * 16 * 3 * tile),     # 1152 tiles: 144 per XCD = 2 rounds + 16, 16 stages -> 4 pieces
+                                  (16, 32, 256, 256, "SAME", 8 * 8 * 3 * tile),      # 576: 72 = 1 round + 8, 8 stages -> 4 pieces of 2
+                                  (8, 32, 512, 512, "SAME", 8 * 8 * 7 * tile),       # 576, 16 stages -> 8 pieces of 2
+                                  (16, 34, 512, 2560, "VALID", 8 * 16 * 3 * tile),   # 5760: 720 = 11 rounds + 16
+                                  (16, 128, 128, 128, "SAME", 0),                    # 4608: 576 = 9 whole rounds
+                                  (4, 32, 512, 512, "SAME", 0),                      # 288 tiles: not persistent
+                                  (5, 30, 512, 544, "SAME", 0)):                     # 540 tiles: no multiple of 8
+    g = K.conv_geom((N, H, H, C), (3, 3, C, Kf), 1, 1, pad)
+    T = N * (-(-g.OH // 4)) * (-(-g.OW // 4))
+    base = 36 * 4 * (C * Kf + T * C + T * Kf)
+    got = int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g))) - base
+    assert got == extra, ((N, H, C, Kf), got, extra)
+print("PLAN OK")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PNP_WINO_TAILSPLIT="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PLAN OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
