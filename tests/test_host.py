@@ -648,3 +648,81 @@ def test_written_ranges_of_an_optimiser_mask():
     assert list(mask) == [0, 1, 1, 1, 0, 1, 1]
     assert st.written_ranges(mask) == [(base + ch, base + 4 * ch), (base + 5 * ch, base + 7 * ch)]
     assert st.written_ranges(np.zeros(nch, np.uint8)) == []
+
+
+def test_transformed_filter_cache_rules_on_the_host(monkeypatch):
+    """kernels._wino_u (the Python side of pnp_conv2d_wino_filter_bind) against a recording stand-in for the library: a store-owned filter
+    gets ONE binding per pass; a torch in-place write (version counter) reports the filter's byte range; the binding is withdrawn when the
+    tensor object dies and when an ad-hoc filter turns up on a cached address; ad-hoc filters are never bound; weights_changed hands
+    ranges through"""
+    import ctypes
+    K = pkg("kernels")
+    calls = []
+
+    class FakeLib(object):
+        def pnp_conv2d_wino_filter_bytes(self, C, Kf):
+            return 36 * C * Kf * 4
+
+        def pnp_conv2d_wino_filter_bind(self, w, kind, U, n):
+            calls.append(("bind" if U is not None else "unbind", getattr(w, "value", w), kind))
+            return 0
+
+        def pnp_weights_changed(self, lo, hi):
+            calls.append(("changed", getattr(lo, "value", lo), getattr(hi, "value", hi)))
+
+        def pnp_conv2d_wino_chosen(self, g, kind):
+            return 4
+
+    monkeypatch.setattr(K._lib, "load", lambda: FakeLib())
+    monkeypatch.setattr(ctypes, "byref", lambda g: g)
+    monkeypatch.setattr(K, "_u_cache", {})
+    monkeypatch.setattr(K, "U_CACHE", True)
+
+    class G(object):
+        R = S = 3
+
+    w = torch.zeros(3, 3, 32, 32)
+    K._wino_u(w, G(), 0)                                  # ad-hoc: nothing
+    assert calls == [] and not K._u_cache
+    w._pnp_var = True
+    K._wino_u(w, G(), 0)
+    K._wino_u(w, G(), 0)
+    K._wino_u(w, G(), 1)
+    assert calls == [("bind", w.data_ptr(), 0), ("bind", w.data_ptr(), 1)] and len(K._u_cache) == 2
+    w.add_(1.0)                                           # a torch op on the filter
+    K._wino_u(w, G(), 0)
+    assert calls[-1] == ("changed", w.data_ptr(), w.data_ptr() + 4 * w.numel())
+    K.weights_changed([(10, 20), (30, 40)])
+    assert calls[-2:] == [("changed", 10, 20), ("changed", 30, 40)]
+    K.weights_changed()
+    assert calls[-1] == ("changed", None, None)
+    ptr = w.data_ptr()
+    del w                                                 # the tensor goes: both bindings with it
+    assert not K._u_cache and sorted(calls[-2:]) == [("unbind", ptr, 0), ("unbind", ptr, 1)]
+    w2 = torch.zeros(3, 3, 32, 32)
+    w2._pnp_var = True
+    K._wino_u(w2, G(), 1)
+    v = torch.zeros(3, 3, 32, 32)                         # an ad-hoc filter "on the same address": move the entry under its key
+    K._u_cache[(v.data_ptr(), 1)] = K._u_cache.pop((w2.data_ptr(), 1))
+    K._wino_u(v, G(), 1)
+    assert calls[-1] == ("unbind", v.data_ptr(), 1) and not K._u_cache
+
+
+def test_captured_gan_steps_fall_back_to_eager_when_the_learning_rate_moved():
+    """adversarial.Trainer._captured: a recording froze the RMSProp learning rates by value — after a decay
+    (Trainer.train, restore_optimizer) the captured steps must not be replayed"""
+    adv = pkg("adversarial")
+
+    class Opt(object):
+        def __init__(self, lr):
+            self.lr = lr
+
+    t = adv.Trainer.__new__(adv.Trainer)
+    t.dis_optimizer, t.gen_optimizer = Opt(3e-4), Opt(3e-4)
+    t._cap = {"dropout": 0.75, "mr": (2, 256, 256, 3), "ct": (2, 256, 256, 3), "lr": (3e-4, 3e-4), "dis": "D", "gen": "G"}
+    assert t._captured("dis", 0.75, {"mr": (2, 256, 256, 3), "ct": (2, 256, 256, 3)}) == "D"
+    assert t._captured("gen", 0.75, {"ct": (2, 256, 256, 3)}) == "G"
+    assert t._captured("gen", 0.5, {"ct": (2, 256, 256, 3)}) is None and t._captured("gen", 0.75, {"ct": (4, 256, 256, 3)}) is None
+    t.gen_optimizer.lr *= 0.95
+    assert t._captured("dis", 0.75, {"mr": (2, 256, 256, 3), "ct": (2, 256, 256, 3)}) is None
+    assert t._captured("gen", 0.75, {"ct": (2, 256, 256, 3)}) is None and t._cap.get("warned")

@@ -151,6 +151,16 @@ def test_bench_prices_the_winograd_transforms_against_the_hbm_roof():
     assert i["bound"] == "hbm" and i["unit"] == "GB/s" and i["peak"] == bench.PEAK_HBM_GBS
     assert abs(i["achieved"] - 200 * 1.45e8 / 6e-3 / 1e9) < 1e-3 and abs(i["frac"] - i["achieved"] / 8000.0) < 1e-9
     assert recs[0]["kernel"] == "wino_out_kernel" and recs[0]["bound"] == "hbm"          # sorted by time, whatever the bound
+    # round 5: a Winograd GEMM row says that it counts EXECUTED flops and carries the same launch in the convolution's algorithmic flops
+    # (x 2.25 for F(2x2): symbols <.., 0 / 1>; x 4 for F(4x4): <.., 2 / 3> and the 128 x 64 tile; filter gradient by its TILE parameter)
+    assert g["flops_counted"] == "executed" and abs(g["achieved_algorithmic"] - 2.25 * g["achieved"]) < 1e-9 and i["flops_counted"] == "none"
+    for name, f in (("wino_gemm_kernel<128, 128, 2, 2, 2>", 4.0), ("wino_gemm_kernel<128, 64, 2, 2, 3>", 4.0), ("wino_gemm_kernel<128, 128, 2, 2, 1>", 2.25),
+                    ("wino_wgrad_gemm_kernel<128, 128, 2, 2, 4>", 4.0), ("wino_wgrad_gemm_kernel<128, 128, 2, 2, 2>", 2.25),
+                    ("conv_taps_kernel<128, 128, 2, 2, 0, 3, 3>", 1.0)):
+        assert bench.wino_alg_factor(name) == f, name
+    d = bench.roofline_records([{"name": "conv_taps_kernel<128, 128, 2, 2, 0, 3, 3>", "ms": 1.0, "launches": 1, "flops": 1e11, "bytes": 1e8}], 157.3)[0]
+    assert d["flops_counted"] == "algorithmic" and d["achieved_algorithmic"] == d["achieved"]
+    assert bench.ALG_GFLOP_PER_SLICE["joint"] == 399.8 + 256.2 and bench.ALG_GFLOP_PER_SLICE["segmenter"] == 248.95
     rec = bench.compact_record({"metric": "m", "value": 1.0, "unit": "slices/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
                                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                                 "config": {"workload": "w"}, "roofline": dict(recs[0])})
