@@ -1192,7 +1192,8 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
         ga.V = V; ga.U = U; ga.Mm = Mm; ga.T = w.T; ga.C = a.C; ga.K = a.K;
         const bool narrow = a.K <= 64;                 // 64 filters: a 128 x 64 tile (a 128-wide one would be half empty)
         ga.nblk_m = pnp_cdiv(w.T, 128); ga.nblk_n = pnp_cdiv(a.K, narrow ? 64 : 128);
-        ga.gn = a.gn; ga.xcd_swizzle = xcd ? 2 : 0;
+        static const int wino_gn = env_int("PNP_WINO_GN", -1);          // filter-tile group width of the route's GEMM (< 0: the convolutions' PNP_CONV_GN)
+        ga.gn = wino_gn >= 0 ? wino_gn : a.gn; ga.xcd_swizzle = xcd ? 2 : 0;
         ga.npos = NP;
         ga.whole = ((double)NP * w.T * a.C * 4.0 < 2147483648.0 && (double)NP * a.C * a.K * 4.0 < 2147483648.0) ? 1 : 0;
         ga.tail_F = plan.F; ga.tail_R = plan.R; ga.tail_s = plan.s; ga.Px = Px;
@@ -1218,7 +1219,8 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
         oa.res_add = a.res_add; oa.stat_ws = a.stat_ws; oa.stat_shift = a.stat_shift;
         oa.ep_scale = a.ep_scale; oa.ep_shift = a.ep_shift; oa.ep_res = a.ep_res; oa.ep_cs = a.ep_cs; oa.ep_alpha = a.ep_alpha;
         oa.Px = Px; oa.tail_P = plan.P; oa.tail_F = plan.F; oa.tail_R = plan.R; oa.tail_s = plan.s; oa.tail_bn = a.K <= 64 ? 64 : 128;
-        oa.nblk_m = pnp_cdiv(w.T, 128); oa.nblk_n = pnp_cdiv(a.K, oa.tail_bn); oa.gn = a.gn;
+        static const int wino_gn_o = env_int("PNP_WINO_GN", -1);
+        oa.nblk_m = pnp_cdiv(w.T, 128); oa.nblk_n = pnp_cdiv(a.K, oa.tail_bn); oa.gn = wino_gn_o >= 0 ? wino_gn_o : a.gn;
         dim3 grid((unsigned)nblk, (unsigned)pnp_cdiv(a.K / 4, NT));
         PnpProfScope ps(cls, st, 0.0, 4.0 * ((double)NP * w.T * a.K + (double)a.M * a.K), "wino_out_kernel<%d>", M);
         hipLaunchKernelGGL(wino_out_kernel<M>, grid, dim3(NT), 0, st, oa);
