@@ -23,7 +23,19 @@ def _blob(rng, B):
     return out
 
 
-def test_captured_segmenter_step_equals_eager_bit_for_bit(dev):
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_captured_segmenter_step_equals_eager_bit_for_bit(dev, dtype):
+    """bf16: the recording must hold its own operand casts — kernels.bf16_of skips the per-tensor shadow while a stream is
+    capturing, so a replay reads the bf16 copy of THIS step's static input, not the warm-up's."""
+    F = pkg("functional")
+    F.set_conv_dtype(dtype)
+    try:
+        _segmenter_capture_case(dev)
+    finally:
+        F.set_conv_dtype("f32")
+
+
+def _segmenter_capture_case(dev):
     ss = pkg("source_segmenter")
     from dp_sync_common import scaled_state
     B = 2
