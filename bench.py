@@ -15,7 +15,7 @@ stdout; round 3's 20 KB line arrived unparsed) carrying
   * `roofline_all_mfma_convs`  the aggregate over every MFMA convolution symbol of the step;
   * `segmenter_step`    BASELINE configs[1] (source segmenter fwd + bwd + Adam, source_segmenter.py:484-489) timed the same way;
   * `cpu_baseline`      the CPU oracle's joint step (oracle/nets_adv.py, torch-CPU fp32) on this host's cores AT THE GPU LINE'S BATCH
-                        (B = 16: 1 warm-up + 3 timed steps), with the B = 2 figure as a second field.
+                        (B = 16: 1 warm-up + 2 timed steps), with the B = 2 figure as a second field.
 The per-symbol table (`roofline_kernels`: forward, data gradient, filter gradient of every convolution symbol) goes to a side file,
 `bench_kernels_<workload>_<dtype>.json` under gpurun_out/ (on a GPU box) or profiles/, and its path is named in the record.
 `--workload segmenter` makes configs[1] the headline line instead (same contract); `--dtype bf16` runs configs[4]'s arithmetic (a
@@ -121,8 +121,8 @@ def cpu_model():
 def cpu_baseline(workload, Bc=16, timed_steps=3, warm=1):
     """The CPU oracle (a port: TF-1.4 cannot run here) on this host's cores, same step definition as the GPU line (SURVEY.md §8(d):
     "same synthetic batch, same step definition"): Bc slices per domain, `warm` warm-up + `timed_steps` timed steps, median.  The default
-    is the GPU line's own batch, B = 16, 1 + 3 steps (~4.5 min of host time for the joint step); main() adds a B = 2 sample as a second
-    field (the smallest batch the reference's PS accepts, ops.py:7)."""
+    is the GPU line's own batch, B = 16, 1 + 2 steps from main() (~3.5 min of host time for the joint step; a third timed step moved the
+    median by < 3 %); main() adds a B = 2 sample as a second field (the smallest batch the reference's PS accepts, ops.py:7)."""
     # torch's default intra-op thread count honours the cgroup / affinity mask of the box (os.cpu_count() does not:
     # forcing 256 threads onto a restricted mask made this sample 50x slower)
     ncores = torch.get_num_threads()
@@ -306,7 +306,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="slices per GPU (of each domain for the joint step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="slices per domain of the cpu_baseline sample (default: the GPU line's B = 16)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed steps of the cpu_baseline sample (after --cpu-warmup)")
     ap.add_argument("--cpu-warmup", type=int, default=1)
     ap.add_argument("--cpu-small-batch", type=int, default=2, help="second, small cpu_baseline sample (0: none)")
     ap.add_argument("--no-probe", action="store_true", help="no per-kernel HIP events (no roofline objects)")
