@@ -124,7 +124,14 @@ int32_t pnp_conv2d_wino_mode(int32_t mode);
  * profiles/r05_wino_f43_tolerance.txt).  tile = 2: F(2x2) only; 4 (the default, environment PNP_WINOGRAD_TILE): F(4x4) where its planner
  * takes the layer, else F(2x2), else the direct kernels; tile < 2: read only.  Returns the previous value. */
 int32_t pnp_conv2d_wino_tile(int32_t tile);
-/* Transformed-filter cache of the route.  U = G g G^T (36 C K floats per filter and pass) only changes when the filter does: the caller
+/* Round 6: arithmetic of the route's forward / data-gradient GEMMs.  0: the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  1 (the default,
+ * environment PNP_WINOGRAD_X3) where it pays (reductions over >= 256 channels), 2 wherever the shapes allow (C % 64 == 0): split-bf16 operands — every transformed value is stored as three bf16 planes whose sum IS the fp32 value, six of the
+ * nine plane products (all terms above 2^-26 of the product) run on v_mfma_f32_32x32x16_bf16 (16x the fp32 pipe's rate) with fp32
+ * accumulation in 64-channel chunks (csrc/conv_wino_x3.hip; tools/wino_bf16x3_study.py -> profiles/r06_wino_bf16x3_tolerance.txt: the
+ * whole layer's error against float64 falls from 4e-6..6e-6 to 1e-6..2e-6, because the chunked chain is shorter than the fp32 pipe's).
+ * mode < 0: read only.  Returns the previous mode.  Workspace queries and the transformed-filter cache follow the mode in force. */
+int32_t pnp_conv2d_wino_x3(int32_t mode);
+/* Transformed-filter cache of the route.  U = G g G^T (36 C K values per filter and pass: fp32, or three bf16 planes) only changes when the filter does: the caller
  * lends one buffer per (filter, pass) and reports weight writes; a launch whose filter has a valid entry skips wino_filter_kernel (the
  * frozen source segmenter / shared half of adversarial.py:839-882 never pay it again, a trained layer once per update instead of once per
  * pass).  pnp_conv2d_wino_filter_bytes(C, K): size of an entry that serves either tile (0: this shape never takes the route).

@@ -347,6 +347,10 @@ __device__ __forceinline__ f32x4 bload4s(__amdgpu_buffer_rsrc_t r, unsigned voff
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+__device__ __forceinline__ float bload1s(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 // bf16-operand kernels (conv_bf16.hip), dispatched from conv_igemm.hip's planners when ConvArgs::dtype == PNP_DTYPE_BF16 and the
 // layer is on the tap-unrolled / linear-wgrad fast paths; every other layer keeps the fp32 kernels.  grid / nsplit / chunks_per_split are
 // planned by the caller exactly as for the fp32 kernels.  tile: 0 = 128x128, 1 = 128x64, 2 = 128x32.  Return false: no instance.
@@ -388,6 +392,11 @@ bool wino_wgrad_chosen(const pnp_conv_geom* g);
 int wino_wgrad_tile(const pnp_conv_geom* g);
 size_t wino_wgrad_workspace_bytes(const pnp_conv_geom* g);
 int launch_wino_wgrad(const ConvArgs& a, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+// split-bf16 GEMMs of the route (conv_wino_x3.hip): M[pos] = V3[pos] x U3[pos]^T, V3 [npos][3][T][C] / U3 [npos][3][K][C] bf16 planes
+// (hi, mid, lo: their sum is the fp32 value), M [npos][T][K] fp32.  dims_ok: one buffer descriptor per operand and transform point.
+bool wino_x3_dims_ok(int T, int C, int K);
+int launch_wino_gemm_x3(const unsigned short* V3, const unsigned short* U3, float* Mm, int T, int C, int K, int npos, int sym, int gn, int xcd,
+                        hipStream_t st);
 inline double conv_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.K * a.Kred; }
 inline double conv_bytes(const ConvArgs& a) {
     return 4.0 * ((double)a.N * a.H * a.W * a.C + (double)a.M * a.K + (double)a.Kred * a.K);

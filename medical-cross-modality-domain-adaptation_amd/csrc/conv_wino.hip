@@ -46,6 +46,29 @@ constexpr int NT = 256;
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// ---- split-bf16 ("x3") operands of the GEMMs (conv_wino_x3.hip): v = hi + mid + lo EXACTLY, hi = bf16(v), mid = bf16(v - hi),
+// lo = bf16(v - hi - mid) (round-to-nearest-even: v_cvt_pk_bf16_f32; both differences are exact in fp32).  Operand layout ("stage-major":
+// what ONE stage of the GEMM reads of one plane is contiguous): [pos][C / 32][plane][rows][32]; pstride = rows * 32 elements between planes.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)v;
+    const float r = v - (float)hi;
+    mid = (__bf16)r;
+    lo = (__bf16)(r - (float)mid);
+}
+__device__ __forceinline__ void st4x3(__bf16* p, size_t pstride, f32x4 v) {
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        __bf16 a, b, c;
+        split3(v[e], a, b, c);
+        h[e] = a; m[e] = b; l[e] = c;
+    }
+    *reinterpret_cast<bf16x4*>(p) = h;
+    *reinterpret_cast<bf16x4*>(p + pstride) = m;
+    *reinterpret_cast<bf16x4*>(p + 2 * pstride) = l;
+}
+
 // Hi x Wi: the input image, Ho x Wo = Hi + 2 pad - 2 dil: the output; ps = pad / dil in {0, 1, 2} (VALID on a pre-padded image, SAME, the
 // data gradient of a VALID convolution); Hsi / Hso ...: extents of one dilation phase's sub-image; tiles enumerate the OUTPUT
 struct WinoGeom {
@@ -127,7 +150,7 @@ struct WinoInArgs {
     int xcd;
 };
 
-template <int M>
+template <int M, bool X3>
 __global__ void __launch_bounds__(NT) wino_in_kernel(WinoInArgs a) {
     constexpr int P = M + 2;                 // patch edge
     const int C4 = a.C >> 2;
@@ -159,6 +182,12 @@ __global__ void __launch_bounds__(NT) wino_in_kernel(WinoInArgs a) {
         // rows (B^T d), then columns ((B^T d) B)
         f32x4 r[P][P];
         float* out = a.V + (size_t)t * a.C + c;
+        // X3: V3 [pos][C / 32][plane][T][32] bf16 — transform point `pos` starts 3 * plane elements behind the previous one
+        __bf16* out3 = reinterpret_cast<__bf16*>(a.V) + ((size_t)(c >> 5) * 3 * a.g.T + t) * 32 + (c & 31);
+        auto put = [&](int pos, f32x4 v) {
+            if constexpr (X3) st4x3(out3 + (size_t)pos * 3 * plane, (size_t)a.g.T * 32, v);
+            else st4(out + (size_t)pos * plane, v);
+        };
         if constexpr (M == 2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -169,10 +198,10 @@ __global__ void __launch_bounds__(NT) wino_in_kernel(WinoInArgs a) {
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                st4(out + (size_t)(4 * p + 0) * plane, r[p][0] - r[p][2]);
-                st4(out + (size_t)(4 * p + 1) * plane, r[p][1] + r[p][2]);
-                st4(out + (size_t)(4 * p + 2) * plane, r[p][2] - r[p][1]);
-                st4(out + (size_t)(4 * p + 3) * plane, r[p][1] - r[p][3]);
+                put(4 * p + 0, r[p][0] - r[p][2]);
+                put(4 * p + 1, r[p][1] + r[p][2]);
+                put(4 * p + 2, r[p][2] - r[p][1]);
+                put(4 * p + 3, r[p][1] - r[p][3]);
             }
         } else {
 #pragma unroll
@@ -187,7 +216,7 @@ __global__ void __launch_bounds__(NT) wino_in_kernel(WinoInArgs a) {
                 f32x4 o[6];
                 w4_bt(r[p][0], r[p][1], r[p][2], r[p][3], r[p][4], r[p][5], o);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) st4(out + (size_t)(6 * p + q) * plane, o[q]);
+                for (int q = 0; q < 6; ++q) put(6 * p + q, o[q]);
             }
         }
     }
@@ -195,66 +224,89 @@ __global__ void __launch_bounds__(NT) wino_in_kernel(WinoInArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // filter transform: U[pos][row][col] = (G g G^T)[pos], rows = reduction channels, cols = output channels of the GEMM.
-//   TRANS false (forward):        g[r][s] = w[r][s][row][col]
-//   TRANS true  (data gradient):  g[r][s] = w[2-r][2-s][col][row]   (the flipped, transposed filter; 32x32 tiles through LDS so that both
-//                                 the read along w's last axis and the write along U's last axis are coalesced)
-template <bool TRANS, int M>
+//   TRANS false (forward):        g[r][s] = w[r][s][row][col]                      (w's fast axis = col)
+//   TRANS true  (data gradient):  g[r][s] = w[2-r][2-s][col][row]   (the flipped, transposed filter: w's fast axis = row)
+//   X3 false: U  [pos][row][col] fp32 (fast axis = col);  X3 true: U3 [pos][row / 32][plane][col][row % 32] bf16 split operands (fast
+//   axis = row: the B operand of conv_wino_x3.hip has the reduction index contiguous).
+// Where the source's and the destination's fast axes differ (TRANS != X3) the nine taps of a 32 x 32 tile go through LDS so that both the
+// read and the write are coalesced; no separate flip / transpose launch in any of the four cases.
+template <bool TRANS, int M, bool X3>
 __global__ void __launch_bounds__(NT) wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int rows, int cols) {
     constexpr int P = M + 2;
-    __shared__ float tile[TRANS ? 9 : 1][32][33];
+    constexpr bool VIA_LDS = TRANS != X3;
+    __shared__ float tile[VIA_LDS ? 9 : 1][32][33];
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
     const size_t plane = (size_t)rows * cols;
-    if constexpr (TRANS) {
-        // w is [tap][cols][rows] here
+    // element (row, col) of memory tap `tap`
+    auto src = [&](int tap, int row, int col) {
+        return TRANS ? w[((size_t)tap * cols + col) * rows + row] : w[((size_t)tap * rows + row) * cols + col];
+    };
+    if constexpr (VIA_LDS) {
+        // tx walks the SOURCE's fast axis; tile[tap][j][tx]
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
             for (int j = ty; j < 32; j += 8) {
-                const int sc = c0 + j, sr = r0 + tx;
-                tile[tap][j][tx] = (sc < cols && sr < rows) ? w[((size_t)tap * cols + sc) * rows + sr] : 0.f;
+                const int sr = TRANS ? r0 + tx : r0 + j, sc = TRANS ? c0 + j : c0 + tx;
+                tile[tap][j][tx] = (sc < cols && sr < rows) ? src(tap, sr, sc) : 0.f;
             }
         __syncthreads();
     }
     for (int j = ty; j < 32; j += 8) {
-        const int row = r0 + j, col = c0 + tx;
+        // tx walks the DESTINATION's fast axis
+        const int row = X3 ? r0 + tx : r0 + j, col = X3 ? c0 + j : c0 + tx;
         const bool ok = row < rows && col < cols;
         float g[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                if constexpr (TRANS) g[r][s] = tile[(2 - r) * 3 + (2 - s)][tx][j];
-                else g[r][s] = ok ? w[((size_t)(r * 3 + s) * rows + row) * cols + col] : 0.f;
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const int tap = TRANS ? 8 - (r * 3 + s_) : r * 3 + s_;
+                if constexpr (VIA_LDS) g[r][s_] = tile[tap][tx][j];
+                else g[r][s_] = ok ? src(tap, row, col) : 0.f;
             }
         float t[P][3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s_ = 0; s_ < 3; ++s_) {
             if constexpr (M == 2) {
-                t[0][s] = g[0][s];
-                t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
-                t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
-                t[3][s] = g[2][s];
+                t[0][s_] = g[0][s_];
+                t[1][s_] = 0.5f * (g[0][s_] + g[1][s_] + g[2][s_]);
+                t[2][s_] = 0.5f * (g[0][s_] - g[1][s_] + g[2][s_]);
+                t[3][s_] = g[2][s_];
             } else {
                 float o[6];
-                w4_g(g[0][s], g[1][s], g[2][s], o);
+                w4_g(g[0][s_], g[1][s_], g[2][s_], o);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) t[i][s] = o[i];
+                for (int i = 0; i < 6; ++i) t[i][s_] = o[i];
             }
         }
         if (ok) {
             float* out = U + (size_t)row * cols + col;
+            __bf16* out3 = reinterpret_cast<__bf16*>(U) + ((size_t)(row >> 5) * 3 * cols + col) * 32 + (row & 31);
+            auto put = [&](int pos, float v) {
+                if constexpr (X3) {
+                    __bf16 hi, mid, lo;
+                    split3(v, hi, mid, lo);
+                    __bf16* q = out3 + (size_t)pos * 3 * plane;
+                    q[0] = hi;
+                    q[(size_t)cols * 32] = mid;
+                    q[(size_t)cols * 64] = lo;
+                } else {
+                    out[(size_t)pos * plane] = v;
+                }
+            };
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 if constexpr (M == 2) {
-                    out[(size_t)(4 * i + 0) * plane] = t[i][0];
-                    out[(size_t)(4 * i + 1) * plane] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-                    out[(size_t)(4 * i + 2) * plane] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-                    out[(size_t)(4 * i + 3) * plane] = t[i][2];
+                    put(4 * i + 0, t[i][0]);
+                    put(4 * i + 1, 0.5f * (t[i][0] + t[i][1] + t[i][2]));
+                    put(4 * i + 2, 0.5f * (t[i][0] - t[i][1] + t[i][2]));
+                    put(4 * i + 3, t[i][2]);
                 } else {
                     float o[6];
                     w4_g(t[i][0], t[i][1], t[i][2], o);
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) out[(size_t)(6 * i + q) * plane] = o[q];
+                    for (int q = 0; q < 6; ++q) put(6 * i + q, o[q]);
                 }
             }
         }
@@ -932,6 +984,30 @@ int wino_tile_max() {
     return m;
 }
 
+// arithmetic of the route's forward / data-gradient GEMMs (PNP_WINOGRAD_X3 / pnp_conv2d_wino_x3): 0 = fp32 matrix pipe (wino_gemm_kernel);
+// 1 = split-bf16 operands on the bf16 matrix pipe with chunked accumulation (conv_wino_x3.hip) where it pays: reductions over >= 256
+// channels (PNP_WINOGRAD_X3_CMIN; measured at B = 16, profiles/r06_x3_layers_B16.txt: 512->512 163 -> 108 us, 256->256 96 -> 39, g10's data
+// gradient 1 554 (F(2x2)) -> 637, cls3 256->256 @64^2 157 -> 126; 128-channel reductions 167 -> 182 and 64-channel ones 219 -> 340 lose: two
+// or four 32-channel stages do not amortise the pipeline fill); 2 = wherever the shapes allow (C % 64 == 0)
+#ifndef PNP_WINOGRAD_X3_DEFAULT
+#define PNP_WINOGRAD_X3_DEFAULT 1
+#endif
+std::atomic<int> g_wino_x3{-1};
+int wino_x3_mode() {
+    int m = g_wino_x3.load(std::memory_order_relaxed);
+    if (m < 0) {
+        m = env_int("PNP_WINOGRAD_X3", PNP_WINOGRAD_X3_DEFAULT);
+        m = m < 0 ? 0 : (m > 2 ? 2 : m);
+        g_wino_x3.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+inline bool use_x3(int T, int C, int K) {
+    static const int cmin = env_int("PNP_WINOGRAD_X3_CMIN", 256);
+    const int m = wino_x3_mode();
+    return m != 0 && wino_x3_dims_ok(T, C, K) && (m >= 2 || C >= cmin);
+}
+
 // ---- transformed-filter cache (pnp_conv2d_wino_filter_bind / pnp_weights_changed) -----------------------------------------------------
 // U = G g G^T only changes when the filter does: the caller lends one buffer per (filter, pass) and tells the library which weights a
 // kernel or a host-side load has written; a launch whose filter has a valid entry skips the transform kernel (frozen layers — the whole
@@ -945,13 +1021,14 @@ struct UEntry {
     bool valid;
     int tile, C, K;
     hipStream_t st;
+    int x3;          // what the buffer holds: fp32 U (0) or the split-bf16 planes U3 (1)
 };
 std::mutex g_umx;
 std::map<std::pair<const void*, int>, UEntry> g_ucache;
 std::atomic<long long> g_ucache_hits{0}, g_ucache_fills{0};
 
 // the buffer to transform into / read from for this launch, and whether the transform kernel has to run
-float* filter_slot(const float* w, int kind, int tile, int C, int K, size_t need, float* ws_u, hipStream_t st, bool* run) {
+float* filter_slot(const float* w, int kind, int tile, int C, int K, int x3, size_t need, float* ws_u, hipStream_t st, bool* run) {
     *run = true;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -962,11 +1039,11 @@ float* filter_slot(const float* w, int kind, int tile, int C, int K, size_t need
     auto it = g_ucache.find({(const void*)w, kind});
     if (it == g_ucache.end() || it->second.bytes < need) return ws_u;
     UEntry& e = it->second;
-    if (e.valid && e.tile == tile && e.C == C && e.K == K && e.st == st) {
+    if (e.valid && e.tile == tile && e.C == C && e.K == K && e.st == st && e.x3 == x3) {
         *run = false;
         g_ucache_hits.fetch_add(1, std::memory_order_relaxed);
     } else {
-        e.valid = true; e.tile = tile; e.C = C; e.K = K; e.st = st;
+        e.valid = true; e.tile = tile; e.C = C; e.K = K; e.st = st; e.x3 = x3;
         g_ucache_fills.fetch_add(1, std::memory_order_relaxed);
     }
     return e.U;
@@ -1057,9 +1134,10 @@ int plan_tile(int dtype, int R, int S, int stride, int pad_mode, int dil, int pa
         // 8 x 8 coefficients meet cancelling sums): 512-channel reductions 3e-6..8e-6 of max|ref|, group_10's data gradient (2 560 channels)
         // 1.7e-5 (teacher-forced, profiles/r05_pytest_gpu.log) — too close to the 2e-5 adoption bar: reductions over > 1 024 channels stay
         // on F(2x2) (1e-6), at 1.80 instead of 1.39 ms for that one launch per generator step
-        if (m == 4 && !wgrad && C > c4max) continue;
-        if (mode >= 2) return m;
+        // (the split-bf16 GEMM accumulates in 96-channel chunks: 1.7e-6 at 2 560 channels — no cap)
         const WinoGeom w = make_wgeom(N, H, W, OH, OW, dil, pad_t, m);
+        if (m == 4 && !wgrad && C > c4max && !use_x3(w.T, C, K)) continue;
+        if (mode >= 2) return m;
         if (w.T < (m == 4 ? tmin4 : tmin2)) continue;
         const long long nwg = (long long)(m + 2) * (m + 2) * pnp_cdiv(w.T, 128) * pnp_cdiv(K, K <= 64 ? 64 : 128);
         const double thr = m == 4 ? (wgrad ? thr4w : thr4) : (wgrad ? thr2w : thr2);
@@ -1135,6 +1213,7 @@ static GemmPlan gemm_plan(int T, int C, int K, int NP, bool xcd) {
 
 static size_t fwd_ws_bytes(const WinoGeom& w, int C, int K) {
     const size_t np = (size_t)(w.m + 2) * (w.m + 2);
+    if (use_x3(w.T, C, K)) return al256(np * C * K * 6) + al256(np * w.T * C * 6) + al256(np * w.T * K * 4);
     return al256(np * C * K * 4) + al256(np * w.T * C * 4) + al256(np * w.T * K * 4) + gemm_plan(w.T, C, K, (int)np, true).px_bytes;
 }
 
@@ -1155,26 +1234,32 @@ template <int M>
 static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int NP = (M + 2) * (M + 2);
     const WinoGeom w = make_wgeom(a.N, a.H, a.W, a.OH, a.OW, a.dil, a.pad_t, M);
-    const size_t ub = al256((size_t)NP * a.C * a.K * 4), vb = al256((size_t)NP * w.T * a.C * 4), mb = al256((size_t)NP * w.T * a.K * 4);
+    const bool x3 = use_x3(w.T, a.C, a.K);
+    const size_t eb = x3 ? 6 : 4;          // bytes per transformed operand value
+    const size_t ub = al256((size_t)NP * a.C * a.K * eb), vb = al256((size_t)NP * w.T * a.C * eb), mb = al256((size_t)NP * w.T * a.K * 4);
     static const int xcd_mode = env_int("PNP_WINO_XCD", 2);
     const bool xcd = a.xcd_swizzle && xcd_mode;
-    const GemmPlan plan = gemm_plan(w.T, a.C, a.K, NP, xcd);
+    GemmPlan plan = gemm_plan(w.T, a.C, a.K, NP, xcd);
+    if (x3) { plan.s = 1; plan.px_bytes = 0; }
     if (!ws || ws_bytes < ub + vb + mb + plan.px_bytes) {
         pnp_set_error("launch_wino: workspace too small (%zu < %zu)", ws_bytes, ub + vb + mb + plan.px_bytes);
         return PNP_EWORKSPACE;
     }
     PNP_REQUIRE(a.y_h == nullptr && a.o_s == 0 && a.ups == 1, "launch_wino: unsupported epilogue");
     bool run_filter;
-    float* U = filter_slot(a.w, flip_transpose ? 1 : 0, M, a.C, a.K, (size_t)NP * a.C * a.K * 4, (float*)ws, st, &run_filter);
+    float* U = filter_slot(a.w, flip_transpose ? 1 : 0, M, a.C, a.K, x3 ? 1 : 0, (size_t)NP * a.C * a.K * eb, (float*)ws, st, &run_filter);
     float* V = (float*)((char*)ws + ub);
     float* Mm = (float*)((char*)ws + ub + vb);
     float* Px = (float*)((char*)ws + ub + vb + mb);
     const int cls = prof_class(kind);
     if (run_filter) {
         dim3 grid((unsigned)pnp_cdiv(a.K, 32), (unsigned)pnp_cdiv(a.C, 32));
-        PnpProfScope ps(cls, st, 0.0, 4.0 * (9.0 + NP) * a.C * a.K, "wino_filter_kernel<%s, %d>", flip_transpose ? "true" : "false", M);
-        if (flip_transpose) hipLaunchKernelGGL((wino_filter_kernel<true, M>), grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
-        else hipLaunchKernelGGL((wino_filter_kernel<false, M>), grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
+        PnpProfScope ps(cls, st, 0.0, (36.0 + eb * NP) * a.C * a.K, "wino_filter_kernel<%s, %d, %s>", flip_transpose ? "true" : "false", M, x3 ? "true" : "false");
+        if (x3) {
+            if (flip_transpose) hipLaunchKernelGGL((wino_filter_kernel<true, M, true>), grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
+            else hipLaunchKernelGGL((wino_filter_kernel<false, M, true>), grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
+        } else if (flip_transpose) hipLaunchKernelGGL((wino_filter_kernel<true, M, false>), grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
+        else hipLaunchKernelGGL((wino_filter_kernel<false, M, false>), grid, dim3(NT), 0, st, a.w, U, a.C, a.K);
         PNP_CHECK_LAUNCH("wino_filter_kernel");
     }
     {
@@ -1183,11 +1268,17 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
         const size_t nvec = (size_t)w.T * (a.C / 4);
         long long nb = (long long)((nvec + NT - 1) / NT);
         if (nb > 65536) nb = 65536;
-        PnpProfScope ps(cls, st, 0.0, 4.0 * ((double)a.N * a.H * a.W * a.C + (double)NP * w.T * a.C), "wino_in_kernel<%d>", M);
-        hipLaunchKernelGGL(wino_in_kernel<M>, dim3((unsigned)nb), dim3(NT), 0, st, ia);
+        PnpProfScope ps(cls, st, 0.0, 4.0 * (double)a.N * a.H * a.W * a.C + (double)eb * NP * w.T * a.C, "wino_in_kernel<%d, %s>", M, x3 ? "true" : "false");
+        if (x3) hipLaunchKernelGGL((wino_in_kernel<M, true>), dim3((unsigned)nb), dim3(NT), 0, st, ia);
+        else hipLaunchKernelGGL((wino_in_kernel<M, false>), dim3((unsigned)nb), dim3(NT), 0, st, ia);
         PNP_CHECK_LAUNCH("wino_in_kernel");
     }
-    {
+    if (x3) {
+        static const int wino_gn3 = env_int("PNP_WINO_GN", -1);
+        const int rc = launch_wino_gemm_x3((const unsigned short*)V, (const unsigned short*)U, Mm, w.T, a.C, a.K, NP, (M == 4 ? 2 : 0) + (kind != 0), wino_gn3 >= 0 ? wino_gn3 : a.gn,
+                                           xcd ? 1 : 0, st);
+        if (rc != PNP_OK) return rc;
+    } else {
         WinoGemmArgs ga{};
         ga.V = V; ga.U = U; ga.Mm = Mm; ga.T = w.T; ga.C = a.C; ga.K = a.K;
         const bool narrow = a.K <= 64;                 // 64 filters: a 128 x 64 tile (a 128-wide one would be half empty)
@@ -1272,8 +1363,8 @@ static int launch_wino_wgrad_m(const ConvArgs& a, float* dw, int accumulate, voi
         ia.x = a.x; ia.V = V; ia.g = w; ia.C = a.C; ia.x_bytes = a.x_bytes; ia.xcd = a.xcd_swizzle ? env_xcd_in() : 0;
         long long nb = (long long)(((size_t)w.T * (a.C / 4) + NT - 1) / NT);
         if (nb > 65536) nb = 65536;
-        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)a.N * a.H * a.W * a.C + (double)NP * w.T * a.C), "wino_in_kernel<%d>", M);
-        hipLaunchKernelGGL(wino_in_kernel<M>, dim3((unsigned)nb), dim3(NT), 0, st, ia);
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)a.N * a.H * a.W * a.C + (double)NP * w.T * a.C), "wino_in_kernel<%d, false>", M);
+        hipLaunchKernelGGL((wino_in_kernel<M, false>), dim3((unsigned)nb), dim3(NT), 0, st, ia);
         PNP_CHECK_LAUNCH("wino_in_kernel");
     }
     {
@@ -1343,11 +1434,19 @@ extern "C" int32_t pnp_conv2d_wino_tile(int32_t tile) {
     return prev;
 }
 
+// arithmetic of the route's forward / data-gradient GEMMs: 0 = fp32 MFMA (wino_gemm_kernel), 1 = split-bf16 operands with chunked
+// accumulation (wino_gemm_x3_kernel); mode < 0 only reads.  Returns the previous mode.  Workspace queries follow the mode in force.
+extern "C" int32_t pnp_conv2d_wino_x3(int32_t mode) {
+    const int prev = wino_x3_mode();
+    if (mode >= 0) g_wino_x3.store(mode > 2 ? 2 : mode, std::memory_order_relaxed);
+    return prev;
+}
+
 // ---- transformed-filter cache: the caller's side -----------------------------------------------------------------------------------------
 // bytes of one (filter, pass) entry that serves either output tile: 36 C K floats; 0: this filter shape never takes the route
 extern "C" size_t pnp_conv2d_wino_filter_bytes(int32_t C, int32_t K) {
     if (C <= 0 || K < 32 || (C % 32) != 0 || (K % 4) != 0) return 0;
-    return (size_t)36 * C * K * sizeof(float);
+    return (size_t)36 * C * K * 6;        // the larger of the two formats: fp32 U (4 bytes per value) / three bf16 planes (6)
 }
 // lend (U != null) or withdraw (U == null) the buffer of filter w's pass (kind 0: forward, 1: data gradient); w == null withdraws every
 // entry.  The buffer must stay allocated until it is withdrawn; a new binding starts invalid.
@@ -1363,7 +1462,7 @@ extern "C" int pnp_conv2d_wino_filter_bind(const float* w, int32_t kind, float* 
         return PNP_OK;
     }
     PNP_REQUIRE(bytes > 0 && ((uintptr_t)U & 15) == 0, "pnp_conv2d_wino_filter_bind: empty or misaligned buffer");
-    g_ucache[{(const void*)w, (int)kind}] = UEntry{U, bytes, false, 0, 0, 0, nullptr};
+    g_ucache[{(const void*)w, (int)kind}] = UEntry{U, bytes, false, 0, 0, 0, nullptr, 0};
     return PNP_OK;
 }
 // the weights in [lo, hi) were written (optimiser / clip kernel queued, host-side load): their entries are stale.  lo == null: all.

@@ -1,0 +1,243 @@
+// conv_wino_x3.hip — the GEMMs of the Winograd F(4x4, 3x3) / F(2x2, 3x3) routes on the bf16 matrix pipe with SPLIT operands ("x3": round 6).
+//
+// gfx950 has no tf32 and v_mfma_f32_32x32x2_f32 runs at 1/16 of v_mfma_f32_32x32x16_bf16's rate (MI355X_MICROARCH.md): the route's fp32
+// GEMMs (conv_wino.hip: wino_gemm_kernel) were 61 % of the joint step's kernel time at 0.73 of a 157 TF/s roof.  A float32 value is the
+// EXACT sum of three bf16 values (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid): 3 x 8 significand bits, every difference exact
+// in fp32), and a bf16 x bf16 product is exact in fp32, so
+//     a b = hi.hi + (hi.mid + mid.hi) + (hi.lo + mid.mid + lo.hi) + [mid.lo + lo.mid + lo.lo  <= 2^-26 |a b|: dropped]
+// — six MFMAs with fp32 accumulation reproduce the fp32 product to 2^-26, BELOW fp32's own rounding of it (2^-24).  The transform kernels
+// write the three planes instead of one fp32 plane (6 instead of 4 bytes per value: wino_in_kernel / wino_filter_kernel / wino_dy_kernel,
+// X3 = true), this file contracts them.  Roof: 2.5 PF / 6 = 417 TF/s fp32-equivalent (2.65x the fp32 MFMA peak).
+//
+// Accuracy is BETTER than the fp32 pipe's, not merely equal: the route's error is the fp32 accumulation chain over the channels in the
+// transform domain (tools/wino_f43_study.py: 6.7e-7 with an fp64 GEMM, 4e-6 with fp32), so the kernel accumulates in CHUNKS of 96 channels:
+// the MFMA accumulator of a chunk is added into a second register set (`total`) and restarted from zero.  tools/wino_bf16x3_study.py ->
+// profiles/r06_wino_bf16x3_tolerance.txt: 512->512 6.1e-6 (fp32 chain) -> 1.1e-6..1.6e-6; 2 560-channel reduction 1.7e-5 -> 1.7e-6.
+//
+// Layout ("stage-major": what ONE stage of a tile reads of one plane is one contiguous run of whole 128-byte lines):
+//          V3 [pos][C / 32][plane][T][32] bf16   (A operand: rows = tiles, reduction index C)
+//          U3 [pos][C / 32][plane][K][32] bf16   (B operand: rows = output columns — the filter transform writes it transposed)
+//          M  [pos][T][K] fp32                   (as the fp32 route's: wino_out_kernel is unchanged)
+// What bounds it (tools/experiments/README.md round 6, tools/experiments/mfma_vmem_overlap.hip): a 128 x 128 tile streams 48 KB per
+// 32-channel stage for 1 536 MFMA cycles per SIMD — 905 MB per 512->512 launch against ~9-10 TB/s that the CUs can pull out of L2 / MALL
+// whatever the access pattern (measured: 2 MB, 12 MB and 64 MB footprints alike) = ~95 us of data movement next to 51 us of MFMAs.  And a
+// wave that issues its own loads does not overlap the two AT ALL (LDS-DMA or register staging alike: T(both) = T(data) + T(MFMA), also
+// in the micro-benchmark): in-order issue parks the wave behind its memory instructions.  So the workgroup is SPECIALISED: waves 0..3
+// only contract (fragments by ds_read_b128, MFMAs, the accumulator chunks), waves 4..7 only stream (LDS-DMA buffer_load_dwordx4 ... lds,
+// no registers, three LDS stages = 144 KB) — the micro-benchmark's 4 + 4 layout runs at the data rate with the MFMAs hidden under it.
+// Stage = 32 channels of all three planes of both operands, LDS image [operand][plane][row][64 B] with conv_bf16r's bank swizzle applied on
+// the source address; one raw s_barrier per stage for all eight waves.  Per 16-channel slice a consumer wave reads 12 fragments for 24 MFMAs.
+// Chunked accumulation: every 64 channels the MFMA accumulator is added into `total` and restarted from zero (first MFMA with C = 0); the
+// adds cost the consumer ~25 % of its time, which the data-bound stage hides.
+#include <type_traits>
+#include "conv_common.h"
+
+using namespace pnpconv;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_void* dst, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+#endif
+}
+// 16-byte chunk swizzle of a 64-byte LDS row (conv_bf16r.hip, BKC = 32)
+__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
+
+struct X3Args {
+    const unsigned short* V;      // [npos][C / 32][3][T][32]
+    const unsigned short* U;      // [npos][C / 32][3][K][32]
+    float* Mm;                    // [npos][T][K]
+    int T, C, K, npos;
+    int nblk_m, nblk_n, gn, xcd;
+};
+
+// 8 waves: consumers 0..3 (2 x 2 wave tiles of BM/2 x BN/2), loaders 4..7.  C a multiple of 64 (a chunk = two stages).
+template <int BM, int BN, int KIND>
+__global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
+    constexpr int NBUF = 3;
+    constexpr int kTermA[6] = {2, 1, 0, 1, 0, 0}, kTermB[6] = {0, 1, 2, 0, 1, 0};      // the kept products, smallest first: (plane of A, plane of B)
+    constexpr int NL = 4;                      // loader waves
+    constexpr int ROWB = 64, RPI = 16;         // bytes per LDS row (32 bf16), rows per DMA instruction (64 lanes x 16 B = 1 KiB contiguous)
+    constexpr int NPA = 3 * BM / RPI, NPB = 3 * BN / RPI;
+    static_assert(NPA % NL == 0 && NPB % NL == 0, "pieces must split evenly over the loader waves");
+    constexpr int NRA = NPA / NL, NRB = NPB / NL, LPS = NRA + NRB;
+    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
+    constexpr int APL = BM * ROWB, BPL = BN * ROWB;            // bytes per plane image
+    constexpr int STG = 3 * (APL + BPL);
+    static_assert(LPS < 64, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(256))) unsigned char lds[NBUF * STG];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nblk = g.nblk_m * g.nblk_n;
+    int lid = (int)blockIdx.x;
+    if (g.xcd) lid = xcd_remap(lid, (int)gridDim.x);          // an XCD owns a contiguous range of tiles = whole transform points (one L2 holds U[pos], V[pos])
+    const int pos = lid / nblk;
+    int mt, nt;
+    tile_coords(lid - pos * nblk, g.nblk_m, g.nblk_n, g.gn, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nst = g.C / 32;
+
+    if (wave >= 4) {
+        // ================================================= loader =================================================
+        // piece q of an operand = plane q / (rows / 16), row block q % (rows / 16); this wave owns q = i NL + lw.  Lane (lrow, lchk) of a
+        // piece moves 16 bytes: global chunk lchk ^ swz(row) of row lrow (64 contiguous bytes per row) -> LDS lane-linear
+        const int lw = wave - 4;
+        const int lrow = lane >> 2, lchk = lane & 3;
+        unsigned avo[NRA], bvo[NRB];
+        int adst[NRA], bdst[NRB];
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const int q = i * NL + lw, plane = q / (BM / RPI), rb = q % (BM / RPI);
+            const int r = rb * RPI + lrow, m = m0 + r;
+            avo[i] = (m < g.T) ? (unsigned)((plane * g.T + m) * 64 + ((lchk ^ swz(r)) << 4)) : OOB2;
+            adst[i] = plane * APL + rb * (RPI * ROWB);
+        }
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) {
+            const int q = i * NL + lw, plane = q / (BN / RPI), rb = q % (BN / RPI);
+            const int r = rb * RPI + lrow, n = n0 + r;
+            bvo[i] = (n < g.K) ? (unsigned)((plane * g.K + n) * 64 + ((lchk ^ swz(r)) << 4)) : OOB2;
+            bdst[i] = 3 * APL + plane * BPL + rb * (RPI * ROWB);
+        }
+        const size_t planeV = (size_t)3 * g.T * g.C, planeU = (size_t)3 * g.K * g.C;
+        const __amdgpu_buffer_rsrc_t rv = make_rsrc(reinterpret_cast<const float*>(g.V + (size_t)pos * planeV), (unsigned)(planeV * 2));
+        const __amdgpu_buffer_rsrc_t ru = make_rsrc(reinterpret_cast<const float*>(g.U + (size_t)pos * planeU), (unsigned)(planeU * 2));
+        const int sstrideV = 3 * g.T * 64, sstrideU = 3 * g.K * 64;          // bytes per stage (32 channels of the three planes)
+        auto issue = [&](int cc, int buf) {
+            unsigned char* base = lds + buf * STG;
+#pragma unroll
+            for (int i = 0; i < NRA; ++i) dma16(rv, (lds_void*)(base + adst[i]), avo[i], cc * sstrideV);
+#pragma unroll
+            for (int i = 0; i < NRB; ++i) dma16(ru, (lds_void*)(base + bdst[i]), bvo[i], cc * sstrideU);
+        };
+        issue(0, 0);
+        issue(min(1, nst - 1), 1);
+        int nb = 2;
+        for (int j = 0; j < nst; ++j) {
+            wait_vm<LPS>();                      // stage j has landed (stage j + 1 may be in flight)
+            __builtin_amdgcn_s_barrier();        // consumers: done with stage j - 1, i.e. with buffer (j + 2) % 3
+            issue(min(j + 2, nst - 1), nb);      // (past the end: the last stage again, into a buffer nobody reads any more)
+            nb = nb == 2 ? 0 : nb + 1;
+        }
+        wait_vm<0>();
+        return;
+    }
+    // ================================================= consumer =================================================
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    // fragment reads: lane (l31, h) reads row l31 of a 32-row block, 16-byte chunk (2 ks + h) ^ swz(row)
+    const int l31 = lane & 31, h = lane >> 5;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = l31 * ROWB + (((2 * ks + h) ^ swz(l31)) << 4);
+
+    Acc<TM, TN> cur, total;
+    total.zero();
+    int buf = 0;
+    auto stage = [&](auto fc) {
+        constexpr bool first = decltype(fc)::value;
+        wait_lgkm0();                        // own fragment reads of the previous stage have retired
+        __builtin_amdgcn_s_barrier();        // the loaders' part of this stage is in LDS
+        asm volatile("" ::: "memory");
+        const unsigned char* A = lds + buf * STG + wm0 * ROWB;
+        const unsigned char* B = lds + buf * STG + 3 * APL + wn0 * ROWB;
+        bf16x8 af[2][3][TM], bfr[2][3][TN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) af[ks][p][tm] = *reinterpret_cast<const bf16x8*>(A + p * APL + tm * (32 * ROWB) + foff[ks]);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bfr[ks][p][tn] = *reinterpret_cast<const bf16x8*>(B + p * BPL + tn * (32 * ROWB) + foff[ks]);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int tr = 0; tr < 6; ++tr) {
+                const int pa = kTermA[tr], pb = kTermB[tr];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        if (first && ks == 0 && tr == 0) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            cur.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][pa][tm], bfr[ks][pb][tn], z, 0, 0, 0);
+                        } else {
+                            cur.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][pa][tm], bfr[ks][pb][tn], cur.v[tm][tn], 0, 0, 0);
+                        }
+                    }
+            }
+        buf = buf == 2 ? 0 : buf + 1;
+    };
+    for (int j = 0; j < nst; j += 2) {          // one accumulation chunk = two stages = 64 channels (host: C % 64 == 0)
+        stage(std::true_type{});
+        stage(std::false_type{});
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) total.v[tm][tn] += cur.v[tm][tn];
+    }
+    ConvArgs e{};            // plain [T][K] rows of a transform point: conv_epilogue with every feature off
+    e.M = g.T;
+    e.K = g.K;
+    e.nsplit = 1;
+    conv_epilogue<TM, TN>(e, total, g.Mm + (size_t)pos * g.T * g.K, m0, n0, wm0, wn0, lane, 0);
+}
+
+}  // namespace
+
+namespace pnpconv {
+
+bool wino_x3_dims_ok(int T, int C, int K) {
+    // one buffer descriptor per operand and transform point: 3 planes of T x C (K x C) bf16 below 2 GiB
+    return (C % 64) == 0 && (double)T * C * 6.0 < 2147483648.0 && (double)K * C * 6.0 < 2147483648.0;
+}
+
+// sym = 0 / 1: F(2x2) forward / data gradient, 2 / 3: F(4x4) (names the symbol like wino_gemm_kernel's last template argument)
+int launch_wino_gemm_x3(const unsigned short* V3, const unsigned short* U3, float* Mm, int T, int C, int K, int npos, int sym, int gn, int xcd,
+                        hipStream_t st) {
+    PNP_REQUIRE(wino_x3_dims_ok(T, C, K), "launch_wino_gemm_x3: operands too large for one buffer descriptor per transform point");
+    PNP_REQUIRE(sym >= 0 && sym < 4, "launch_wino_gemm_x3: bad symbol index");
+    X3Args g{};
+    g.V = V3; g.U = U3; g.Mm = Mm; g.T = T; g.C = C; g.K = K; g.npos = npos;
+    const bool narrow = K <= 64;
+    g.nblk_m = pnp_cdiv(T, 128); g.nblk_n = pnp_cdiv(K, narrow ? 64 : 128);
+    g.gn = gn; g.xcd = xcd ? 1 : 0;
+    const dim3 grid((unsigned)(g.nblk_m * g.nblk_n * npos));
+    // flops = the bf16 MFMA flops the kernel EXECUTES (six products per fp32 multiply-add): its roof is the dense bf16 peak
+    const double fl = 6.0 * 2.0 * npos * (double)T * C * K;
+    const double by = (double)npos * (6.0 * ((double)T * C + (double)C * K) + 4.0 * (double)T * K);
+    PnpProfScope ps(prof_class(sym & 1), st, fl, by, "wino_gemm_x3_kernel<128, %d, %d>", narrow ? 64 : 128, sym);
+#define PNP_X3_LAUNCH(BN_, SYM_) hipLaunchKernelGGL((wino_gemm_x3_kernel<128, BN_, SYM_>), grid, dim3(512), 0, st, g)
+    if (narrow) {
+        switch (sym) {
+            case 0: PNP_X3_LAUNCH(64, 0); break;
+            case 1: PNP_X3_LAUNCH(64, 1); break;
+            case 2: PNP_X3_LAUNCH(64, 2); break;
+            default: PNP_X3_LAUNCH(64, 3); break;
+        }
+    } else {
+        switch (sym) {
+            case 0: PNP_X3_LAUNCH(128, 0); break;
+            case 1: PNP_X3_LAUNCH(128, 1); break;
+            case 2: PNP_X3_LAUNCH(128, 2); break;
+            default: PNP_X3_LAUNCH(128, 3); break;
+        }
+    }
+#undef PNP_X3_LAUNCH
+    PNP_CHECK_LAUNCH("wino_gemm_x3_kernel");
+    return PNP_OK;
+}
+
+}  // namespace pnpconv

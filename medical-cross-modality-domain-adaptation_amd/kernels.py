@@ -128,6 +128,13 @@ def wino_tile(tile=-1):
     return int(_lib.load().pnp_conv2d_wino_tile(int(tile)))
 
 
+def wino_x3(mode=-1):
+    """arithmetic of the route's forward / data-gradient GEMMs: 0 = fp32 matrix pipe, 1 = split-bf16 operands (three bf16 planes per value,
+    six MFMA products, fp32 accumulation in 64-channel chunks: csrc/conv_wino_x3.hip) where it pays (reductions over >= 256 channels), 2 =
+    wherever the shapes allow; returns the previous mode (mode < 0: read only)"""
+    return int(_lib.load().pnp_conv2d_wino_x3(int(mode)))
+
+
 def wino_chosen(g, kind=0):
     """pnp_conv2d_fwd* (kind 0) / pnp_conv2d_dgrad* (kind 1) / pnp_conv2d_wgrad* (kind 2) of this layer (g = the forward geometry): 0 = the
     direct kernels, else the output tile edge of the Winograd route (2 or 4) — truthy exactly when the layer is on the route"""

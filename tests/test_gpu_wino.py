@@ -44,20 +44,31 @@ def _ran(L, fn, cls):
     return out, [r["name"] for r in L.prof_summary()]
 
 
-@pytest.fixture(params=[2, 4], ids=["F2x2", "F4x4"])
+@pytest.fixture(params=[(2, 0), (4, 0), (2, 1), (4, 1)], ids=["F2x2", "F4x4", "F2x2-x3", "F4x4-x3"])
 def wino(request):
-    """yields a setter of the route policy with the output tile of this run in force (wino.tile); restores the modes in force before the
-    test (forward / data gradient, filter gradient, tile)"""
+    """yields a setter of the route policy with the output tile (wino.tile) and the GEMM arithmetic (wino.x3: 0 = fp32 matrix pipe, 1 =
+    split-bf16 operands, csrc/conv_wino_x3.hip) of this run in force; restores the modes in force before the test"""
     K = pkg("kernels")
-    prev, prev_w, prev_t = K.wino_mode(-1), K.wino_wgrad_mode(-1), K.wino_tile(request.param)
+    tile, x3 = request.param
+    prev, prev_w, prev_t, prev_x = K.wino_mode(-1), K.wino_wgrad_mode(-1), K.wino_tile(tile), K.wino_x3(2 if x3 else 0)        # (2: wherever the shapes allow)
 
     def setter(mode):
         return K.wino_mode(mode)
-    setter.tile = request.param
+    setter.tile = tile
+    setter.x3 = x3
     yield setter
     K.wino_mode(prev)
     K.wino_wgrad_mode(prev_w)
     K.wino_tile(prev_t)
+    K.wino_x3(prev_x)
+
+
+def _route_names(tile, x3, trans, bn, sym):
+    """kernel symbols of one forward / data-gradient launch of the route"""
+    b = "true" if x3 else "false"
+    gemm = ("wino_gemm_x3_kernel<128, %d, %d>" if x3 else "wino_gemm_kernel<128, %d, 2, 2, %d>") % (bn, sym)
+    return sorted(["wino_filter_kernel<%s, %d, %s>" % ("true" if trans else "false", tile, b), gemm, "wino_in_kernel<%d, %s>" % (tile, b),
+                   "wino_out_kernel<%d>" % tile])
 
 
 def _where(err, K_):
@@ -92,18 +103,19 @@ def test_winograd_fwd_dgrad_vs_float64_and_direct(dev, wino, case):
     dx0 = K.conv2d_dgrad(dyd, wd, g)
     assert not any("wino" in n for n in names0), names0
     wino(2)
-    # (F(4x4) does not take reductions over more than 1 024 channels: group_10's data gradient runs on F(2x2) whatever the mode)
-    tile_d = 2 if (wino.tile == 4 and Kf > 1024) else wino.tile
+    # (on the fp32 matrix pipe F(4x4) does not take reductions over more than 1 024 channels: group_10's data gradient runs on F(2x2)
+    # whatever the mode; the split-bf16 GEMM accumulates in 96-channel chunks and has no such cap)
+    # (the split-bf16 GEMM takes reductions over a multiple of 64 channels; the others keep the fp32 pipe)
+    x3f, x3d = bool(wino.x3 and C % 64 == 0), bool(wino.x3 and Kf % 64 == 0)
+    tile_d = 2 if (wino.tile == 4 and Kf > 1024 and not x3d) else wino.tile
     assert K.wino_chosen(g, 0) == wino.tile and K.wino_chosen(g, 1) == tile_d
     y1, names1 = _ran(L, lambda: K.conv2d_fwd(xd, wd, g), L.PROF_CONV_FWD)
-    kb = 0 if wino.tile == 2 else 2          # wino_gemm_kernel<.., 0 / 1>: F(2x2) forward / data gradient, <.., 2 / 3>: F(4x4)
+    kb = 0 if wino.tile == 2 else 2          # wino_gemm[_x3]_kernel<.., 0 / 1>: F(2x2) forward / data gradient, <.., 2 / 3>: F(4x4)
     # (128 x 64 GEMM tiles where the GEMM has <= 64 columns: the forward's filters, the data gradient's channels)
-    want = ["wino_filter_kernel<false, %d>", "wino_gemm_kernel<128, %d, 2, 2, %d>" % (64 if Kf <= 64 else 128, kb), "wino_in_kernel<%d>", "wino_out_kernel<%d>"]
-    assert sorted(names1) == [n % wino.tile if "%d" in n else n for n in want], names1
+    assert sorted(names1) == _route_names(wino.tile, x3f, False, 64 if Kf <= 64 else 128, kb), names1
     dx1, names2 = _ran(L, lambda: K.conv2d_dgrad(dyd, wd, g), L.PROF_CONV_DGRAD)
     kbd = 0 if tile_d == 2 else 2
-    want = ["wino_filter_kernel<true, %d>", "wino_gemm_kernel<128, %d, 2, 2, %d>" % (64 if C <= 64 else 128, kbd + 1), "wino_in_kernel<%d>", "wino_out_kernel<%d>"]
-    assert sorted(names2) == [n % tile_d if "%d" in n else n for n in want], names2
+    assert sorted(names2) == _route_names(tile_d, x3d, True, 64 if C <= 64 else 128, kbd + 1), names2
     dxr = K.conv2d_dgrad(dyd, wd, g, residual=resd)
     # the filter gradient on the route (its own switch): plain and added into a buffer that already holds a contribution
     wg = torch.from_numpy(w).double().requires_grad_(True)
@@ -116,13 +128,13 @@ def test_winograd_fwd_dgrad_vs_float64_and_direct(dev, wino, case):
     dw1, names3 = _ran(L, lambda: K.conv2d_wgrad(xd, dyd, g), L.PROF_CONV_WGRAD)
     # (+ wino_splitsum_kernel where a narrow layer's reduction is split many ways)
     assert sorted(n for n in names3 if n != "wino_splitsum_kernel") == [n % wino.tile for n in (
-        "wino_dy_kernel<%d>", "wino_in_kernel<%d>", "wino_wgrad_gemm_kernel<128, 128, 2, 2, %d>", "wino_wgrad_out_kernel<%d>")], names3
+        "wino_dy_kernel<%d>", "wino_in_kernel<%d, false>", "wino_wgrad_gemm_kernel<128, 128, 2, 2, %d>", "wino_wgrad_out_kernel<%d>")], names3
     held = torch.from_numpy(rng.standard_normal(w.shape).astype(np.float32)).to(dev)
     dwa = K.conv2d_wgrad(xd, dyd, g, into=held.clone())
     errs = {"y direct": _rel(y0, yo), "y wino": _rel(y1, yo), "dx direct": _rel(dx0, xg.grad), "dx wino": _rel(dx1, xg.grad),
             "dx+res wino": _rel(dxr, xg.grad + torch.from_numpy(res).double()), "dw direct": _rel(dw0, wg.grad), "dw wino": _rel(dw1, wg.grad),
             "dw+held wino": _rel(dwa, wg.grad + held.cpu().double())}
-    print("wino F(%dx%d) %s: %s" % (wino.tile, wino.tile, case, {k: "%.2e" % v for k, v in errs.items()}))
+    print("wino F(%dx%d)%s %s: %s" % (wino.tile, wino.tile, " x3" if wino.x3 else "", case, {k: "%.2e" % v for k, v in errs.items()}))
     if errs["y wino"] > BAR:
         print("  forward mismatch:", _where(y1.cpu().double() - yo.detach(), Kf))
     if errs["dx wino"] > BAR:
@@ -198,10 +210,11 @@ def test_segmenter_step_on_the_winograd_route(dev, wino):
     assert not any("wino" in n for n in n0)
     assert any(n.startswith("wino_wgrad_gemm_kernel") for n in n1), sorted(set(n1))
     kb = 0 if wino.tile == 2 else 2
-    assert any(n.startswith("wino_gemm_kernel<128, 128, 2, 2, %d>" % kb) for n in n1) and any(n.startswith("wino_gemm_kernel<128, 128, 2, 2, %d>" % (kb + 1)) for n in n1), sorted(set(n1))
+    gk = "wino_gemm_x3_kernel<128, 128, %d>" if wino.x3 else "wino_gemm_kernel<128, 128, 2, 2, %d>"
+    assert any(n.startswith(gk % kb) for n in n1) and any(n.startswith(gk % (kb + 1)) for n in n1), sorted(set(n1))
     cos = float(torch.nn.functional.cosine_similarity(g0.double().flatten(), g1.double().flatten(), dim=0))
     cw = float(torch.nn.functional.cosine_similarity(w0.double().flatten(), w1.double().flatten(), dim=0))
-    print("segmenter step, Winograd F(%dx%d) route vs direct: loss %.7f vs %.7f, gradient cosine %.8f, weights-after-Adam cosine %.8f" % (wino.tile, wino.tile, l1, l0, cos, cw))
+    print("segmenter step, Winograd F(%dx%d)%s route vs direct: loss %.7f vs %.7f, gradient cosine %.8f, weights-after-Adam cosine %.8f" % (wino.tile, wino.tile, " x3" if wino.x3 else "", l1, l0, cos, cw))
     assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0)) and cos > 0.99999 and cw > 0.999999
 
 

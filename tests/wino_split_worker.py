@@ -23,6 +23,7 @@ def main():
     rng = np.random.default_rng(0)
     K.wino_mode(2)
     K.wino_tile(4)
+    K.wino_x3(0)                # the persistent launch and its tail split belong to the fp32-pipe GEMM (wino_gemm_kernel)
     worst = 0.0
     # (N, H, C, K, dilation, padding, pieces per tail tile when the split is on: tiles / 8 per XCD = whole rounds of 64 + R, s R <= 64)
     for (N, H, C, Kf, dil, pad, s_want) in ((16, 32, 512, 512, 1, "SAME", 4), (16, 32, 256, 256, 1, "SAME", 4), (8, 32, 512, 512, 2, "SAME", 8),

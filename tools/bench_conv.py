@@ -19,6 +19,8 @@ if os.environ.get("WINO_WGRAD") is not None:    # the same for the filter gradie
     K.wino_wgrad_mode(int(os.environ["WINO_WGRAD"]))
 if os.environ.get("TILE") is not None:          # largest output tile of the route: 2 = F(2x2, 3x3) only, 4 = F(4x4, 3x3) first
     K.wino_tile(int(os.environ["TILE"]))
+if os.environ.get("X3") is not None:            # arithmetic of the route's GEMMs: 0 fp32 matrix pipe, 1 split-bf16 operands (csrc/conv_wino_x3.hip)
+    K.wino_x3(int(os.environ["X3"]))
 SKIP_WGRAD = bool(os.environ.get("SKIP_WGRAD"))
 PROF = bool(os.environ.get("PROF"))             # after each layer's line: one more pass of each kind with the library's per-launch HIP events, per kernel symbol
 LAYERS = [  # name, H, C, K, R, dil, padding, count in segmenter fwd
