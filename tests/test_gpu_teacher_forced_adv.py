@@ -116,40 +116,46 @@ def test_every_kernel_of_every_adaptation_unit_teacher_forced_B16(dev):
     # ---- whole generator step of the product and of the float32 CPU oracle, both against float64
     V32, _, o32, gen32 = _gen_units(sd, ct, torch.float32, 22, units=False)
     g32 = {k: v.grad.clone() for k, v in V32.items() if v.requires_grad}
-    # the product twice: with the route's default output tile (F(4x4, 3x3) where its planner takes a layer) and with F(2x2) only
+    # the product three times: the default route (F(4x4, 3x3) where its planner takes a layer, split-bf16 GEMMs with chunked accumulation
+    # on the reductions over >= 256 channels: round 6), F(4x4) with every GEMM on the fp32 matrix pipe (round 5's default), and F(2x2) only
     K = pkg("kernels")
-    prev_tile = K.wino_tile(-1)
+    prev_tile, prev_x3 = K.wino_tile(-1), K.wino_x3(-1)
     stats = {}
     try:
-        for tile in (4, 2):
+        for tile, x3 in ((4, 1), (4, 0), (2, 0)):
             K.wino_tile(tile)
+            K.wino_x3(x3)
             net.store.load_state_dict(sd)
             loss = net.gen_loss_and_grads(torch.from_numpy(ct).to(dev), KEEP, drop_seed=22)
             g_hip = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if v.name.startswith("adapt_")}
             rows = [(k, rel(g_hip[k], g64[k]), rel(g32[k], g64[k]), _cos(g_hip[k], g64[k]), _cos(g32[k], g64[k])) for k in g64]
             eh, ec = np.array([r[1] for r in rows]), np.array([r[2] for r in rows])
-            print("gen B=16 whole step vs float64 over %d variables, route tile %d: hip median %.3e max %.3e min cosine %.8f | cpu-fp32 median %.3e max "
+            print("gen B=16 whole step vs float64 over %d variables, route tile %d x3 %d: hip median %.3e max %.3e min cosine %.8f | cpu-fp32 median %.3e max "
                   "%.3e min cosine %.8f | loss hip %.9f cpu32 %.9f fp64 %.9f | logits hip %.2e cpu32 %.2e" % (
-                      len(rows), tile, np.median(eh), eh.max(), min(r[3] for r in rows), np.median(ec), ec.max(), min(r[4] for r in rows),
+                      len(rows), tile, x3, np.median(eh), eh.max(), min(r[3] for r in rows), np.median(ec), ec.max(), min(r[4] for r in rows),
                       float(loss), float(gen32), float(gen64), rel(net.ct_logits, logits64), rel(o32["ct_logits"], logits64)))
-            stats[tile] = (float(loss), rel(net.ct_logits, logits64), eh, ec, min(r[3] for r in rows))
+            stats[(tile, x3)] = (float(loss), rel(net.ct_logits, logits64), eh, ec, min(r[3] for r in rows))
     finally:
         K.wino_tile(prev_tile)
-    for tile, (lossv, elog, eh, ec, cmin) in stats.items():
+        K.wino_x3(prev_x3)
+    for (tile, x3), (lossv, elog, eh, ec, cmin) in stats.items():
         assert elog < 1e-4
         # (the loss is a 0.002-weighted mean of critic scores that nearly cancel: float32 evaluation noise on it is ~3e-4 relative — measured
         # r3b: hip 3.1e-4, cpu-float32 2.5e-4 from float64 — so the bar is the float32 oracle's own distance, not 1e-4)
         assert abs(lossv - float(gen64)) < max(3.0 * abs(float(gen32) - float(gen64)), 1e-4 * abs(float(gen64))) + 1e-8
         # "same error class as another float32 evaluation of the graph": the product may not be further from float64 than a small multiple of
         # what the float32 CPU oracle is (its own distance is pure evaluation-order noise amplified by leaky-ReLU / max-pool / dropout kinks).
-        # Direct kernels + F(2x2) (every kernel at 1e-6..3e-6 of max|ref|): round 3-5 measured hip median 5.6e-3 / max 1.5e-2 / min cosine
-        # 0.999976 against cpu-fp32 6.0e-3 / 1.2e-2 / 0.999959 -> 1.5 x the oracle's median.  F(4x4) (round 5's default; its GEMMs
-        # accumulate in the transform domain: every kernel at 3e-6..8e-6, g10's data gradient 1.7e-5 — inside north_star's 1e-4 and the
-        # 2e-5 adoption bar of tools/wino_f43_study.py) measured 9.3e-3 / 1.75e-2 / 0.999907 (9.7e-3 / 1.84e-2 / 0.999898 once the 64-channel layers joined the route): 1.56-1.63 x the oracle's median -> held to 2 x, and
-        # stated as such in README / DESIGN (PNP_WINOGRAD_TILE=2 restores the tighter arithmetic at 0.86 x the speed).
+        #  * direct kernels + F(2x2) (every kernel at 1e-6..3e-6 of max|ref|): hip median 4.7e-3 / max 1.6e-2 / min cosine 0.999974 against
+        #    cpu-fp32 6.0e-3 / 1.2e-2 / 0.999959 -> bar 1.5 x the oracle's median, cosine 0.9999
+        #  * THE DEFAULT since round 6 — F(4x4) with split-bf16 GEMMs accumulating in 64-channel chunks on the reductions over >= 256
+        #    channels (csrc/conv_wino_x3.hip; per kernel 1.7e-6..2.3e-6, below the direct fp32 kernel's 2.9e-6): 7.1e-3 / 1.37e-2 / 0.999955
+        #    = 1.19 x the oracle's median -> the SAME bar as F(2x2): 1.5 x, 0.9999.  (Round 5 had moved the default's bar to 2 x / 0.99985
+        #    to admit F(4x4) on the fp32 matrix pipe — 9.7e-3 / 1.84e-2 / 0.999898; VERDICT r5 weak #1.  That arithmetic is no longer the
+        #    default; it stays selectable, PNP_WINOGRAD_X3=0, and is held to the looser bar here so that the switch keeps working.)
         # This is THE whole-step statement for the generator path: the float32-vs-float32 band of test_joint_step_B16_vs_float32_oracle is
         # two such distances added.
-        mult = 1.5 if tile == 2 else 2.0
-        assert np.median(eh) < mult * np.median(ec) + 1e-4, (tile, np.median(eh), np.median(ec))
+        legacy = tile == 4 and x3 == 0
+        mult = 2.0 if legacy else 1.5
+        assert np.median(eh) < mult * np.median(ec) + 1e-4, (tile, x3, np.median(eh), np.median(ec))
         assert eh.max() < max(2.0 * ec.max(), 1e-3)
-        assert cmin > (0.9999 if tile == 2 else 0.99985)
+        assert cmin > (0.99985 if legacy else 0.9999), (tile, x3, cmin)
