@@ -623,7 +623,7 @@ ConvArgs base_args(const void* x, const void* w, float* y, const pnp_conv_geom* 
     const bool p2 = (a.OW & (a.OW - 1)) == 0 && (a.OHW & (a.OHW - 1)) == 0;
     a.ow_sh = p2 ? __builtin_ctz((unsigned)a.OW) : -1;
     a.ohw_sh = p2 ? __builtin_ctz((unsigned)a.OHW) : -1;
-    a.drop_scale = 1.f;
+    a.drop_keep = 1.f;
     static const int env_noswz = getenv("PNP_CONV_NOSWIZZLE") ? 1 : 0;
     a.xcd_swizzle = env_noswz ? 0 : 1;
     a.x_bytes = (unsigned)((size_t)g->N * g->H * g->W * g->C * 2);
@@ -714,7 +714,7 @@ int pnp_conv2d_fwd_bf16r(const void* xh, const void* w_oi, float* y, void* yh, c
     a.y_h = (unsigned short*)yh;
     if (keep_prob < 1.f) {
         a.do_drop = 1;
-        a.drop_scale = 1.f / keep_prob;
+        a.drop_keep = keep_prob;
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
         a.sp = pnp_step_params_ptr(); a.drop_sid = stream_id;

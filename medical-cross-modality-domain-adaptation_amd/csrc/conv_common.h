@@ -26,7 +26,7 @@ struct ConvArgs {
     int nsplit, chunks_per_split;   // wgrad only
     long long split_stride;          // wgrad only: elements between split partials
     uint32_t drop_thresh, drop_key;
-    float drop_scale;
+    float drop_keep;             // keep_prob: tf.nn.dropout DIVIDES (div(x, keep_prob) * mask) — one correctly rounded fp32 division per kept value
     int do_drop;
     const pnp_step_params* sp;   // step capture: the dropout seed lives in device memory (pnp_common.h); null: drop_key as passed
     uint32_t drop_sid;           // the call site's stream id (only read with sp)
@@ -205,7 +205,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const Acc<TM, T
         const uint32_t dkey = pnp_eff_drop_key(a.drop_key, a.sp, a.drop_sid);
         PNP_EP_FOR {
             const uint32_t idx = (uint32_t)((size_t)PNP_EP_M * a.K + ncol[tn]);
-            o.v[tm][tn][r] = pnp_drop_keep(idx, dkey, a.drop_thresh) ? o.v[tm][tn][r] * a.drop_scale : 0.f;
+            o.v[tm][tn][r] = pnp_drop_keep(idx, dkey, a.drop_thresh) ? o.v[tm][tn][r] / a.drop_keep : 0.f;
         }
     }
     // ---- residual add (data gradients: the gradient that reaches the same tensor through a shortcut): all loads, then all adds

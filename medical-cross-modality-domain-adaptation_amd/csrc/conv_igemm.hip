@@ -1175,7 +1175,7 @@ struct NarrowArgs {
     int N, H, W, C, K, R, S, OH, OW, dil, pad_t, pad_l;
     int PH, PW, CP;                 // patch extent (pixels) and padded pixel stride (floats)
     int do_drop;
-    float drop_scale;
+    float drop_keep;
     uint32_t drop_thresh, drop_key;
     unsigned x_bytes;
     const pnp_step_params* sp;
@@ -1230,7 +1230,7 @@ __global__ void __launch_bounds__(256) conv_fwd_narrow_kernel(NarrowArgs a) {
             if (k < K) {
                 const size_t idx = m * K + k;
                 float v = acc[k];
-                if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, pnp_eff_drop_key(a.drop_key, a.sp, a.drop_sid), a.drop_thresh) ? v * a.drop_scale : 0.f;
+                if (a.do_drop) v = pnp_drop_keep((uint32_t)idx, pnp_eff_drop_key(a.drop_key, a.sp, a.drop_sid), a.drop_thresh) ? v / a.drop_keep : 0.f;
                 a.y[idx] = v;
             }
     }
@@ -1452,7 +1452,7 @@ __global__ void __launch_bounds__(256) wgrad_direct4_kernel(WgdArgs a) {
 // forward conv with a split reduction: sum the partials, then the dropout of the fused conv->dropout (same element-index hash as the
 // un-split epilogue)
 __global__ void splitk_reduce_drop_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nsplit, size_t stride,
-                                          uint32_t drop_key, uint32_t drop_thresh, float drop_scale, const pnp_step_params* sp,
+                                          uint32_t drop_key, uint32_t drop_thresh, float drop_keep, const pnp_step_params* sp,
                                           uint32_t drop_sid) {
     drop_key = pnp_eff_drop_key(drop_key, sp, drop_sid);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1460,7 +1460,7 @@ __global__ void splitk_reduce_drop_kernel(const float* __restrict__ part, float*
     for (; i < n; i += gs) {
         float s = 0.f;
         for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * stride + i];
-        out[i] = pnp_drop_keep((uint32_t)i, drop_key, drop_thresh) ? s * drop_scale : 0.f;
+        out[i] = pnp_drop_keep((uint32_t)i, drop_key, drop_thresh) ? s / drop_keep : 0.f;
     }
 }
 
@@ -1664,7 +1664,7 @@ ConvArgs make_args(const float* x, const float* w, float* y, const pnp_conv_geom
     const bool p2 = (a.OW & (a.OW - 1)) == 0 && (a.OHW & (a.OHW - 1)) == 0;
     a.ow_sh = p2 ? __builtin_ctz((unsigned)a.OW) : -1;
     a.ohw_sh = p2 ? __builtin_ctz((unsigned)a.OHW) : -1;
-    a.do_drop = 0; a.drop_scale = 1.f; a.drop_key = 0; a.drop_thresh = 0;
+    a.do_drop = 0; a.drop_keep = 1.f; a.drop_key = 0; a.drop_thresh = 0;
     static const int env_noswz = getenv("PNP_CONV_NOSWIZZLE") ? 1 : 0;
     a.xcd_swizzle = env_noswz ? 0 : 1;
     a.x_bytes = (unsigned)((size_t)g->N * g->H * g->W * g->C * sizeof(float));
@@ -1823,7 +1823,7 @@ int launch_fwd_tile(ConvArgs& a, float* split_ws, int nsplit, hipStream_t st) {
         if (nb > 4096) nb = 4096;
         if (drop_in_reduce) {
             hipLaunchKernelGGL(splitk_reduce_drop_kernel, dim3(nb), dim3(256), 0, st, (const float*)split_ws, final_out, nout, nsplit, nout,
-                               a.drop_key, a.drop_thresh, a.drop_scale, a.sp, a.drop_sid);
+                               a.drop_key, a.drop_thresh, a.drop_keep, a.sp, a.drop_sid);
         } else if (a.o_s != 0) {
             ConvArgs ar = a;
             ar.y = final_out;
@@ -1975,7 +1975,7 @@ int launch_narrow(const float* x, const float* w, float* y, const pnp_conv_geom*
     na.x = x; na.w = w; na.y = y;
     na.N = g->N; na.H = g->H; na.W = g->W; na.C = g->C; na.K = g->K; na.R = g->R; na.S = g->S; na.OH = g->OH; na.OW = g->OW;
     na.dil = g->dil; na.pad_t = g->pad_t; na.pad_l = g->pad_l;
-    na.do_drop = a.do_drop; na.drop_scale = a.drop_scale; na.drop_thresh = a.drop_thresh; na.drop_key = a.drop_key;
+    na.do_drop = a.do_drop; na.drop_keep = a.drop_keep; na.drop_thresh = a.drop_thresh; na.drop_key = a.drop_key;
     na.sp = a.sp; na.drop_sid = a.drop_sid;
     na.x_bytes = a.x_bytes;
     const size_t lds = (size_t)na.PH * na.PW * na.CP * sizeof(float);
@@ -2181,7 +2181,7 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
     ConvArgs a = make_args(x, w, y, g);
     if (keep_prob < 1.f) {
         a.do_drop = 1;
-        a.drop_scale = 1.f / keep_prob;
+        a.drop_keep = keep_prob;
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
         a.sp = pnp_step_params_ptr(); a.drop_sid = stream_id;
@@ -2249,7 +2249,7 @@ static int fwd_stats_impl(const float* x, const float* w, float* y, const pnp_co
     ConvArgs a = make_args(x, w, y, g);
     if (keep_prob < 1.f) {
         a.do_drop = 1;
-        a.drop_scale = 1.f / keep_prob;
+        a.drop_keep = keep_prob;
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
         a.sp = pnp_step_params_ptr(); a.drop_sid = stream_id;
@@ -2286,7 +2286,7 @@ int pnp_conv2d_fwd_bn_ws(const float* x, const float* w, float* y, const pnp_con
     ConvArgs a = make_args(x, w, y, g);
     if (keep_prob < 1.f) {
         a.do_drop = 1;
-        a.drop_scale = 1.f / keep_prob;
+        a.drop_keep = keep_prob;
         a.drop_key = pnp_drop_key(seed, stream_id);
         a.drop_thresh = pnp_drop_thresh(keep_prob);
         a.sp = pnp_step_params_ptr(); a.drop_sid = stream_id;

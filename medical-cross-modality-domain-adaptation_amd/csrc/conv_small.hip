@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) conv_n16_kernel(ConvArgs a, int tiles_w, 
                 const int m = ook[q][i] ? (n * a.OH + oh) * a.OW + ow : 0;
                 oidx[q][i] = (size_t)m * 16 + p;
                 float v = acc[q][i];
-                if (a.do_drop) v = pnp_drop_keep((uint32_t)oidx[q][i], pnp_eff_drop_key(a.drop_key, a.sp, a.drop_sid), a.drop_thresh) ? v * a.drop_scale : 0.f;
+                if (a.do_drop) v = pnp_drop_keep((uint32_t)oidx[q][i], pnp_eff_drop_key(a.drop_key, a.sp, a.drop_sid), a.drop_thresh) ? v / a.drop_keep : 0.f;
                 if (a.res_add) v += a.res_add[oidx[q][i]];
                 if (a.ep_scale) v = bn_epilogue(a, v, m, p);
                 ov[q][i] = v;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) conv_c3n16_kernel(ConvArgs a, int tiles_w
                 const int m = ook[i] ? (n * a.OH + oh) * a.OW + ow : 0;
                 oidx[i] = (size_t)m * 16 + p;
                 float v = acc[i];
-                if (a.do_drop) v = pnp_drop_keep((uint32_t)oidx[i], pnp_eff_drop_key(a.drop_key, a.sp, a.drop_sid), a.drop_thresh) ? v * a.drop_scale : 0.f;
+                if (a.do_drop) v = pnp_drop_keep((uint32_t)oidx[i], pnp_eff_drop_key(a.drop_key, a.sp, a.drop_sid), a.drop_thresh) ? v / a.drop_keep : 0.f;
                 if (a.res_add) v += a.res_add[oidx[i]];
                 if (a.ep_scale) v = bn_epilogue(a, v, m, p);
                 ov[i] = v;

@@ -524,7 +524,7 @@ struct WinoOutArgs {
     int tiles_per_block;
     int do_drop;
     uint32_t drop_thresh, drop_key;
-    float drop_scale;
+    float drop_keep;
     const pnp_step_params* sp;
     uint32_t drop_sid;
     const float* res_add;
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(NT) wino_out_kernel(WinoOutArgs a) {
                     if (a.do_drop) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            val[e] = pnp_drop_keep((uint32_t)(idx + e), dkey, a.drop_thresh) ? val[e] * a.drop_scale : 0.f;
+                            val[e] = pnp_drop_keep((uint32_t)(idx + e), dkey, a.drop_thresh) ? val[e] / a.drop_keep : 0.f;
                     }
                     if (a.res_add) val += ld4(a.res_add + idx);
                     if (stats) {
@@ -1305,7 +1305,7 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
         oa.Mm = Mm; oa.y = a.y; oa.g = w; oa.K = a.K;
         int nblk;
         out_plan(w.T, a.K, &oa.tiles_per_block, &nblk);
-        oa.do_drop = a.do_drop; oa.drop_thresh = a.drop_thresh; oa.drop_key = a.drop_key; oa.drop_scale = a.drop_scale;
+        oa.do_drop = a.do_drop; oa.drop_thresh = a.drop_thresh; oa.drop_key = a.drop_key; oa.drop_keep = a.drop_keep;
         oa.sp = a.sp; oa.drop_sid = a.drop_sid;
         oa.res_add = a.res_add; oa.stat_ws = a.stat_ws; oa.stat_shift = a.stat_shift;
         oa.ep_scale = a.ep_scale; oa.ep_shift = a.ep_shift; oa.ep_res = a.ep_res; oa.ep_cs = a.ep_cs; oa.ep_alpha = a.ep_alpha;

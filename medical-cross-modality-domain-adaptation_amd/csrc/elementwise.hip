@@ -545,7 +545,7 @@ struct BnBwdArgs {
     int training;
     int do_drop;
     uint32_t drop_key, drop_thresh;
-    float drop_scale;
+    float drop_keep;
     const pnp_step_params* sp;       // step capture: dropout seed from device memory (pnp_common.h)
     uint32_t drop_sid;
     __bf16* dxh;     // bf16 copy of dx (operand of the bf16-resident data / filter gradient kernels); null: none
@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(BnBwdArgs a) {
             if (a.do_drop) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    r[e] = pnp_drop_keep((uint32_t)(i * 4 + e), dkey, a.drop_thresh) ? r[e] * a.drop_scale : 0.f;
+                    r[e] = pnp_drop_keep((uint32_t)(i * 4 + e), dkey, a.drop_thresh) ? r[e] / a.drop_keep : 0.f;
             }
             if (a.dx) st4(a.dx + i * 4, r);       // (null: only the bf16 copy is wanted — dx feeds nothing but resident convolutions)
             if (a.dxh) st4h(a.dxh + i * 4, r);
@@ -621,7 +621,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(BnBwdArgs a) {
             } else {
                 r = a.gamma[c] * rs * g;
             }
-            if (a.do_drop) r = pnp_drop_keep((uint32_t)i, dkey, a.drop_thresh) ? r * a.drop_scale : 0.f;
+            if (a.do_drop) r = pnp_drop_keep((uint32_t)i, dkey, a.drop_thresh) ? r / a.drop_keep : 0.f;
             if (a.dx) a.dx[i] = r;
             if (a.dxh) a.dxh[i] = (__bf16)r;
         }
@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(BnBwdArgs a) {
 }
 
 __global__ void __launch_bounds__(NT) dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
-                                                     uint32_t key, uint32_t thresh, float scale, __bf16* __restrict__ yh,
+                                                     uint32_t key, uint32_t thresh, float keep, __bf16* __restrict__ yh,
                                                      const pnp_step_params* sp, uint32_t sid) {
     key = pnp_eff_drop_key(key, sp, sid);
     const size_t gs = (size_t)gridDim.x * NT;
@@ -637,12 +637,12 @@ __global__ void __launch_bounds__(NT) dropout_kernel(const float* __restrict__ x
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += gs) {
         f32x4 v = ld4(x + i * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = pnp_drop_keep((uint32_t)(i * 4 + e), key, thresh) ? v[e] * scale : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = pnp_drop_keep((uint32_t)(i * 4 + e), key, thresh) ? v[e] / keep : 0.f;
         if (y) st4(y + i * 4, v);
         if (yh) st4h(yh + i * 4, v);
     }
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += gs) {
-        const float v = pnp_drop_keep((uint32_t)i, key, thresh) ? x[i] * scale : 0.f;
+        const float v = pnp_drop_keep((uint32_t)i, key, thresh) ? x[i] / keep : 0.f;
         if (y) y[i] = v;
         if (yh) yh[i] = (__bf16)v;
     }
@@ -1013,7 +1013,7 @@ int pnp_bn_bwd_apply_h(const float* dout, const float* out, const float* x, cons
     a.drop_key = pnp_drop_key(seed, stream_id);
     a.drop_thresh = pnp_drop_thresh(keep_prob);
     a.sp = pnp_step_params_ptr(); a.drop_sid = stream_id;
-    a.drop_scale = keep_prob < 1.f ? 1.f / keep_prob : 1.f;
+    a.drop_keep = keep_prob < 1.f ? keep_prob : 1.f;
     a.dxh = (__bf16*)dxh;
     const bool vec = (C % 4 == 0) && (!dshortcut || (Cs % 4 == 0 && ((C - Cs) / 2) % 4 == 0));
     const size_t nvec = (size_t)P * (vec ? C / 4 : C);
@@ -1066,10 +1066,10 @@ int pnp_dropout_h(const float* x, float* y, void* yh, size_t n, float keep_prob,
     PNP_REQUIRE(x && (y || yh) && keep_prob > 0.f, "pnp_dropout: bad argument");
     PNP_REQUIRE(n < (1ull << 32), "pnp_dropout: tensor exceeds 2^32 elements");
     if (n == 0) return PNP_OK;
-    const float scale = keep_prob < 1.f ? 1.f / keep_prob : 1.f;
+    const float keepv = keep_prob < 1.f ? keep_prob : 1.f;      // tf.nn.dropout divides: div(x, keep_prob) * mask
     const uint32_t thresh = keep_prob < 1.f ? pnp_drop_thresh(keep_prob) : 0u;
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, (hipStream_t)stream, x, y, n,
-                       pnp_drop_key(seed, stream_id), thresh, scale, (__bf16*)yh, pnp_step_params_ptr(), stream_id);
+                       pnp_drop_key(seed, stream_id), thresh, keepv, (__bf16*)yh, pnp_step_params_ptr(), stream_id);
     PNP_CHECK_LAUNCH("pnp_dropout");
     return PNP_OK;
 }

@@ -194,6 +194,7 @@ def test_winograd_route_planner_on_the_host(built):
     geo = lambda N, H, C, Kf, k=3, stride=1, dil=1, pad="SAME", dt=L.DTYPE_F32: K.conv_geom((N, H, H, C), (k, k, C, Kf), stride, dil, pad, dtype=dt)
     ch = lambda g: (bool(K.wino_chosen(g, 0)), bool(K.wino_chosen(g, 1)))
     prev, prev_t = K.wino_mode(-1), K.wino_tile(2)          # F(2x2, 3x3) alone first; F(4x4, 3x3): the next test
+    prev_x3 = K.wino_x3(0)                                  # (the fp32-pipe plan; the split-bf16 GEMM's: test_winograd_x3_plan_on_the_host)
     try:
         K.wino_mode(0)
         assert ch(geo(16, 32, 512, 512)) == (False, False)
@@ -248,6 +249,7 @@ def test_winograd_route_planner_on_the_host(built):
     finally:
         K.wino_mode(prev)
         K.wino_tile(prev_t)
+        K.wino_x3(prev_x3)
     assert K.wino_mode(-1) == prev and K.wino_tile(-1) == prev_t
 
 
@@ -260,7 +262,7 @@ def test_winograd_f4_planner_on_the_host(built):
     lib = L.load()
     geo = lambda N, H, C, Kf, k=3, stride=1, dil=1, pad="SAME", dt=L.DTYPE_F32: K.conv_geom((N, H, H, C), (k, k, C, Kf), stride, dil, pad, dtype=dt)
     ch = lambda g: (K.wino_chosen(g, 0), K.wino_chosen(g, 1), K.wino_chosen(g, 2))
-    prev, prev_w, prev_t = K.wino_mode(1), K.wino_wgrad_mode(1), K.wino_tile(4)
+    prev, prev_w, prev_t, prev_x3 = K.wino_mode(1), K.wino_wgrad_mode(1), K.wino_tile(4), K.wino_x3(0)
     try:
         assert K.wino_tile(-1) == 4
         assert ch(geo(16, 32, 512, 512)) == (4, 4, 4) and ch(geo(16, 32, 512, 512, dil=2)) == (4, 4, 4)
@@ -301,6 +303,46 @@ def test_winograd_f4_planner_on_the_host(built):
         K.wino_mode(prev)
         K.wino_wgrad_mode(prev_w)
         K.wino_tile(prev_t)
+        K.wino_x3(prev_x3)
+
+
+def test_winograd_x3_plan_on_the_host(built):
+    """round 6: the split-bf16 GEMMs of the route (csrc/conv_wino_x3.hip; pnp_conv2d_wino_x3 / PNP_WINOGRAD_X3).  Mode 1 (the default) gives
+    them the reductions over >= 256 channels, mode 2 every reduction over a multiple of 64 channels, mode 0 none; their operands are three
+    bf16 planes (6 bytes per transformed value instead of 4) and the product M stays fp32; chunked accumulation lifts the 1 024-channel cap
+    of F(4x4) on the fp32 pipe (group_10's data gradient takes F(4x4))"""
+    import ctypes
+    import importlib
+    K, L = importlib.import_module(built.__name__ + ".kernels"), built._lib
+    lib = L.load()
+    geo = lambda N, H, C, Kf, dil=1, pad="SAME": K.conv_geom((N, H, H, C), (3, 3, C, Kf), 1, dil, pad)
+    al = lambda b: (b + 255) // 256 * 256
+    ws = lambda g: int(lib.pnp_conv2d_fwd_workspace_bytes(ctypes.byref(g)))
+    f32 = lambda g, T: al(36 * 4 * g.C * g.K) + al(36 * 4 * T * g.C) + al(36 * 4 * T * g.K)
+    x3 = lambda g, T: al(36 * 6 * g.C * g.K) + al(36 * 6 * T * g.C) + al(36 * 4 * T * g.K)
+    prev, prev_t, prev_x3 = K.wino_mode(1), K.wino_tile(4), K.wino_x3(1)
+    try:
+        assert prev_x3 == 1, "the split-bf16 GEMM is the default arithmetic of the route"
+        T = 16 * 8 * 8
+        g512, g256, g128, g10 = geo(16, 32, 512, 512), geo(16, 32, 256, 512), geo(16, 128, 128, 128), geo(16, 34, 512, 2560, pad="VALID")
+        assert ws(g512) == x3(g512, T) and ws(g256) == x3(g256, T) and ws(g10) == x3(g10, T)
+        assert ws(g128) == f32(g128, 16 * 32 * 32)                               # 128-channel reduction: stays on the fp32 pipe under mode 1
+        assert K.wino_chosen(g10, 1) == 4                                        # data gradient: reduction over 2 560 channels, chunked
+        Td = 16 * 9 * 9                                                          # its output is the 34 x 34 mirror-padded map: 9 x 9 tiles of 4 x 4
+        assert int(lib.pnp_conv2d_dgrad_workspace_bytes(ctypes.byref(g10))) == al(36 * 6 * 2560 * 512) + al(36 * 6 * Td * 2560) + al(36 * 4 * Td * 512)
+        assert int(lib.pnp_conv2d_wino_filter_bytes(512, 512)) == 36 * 6 * 512 * 512          # an entry of the transformed-filter cache serves either format
+        K.wino_x3(2)
+        assert ws(g128) == x3(g128, 16 * 32 * 32)
+        g96 = geo(4, 32, 96, 128)
+        K.wino_mode(2)
+        assert ws(g96) == f32(g96, 4 * 8 * 8)                                     # 96 channels: no multiple of 64 -> fp32 pipe in every mode
+        K.wino_mode(1)
+        K.wino_x3(0)
+        assert ws(g512) == f32(g512, T) and K.wino_chosen(g10, 1) == 2
+    finally:
+        K.wino_mode(prev)
+        K.wino_tile(prev_t)
+        K.wino_x3(prev_x3)
 
 
 @pytest.mark.parametrize("m", [2, 4])
@@ -315,7 +357,7 @@ def test_winograd_eligibility_and_tile_count_agree_with_the_restatement(built, m
     K, L = importlib.import_module(built.__name__ + ".kernels"), built._lib
     lib = L.load()
     rng = np.random.default_rng(21)
-    prev, prev_t = K.wino_mode(2), K.wino_tile(m)
+    prev, prev_t, prev_x3 = K.wino_mode(2), K.wino_tile(m), K.wino_x3(0)
     np_ = (m + 2) ** 2
     try:
         seen = {True: 0, False: 0}
@@ -344,6 +386,7 @@ def test_winograd_eligibility_and_tile_count_agree_with_the_restatement(built, m
     finally:
         K.wino_mode(prev)
         K.wino_tile(prev_t)
+        K.wino_x3(prev_x3)
 
 
 def test_tail_split_plan_through_the_workspace_query(built):
@@ -359,7 +402,7 @@ sys.path.insert(0, %r)
 K = importlib.import_module("medical-cross-modality-domain-adaptation_amd.kernels")
 L = importlib.import_module("medical-cross-modality-domain-adaptation_amd._lib")
 lib = L.load()
-K.wino_mode(2); K.wino_tile(4)
+K.wino_mode(2); K.wino_tile(4); K.wino_x3(0)          # (the tail split belongs to the fp32-pipe GEMM)
 tile = 128 * 128 * 4
 for (N, H, C, Kf, pad, extra) in ((16, 32, 512, 512, "SAME", 8 * 16 * 3 * tile),     # 1152 tiles: 144 per XCD = 2 rounds + 16, 16 stages -> 4 pieces
                                   (16, 32, 256, 256, "SAME", 8 * 8 * 3 * tile),      # 576: 72 = 1 round + 8, 8 stages -> 4 pieces of 2

@@ -289,6 +289,12 @@ def test_joint_steps_with_and_without_the_filter_cache(dev, wino):
                                cost_kwargs={"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.3},
                                network_config={"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True, "cls_trainable": True,
                                                "m_cls_trainable": True})
+            # He-scaled filters and non-trivial moving statistics (tests/test_gpu_adversarial.py::he_state — what every other whole-step test
+            # starts from): the reference's stddev-.01 init with un-calibrated statistics overflows within two updates, and a comparison
+            # of two overflowed networks proves little
+            from test_gpu_adversarial import he_state
+            net.store.load_state_dict(he_state(net, 9))
+            K.weights_changed()
             tr = adv.Trainer(net, None, None, None, None, num_cls=5, batch_size=B, opt_kwargs={"learning_rate": 3e-4},
                              train_config={"dis_sub_iter": 1, "gen_sub_iter": 1})
             tr._get_optimizer()
@@ -304,9 +310,9 @@ def test_joint_steps_with_and_without_the_filter_cache(dev, wino):
     (l0, a0, s0), (l1, a1, s1) = out[False], out[True]
     print("joint steps: filter-transform cache off %s / on %s (hits, fills); losses %s" % (s0, s1, l1))
     assert s0 == (0, 0) and s1[0] > s1[1] > 0
-    # (bit-for-bit, NaN == NaN: with the reference's stddev-.01 init and un-calibrated moving statistics the CT front's update overflows
-    # in both runs alike — what is compared here is cached against un-cached, not the health of an untrained network)
-    assert l0 == l1 and bool(((a0 == a1) | (torch.isnan(a0) & torch.isnan(a1))).all())
+    # bit for bit, on finite numbers
+    assert all(np.isfinite(v) for v in l0) and bool(torch.isfinite(a0).all()) and bool(torch.isfinite(a1).all())
+    assert l0 == l1 and bool((a0 == a1).all())
 
 
 @pytest.mark.parametrize("split", ["0", "1"], ids=["persistent", "persistent+tail-split"])
