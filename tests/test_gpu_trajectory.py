@@ -1,0 +1,164 @@
+"""-m gpu: TRAINING TRAJECTORIES of the route's arithmetics (VERDICT r5 "missing" #5 / "next" #2a).
+
+The reference's only validation is watching its loss / Dice curves (/root/reference/source_segmenter.py:490-505, adversarial.py:894-922).
+Per-kernel parity says every launch is within 1e-6..1e-5 of float64; this file says what that does to a RUN: the segmenter trained for
+150 Adam steps and the adaptation phase for 20 joint iterations (1 discriminator + 1 generator update each) on synthetic blob slices,
+from the same weights, batches and dropout seeds, once per arithmetic
+    default            F(4x4, 3x3) with split-bf16 chunked GEMMs on the deep reductions (round 6)
+    F(4x4) fp32 pipe   round 5's default (PNP_WINOGRAD_X3=0)
+    F(2x2)             round 4's route
+    direct             no Winograd route at all
+and — the yardstick — three more runs of the DIRECT arithmetic that differ only in their dropout seeds.  Training is chaotic: runs that
+agree to 1e-6 per kernel separate after a few dozen steps whatever the arithmetic.  The statement tested is therefore statistical:
+  * the first step (same weights: pure forward arithmetic) agrees with the direct arithmetic to 1e-5 of the loss, the first 5 steps to
+    5e-3 (Adam's first updates are sign-like — g / sqrt(g^2) — so a rounding difference in a near-zero gradient moves a weight by the
+    full learning rate: runs start to separate at the second step whatever the arithmetic);
+  * at the end (mean over the last 20 steps of the loss, final Dice on held-out slices) every arithmetic lies inside the band the dropout
+    seeds span around their mean (widened by half its width on each side, and never narrower than 5 % of the mean)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+ARITH = {"default": (1, 4, 1), "F(4x4) fp32 pipe": (1, 4, 0), "F(2x2)": (1, 2, 0), "direct": (0, 4, 0)}       # (route mode, tile, x3)
+
+
+def _slices(n, seed):
+    syn = pkg("synthetic")
+    rng = np.random.default_rng(seed)
+    xs, ys = [], []
+    for _ in range(n):
+        img, lab = syn.make_slice(rng)
+        xs.append(img + 0.7 * lab[:, :, 1:2])                  # a learnable signal: the class shifts the intensity by 1.0 in all
+        ys.append(np.eye(5, dtype=np.float32)[lab[:, :, 1].astype(np.int64)])
+    return np.stack(xs).astype(np.float32), np.stack(ys)
+
+
+class _Modes:
+    def __init__(self, arith):
+        self.K = pkg("kernels")
+        self.want = ARITH[arith]
+
+    def __enter__(self):
+        K = self.K
+        self.prev = (K.wino_mode(-1), K.wino_wgrad_mode(-1), K.wino_tile(-1), K.wino_x3(-1))
+        K.wino_mode(self.want[0]); K.wino_wgrad_mode(self.want[0]); K.wino_tile(self.want[1]); K.wino_x3(self.want[2])
+
+    def __exit__(self, *a):
+        K = self.K
+        K.wino_mode(self.prev[0]); K.wino_wgrad_mode(self.prev[1]); K.wino_tile(self.prev[2]); K.wino_x3(self.prev[3])
+        K.wino_u_cache_clear()
+
+
+def _band(vals):
+    lo, hi, m = min(vals), max(vals), float(np.mean(vals))
+    half = max(hi - lo, 0.05 * abs(m))
+    return lo - 0.5 * half, hi + 0.5 * half
+
+
+def _he(net, seed):
+    bench = importlib.import_module("bench")
+    sd = bench.he_state(net.store.state_dict(), seed)
+    net.store.load_state_dict(sd)
+    return sd
+
+
+def _segmenter_run(dev, arith, seed_off, x, y, xv, yv, steps, B):
+    ss, K = pkg("source_segmenter"), pkg("kernels")
+    with _Modes(arith):
+        net = ss.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, seed=0,
+                          cost_kwargs={"cross_flag": True, "miu_cross": 1.0, "dice_flag": True, "miu_dice": 1.0, "regularizer": 1e-4})
+        _he(net, 7)
+        K.weights_changed()
+        tr = ss.Trainer(net, None, None, num_cls=5, batch_size=B, optimizer="adam", opt_kwargs={"learning_rate": 1e-3})
+        tr.opt = tr._get_optimizer(steps)
+        losses = []
+        nb = x.shape[0] // B
+        for i in range(steps):
+            b = (i % nb) * B
+            losses.append(float(tr.train_step(x[b:b + B], y[b:b + B], 0.75, 1000 * seed_off + i + 1)))
+        net.evaluate(xv, yv, keep_prob=1.0)
+        dice = float(net.dice_eval)
+        torch.cuda.synchronize()
+    return np.array(losses), dice
+
+
+def test_segmenter_trajectory_by_arithmetic(dev):
+    B, steps = 8, 150
+    xa, ya = _slices(32, 0)
+    xva, yva = _slices(B, 99)
+    x, y, xv, yv = (torch.from_numpy(a).to(dev) for a in (xa, ya, xva, yva))
+    runs = {a: _segmenter_run(dev, a, 0, x, y, xv, yv, steps, B) for a in ARITH}
+    seeds = [runs["direct"]] + [_segmenter_run(dev, "direct", s, x, y, xv, yv, steps, B) for s in (1, 2, 3)]
+    end = lambda l: float(l[-20:].mean())
+    lb, db = _band([end(l) for l, _ in seeds]), _band([d for _, d in seeds])
+    l0 = runs["direct"][0]
+    print("segmenter, %d Adam steps at B = %d: loss %.4f -> last-20 mean; dropout-seed yardstick (direct arithmetic, 4 seeds): loss %s Dice %s"
+          % (steps, B, l0[0], ["%.4f" % end(l) for l, _ in seeds], ["%.4f" % d for _, d in seeds]))
+    for a, (l, d) in runs.items():
+        early = float(np.abs(l[:5] - l0[:5]).max() / np.abs(l0[:5]).max())
+        first = abs(l[0] - l0[0]) / abs(l0[0])
+        print("  %-18s step-0 |dloss| / loss %.1e, first-5-steps %.2e   loss[10] %.5f loss[50] %.5f  last-20 mean %.4f (band %.4f .. %.4f)   held-out Dice %.4f (band %.4f .. %.4f)"
+              % (a, first, early, l[10], l[50], end(l), lb[0], lb[1], d, db[0], db[1]))
+        assert np.isfinite(l).all()
+        assert first < 1e-5 and early < 5e-3, (a, first, early)
+        assert lb[0] <= end(l) <= lb[1], (a, end(l), lb)
+        assert db[0] <= d <= db[1], (a, d, db)
+    assert end(l0) < 0.8 * l0[0], "the run must actually learn for the comparison to mean anything"
+
+
+def _joint_run(dev, arith, seed_off, mr, ct, iters, B):
+    adv, K = pkg("adversarial"), pkg("kernels")
+    from test_gpu_adversarial import he_state
+    with _Modes(arith):
+        net = adv.Full_DRN(channels=3, n_class=5, batch_size=B, device=dev, seed=0,
+                           cost_kwargs={"regularizer": 1e-4, "gan_regularizer": 1e-4, "miu_gen": 0.002, "miu_dis": 0.002, "lambda_mask_loss": 0.3},
+                           network_config={"mr_front_trainable": False, "joint_trainable": False, "ct_front_trainable": True, "cls_trainable": True,
+                                           "m_cls_trainable": True})
+        net.store.load_state_dict(he_state(net, 9))
+        K.weights_changed()
+        tr = adv.Trainer(net, None, None, None, None, num_cls=5, batch_size=B, opt_kwargs={"learning_rate": 3e-4},
+                         train_config={"dis_sub_iter": 1, "gen_sub_iter": 1})
+        tr._get_optimizer()
+        dl, gl = [], []
+        nb = mr.shape[0] // B
+        for i in range(iters):
+            b = (i % nb) * B
+            dl.append(float(tr.dis_step(mr[b:b + B], ct[b:b + B], 0.75, 1000 * seed_off + 2 * i + 1)))
+            gl.append(float(tr.gen_step(ct[b:b + B], 0.75, 1000 * seed_off + 2 * i + 2)))
+        torch.cuda.synchronize()
+        arena = net.store.arena.clone()
+    return np.array(dl), np.array(gl), arena
+
+
+def test_joint_trajectory_by_arithmetic(dev):
+    B, iters = 4, 20
+    mra, _ = _slices(16, 10)
+    cta, _ = _slices(16, 11)
+    mr, ct = torch.from_numpy(mra).to(dev), torch.from_numpy(cta * 1.2 + 0.1).to(dev)
+    runs = {a: _joint_run(dev, a, 0, mr, ct, iters, B) for a in ARITH}
+    seeds = [runs["direct"]] + [_joint_run(dev, "direct", s, mr, ct, iters, B) for s in (1, 2, 3)]
+    end = lambda l: float(l[-5:].mean())
+    dband, gband = _band([end(d) for d, _, _ in seeds]), _band([end(g) for _, g, _ in seeds])
+    d0, g0, a0 = runs["direct"]
+    # how far the WEIGHTS have moved apart after 20 updates, against how far two dropout seeds of one arithmetic move them apart
+    dist = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+    wseed = max(dist(s[2], a0) for s in seeds[1:])
+    print("joint, %d iterations (1 dis + 1 gen update) at B = %d; dropout-seed yardstick (direct, 4 seeds): dis loss last-5 %s  gen %s  weights apart by <= %.3e"
+          % (iters, B, ["%.5f" % end(d) for d, _, _ in seeds], ["%.6f" % end(g) for _, g, _ in seeds], wseed))
+    for a, (d, g, ar) in runs.items():
+        e_d = float(np.abs(d[:3] - d0[:3]).max() / (np.abs(d0[:3]).max() + 1e-12))
+        e_g = float(np.abs(g[:3] - g0[:3]).max() / (np.abs(g0[:3]).max() + 1e-12))
+        wd = dist(ar, a0)
+        print("  %-18s first-3 |d dis| %.2e |d gen| %.2e   dis last-5 %.5f (band %.5f .. %.5f)  gen last-5 %.6f (band %.6f .. %.6f)  weights vs direct %.3e"
+              % (a, e_d, e_g, end(d), dband[0], dband[1], end(g), gband[0], gband[1], wd))
+        assert np.isfinite(d).all() and np.isfinite(g).all() and bool(torch.isfinite(ar).all())
+        assert e_d < 2e-3 and e_g < 2e-2, (a, e_d, e_g)          # (the generator loss is a 0.002-weighted near-cancelling mean: float32 noise ~3e-4 of it per evaluation)
+        assert dband[0] <= end(d) <= dband[1], (a, end(d), dband)
+        assert gband[0] <= end(g) <= gband[1], (a, end(g), gband)
+        assert wd <= wseed, (a, wd, wseed)                       # an arithmetic moves the weights less than a dropout seed does
