@@ -395,8 +395,10 @@ int launch_wino_wgrad(const ConvArgs& a, float* dw, int accumulate, void* ws, si
 // split-bf16 GEMMs of the route (conv_wino_x3.hip): M[pos] = V3[pos] x U3[pos]^T, V3 [npos][3][T][C] / U3 [npos][3][K][C] bf16 planes
 // (hi, mid, lo: their sum is the fp32 value), M [npos][T][K] fp32.  dims_ok: one buffer descriptor per operand and transform point.
 bool wino_x3_dims_ok(int T, int C, int K);
+// sym 0..3: forward / data gradient of F(2x2) / F(4x4) (nsplit = 1, stages_per_split = C / 32); 4 / 5: the filter gradient's GEMMs
+// (T := channels, C := tiles padded to a multiple of 64, reduction split nsplit ways: M = [nsplit][npos][T][K])
 int launch_wino_gemm_x3(const unsigned short* V3, const unsigned short* U3, float* Mm, int T, int C, int K, int npos, int sym, int gn, int xcd,
-                        hipStream_t st);
+                        int nsplit, int stages_per_split, hipStream_t st);
 inline double conv_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.K * a.Kred; }
 inline double conv_bytes(const ConvArgs& a) {
     return 4.0 * ((double)a.N * a.H * a.W * a.C + (double)a.M * a.K + (double)a.Kred * a.K);

@@ -767,6 +767,166 @@ __global__ void __launch_bounds__(NT) wino_dy_kernel(WinoDyArgs a) {
     }
 }
 
+// ---- the filter gradient on the split-bf16 GEMM (conv_wino_x3.hip, sym 4 / 5) ------------------------------------------------------
+// S[pos] = V[pos]^T x Y[pos] reduces over the TILES, so both operands need the tile index contiguous:
+//     V3t [pos][Tp / 32][plane][C][32 tiles],  Y3t [pos][Tp / 32][plane][K][32 tiles]      (Tp = T rounded up to 64, zero-filled)
+// — the stage-major layout of the forward's operands with rows = channels (filters).  A workgroup transforms 32 tiles x 32 channels
+// (thread = tile, channel quad: the same loads and arithmetic as wino_in_kernel / wino_dy_kernel) and transposes them through LDS, PG
+// transform points per round, so that every store instruction writes whole 64-byte rows (8 lanes x 4 tiles x 2 bytes).
+template <int M>
+__device__ __forceinline__ void bt_2d(const f32x4 (&d)[M + 2][M + 2], f32x4 (&v)[(M + 2) * (M + 2)]) {
+    constexpr int P = M + 2;
+    f32x4 r[P][P];
+    if constexpr (M == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            r[0][q] = d[0][q] - d[2][q];
+            r[1][q] = d[1][q] + d[2][q];
+            r[2][q] = d[2][q] - d[1][q];
+            r[3][q] = d[1][q] - d[3][q];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            v[4 * p + 0] = r[p][0] - r[p][2];
+            v[4 * p + 1] = r[p][1] + r[p][2];
+            v[4 * p + 2] = r[p][2] - r[p][1];
+            v[4 * p + 3] = r[p][1] - r[p][3];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            f32x4 o[6];
+            w4_bt(d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q], o);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) r[p][q] = o[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            f32x4 o[6];
+            w4_bt(r[p][0], r[p][1], r[p][2], r[p][3], r[p][4], r[p][5], o);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) v[6 * p + q] = o[q];
+        }
+    }
+}
+template <int M>
+__device__ __forceinline__ void a_2d(const f32x4 (&y)[M][M], f32x4 (&v)[(M + 2) * (M + 2)]) {
+    if constexpr (M == 2) {
+        f32x4 z[4][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            z[0][q] = y[0][q];
+            z[1][q] = y[0][q] + y[1][q];
+            z[2][q] = y[0][q] - y[1][q];
+            z[3][q] = -y[1][q];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            v[4 * p + 0] = z[p][0];
+            v[4 * p + 1] = z[p][0] + z[p][1];
+            v[4 * p + 2] = z[p][0] - z[p][1];
+            v[4 * p + 3] = -z[p][1];
+        }
+    } else {
+        f32x4 z[6][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 c6[6];
+            w4_a(y[0][q], y[1][q], y[2][q], y[3][q], c6);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) z[p][q] = c6[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            f32x4 o[6];
+            w4_a(z[p][0], z[p][1], z[p][2], z[p][3], o);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) v[6 * p + q] = o[q];
+        }
+    }
+}
+// v[pos] (4 channels ch0 + 4 c4 ..) of tile tl = tid >> 3  ->  out[pos][tblk][plane][channel][tl]
+template <int NP, int PG>
+__device__ __forceinline__ void emit_t(const f32x4 (&v)[NP], float (*tile)[32][34], __bf16* __restrict__ out, size_t pos_stride, int tblk, int rows, int ch0,
+                                       int tid) {
+    const int c4 = tid & 7, tl = tid >> 3;          // producer view: channel quad, tile
+    const int cl = tid >> 3, tq = tid & 7;          // consumer view: channel, tile quad
+#pragma unroll
+    for (int r0 = 0; r0 < NP; r0 += PG) {
+#pragma unroll
+        for (int p = 0; p < PG; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[p][c4 * 4 + e][tl] = v[r0 + p][e];        // (row stride 34: the 64 lanes of a wave hit 64 banks)
+        __syncthreads();
+        if (ch0 + cl < rows) {
+#pragma unroll
+            for (int p = 0; p < PG; ++p) {
+                const float* src = &tile[p][cl][4 * tq];
+                const f32x4 w = {src[0], src[1], src[2], src[3]};
+                st4x3(out + (size_t)(r0 + p) * pos_stride + ((size_t)tblk * 3 * rows + ch0 + cl) * 32 + 4 * tq, (size_t)rows * 32, w);
+            }
+        }
+        __syncthreads();
+    }
+}
+struct WinoTArgs {
+    const float* src;      // x (wino_in_t) or dy (wino_dy_t)
+    __bf16* out;
+    WinoGeom g;
+    int rows;              // C or K
+    unsigned src_bytes;
+    int ntb;               // Tp / 32
+};
+template <int M>
+__global__ void __launch_bounds__(NT) wino_in_t_kernel(WinoTArgs a) {
+    constexpr int P = M + 2, NP = P * P, PG = M == 4 ? 12 : 8;
+    __shared__ float tile[PG][32][34];
+    const int tid = threadIdx.x, c4 = tid & 7, tl = tid >> 3;
+    const int t = blockIdx.x * 32 + tl, c = blockIdx.y * 32 + c4 * 4;
+    const bool tok = t < a.g.T;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.src, a.src_bytes);
+    int n, pa, pb, ti, tj;
+    tile_of(a.g, tok ? t : 0, n, pa, pb, ti, tj);
+    f32x4 d[P][P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int u = M * ti - a.g.ps + p;
+        const bool uok = tok & ((unsigned)u < (unsigned)a.g.Hsi);
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int v_ = M * tj - a.g.ps + q;
+            const bool ok = uok & ((unsigned)v_ < (unsigned)a.g.Wsi);
+            const unsigned off = (unsigned)(((n * a.g.Hi + pa + a.g.dil * u) * a.g.Wi + pb + a.g.dil * v_) * a.rows + c) * 4u;
+            d[p][q] = bload4(rx, ok ? off : OOB);
+        }
+    }
+    f32x4 v[NP];
+    bt_2d<M>(d, v);
+    emit_t<NP, PG>(v, tile, a.out, (size_t)a.ntb * 3 * a.rows * 32, (int)blockIdx.x, a.rows, (int)blockIdx.y * 32, tid);
+}
+template <int M>
+__global__ void __launch_bounds__(NT) wino_dy_t_kernel(WinoTArgs a) {
+    constexpr int P = M + 2, NP = P * P, PG = M == 4 ? 12 : 8;
+    __shared__ float tile[PG][32][34];
+    const int tid = threadIdx.x, c4 = tid & 7, tl = tid >> 3;
+    const int t = blockIdx.x * 32 + tl, k = blockIdx.y * 32 + c4 * 4;
+    const bool tok = t < a.g.T && k < a.rows;
+    int n, pa, pb, ti, tj;
+    tile_of(a.g, t < a.g.T ? t : 0, n, pa, pb, ti, tj);
+    f32x4 y[M][M];
+#pragma unroll
+    for (int p = 0; p < M; ++p)
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            const int u = M * ti + p, v_ = M * tj + q;
+            const f32x4 zero = {0, 0, 0, 0};
+            y[p][q] = (tok && u < a.g.Hso && v_ < a.g.Wso) ? ld4(a.src + ((size_t)(n * a.g.Ho + pa + a.g.dil * u) * a.g.Wo + pb + a.g.dil * v_) * a.rows + k) : zero;
+        }
+    f32x4 v[NP];
+    a_2d<M>(y, v);
+    emit_t<NP, PG>(v, tile, a.out, (size_t)a.ntb * 3 * a.rows * 32, (int)blockIdx.x, a.rows, (int)blockIdx.y * 32, tid);
+}
+
 // S[z][pos] = V[pos][rows of split z]^T x Y[pos][rows of split z].  Workgroup = one 128 x 128 tile of (C x K) of one transform point and
 // one reduction split; both operands are [tile row][channel] with the reduction index as the ROW, so both LDS tiles are [32][128 + 4]
 // like the B tile of the convolutions (fragments by ds_read_b32: Frag<.., A_MMAJOR = false>, the layout of conv_wgrad_kernel).
@@ -1276,7 +1436,7 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
     if (x3) {
         static const int wino_gn3 = env_int("PNP_WINO_GN", -1);
         const int rc = launch_wino_gemm_x3((const unsigned short*)V, (const unsigned short*)U, Mm, w.T, a.C, a.K, NP, (M == 4 ? 2 : 0) + (kind != 0), wino_gn3 >= 0 ? wino_gn3 : a.gn,
-                                           xcd ? 1 : 0, st);
+                                           xcd ? 1 : 0, 1, a.C / 32, st);
         if (rc != PNP_OK) return rc;
     } else {
         WinoGemmArgs ga{};
@@ -1332,8 +1492,45 @@ int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size
 bool wino_wgrad_chosen(const pnp_conv_geom* g) { return plan_tile(g, true) != 0; }
 int wino_wgrad_tile(const pnp_conv_geom* g) { return plan_tile(g, true); }
 
+// the filter gradient's GEMMs on the split-bf16 kernel (PNP_WINOGRAD_X3 on, PNP_WINOGRAD_X3_WGRAD != 0).  Mode 1: where measured to pay at
+// B = 16 (profiles/r06_x3_wgrad_layers_B16.txt) — reductions over 256 .. 2 048 tiles, i.e. the 32^2 maps: 512->512 0.239 -> 0.200 ms, g10
+// 0.94 -> 0.71, 256->256 0.089 -> 0.074; on the large maps the two TRANSPOSING transforms (6 bytes per value, through LDS) cost more than
+// the GEMM gains: cls3 256->256 @64^2 (4 096 tiles) 0.255 -> 0.267, cls2 128->128 @128^2 (16 384 tiles) 0.36 -> 0.48.  Mode 2: everywhere.
+inline int x3_tp(int T) { return (T + 63) & ~63; }
+inline bool use_x3_wgrad(int T, int C, int K) {
+    static const int on = env_int("PNP_WINOGRAD_X3_WGRAD", 1), tmin = env_int("PNP_WINOGRAD_X3_WGRAD_TMIN", 256), tmax = env_int("PNP_WINOGRAD_X3_WGRAD_TMAX", 2048);
+    const int m = wino_x3_mode();
+    if (!on || m == 0 || !wino_x3_dims_ok(C, x3_tp(T), K) || !wino_x3_dims_ok(K, x3_tp(T), C)) return false;
+    return m >= 2 || (T >= tmin && T <= tmax);
+}
+// reduction split of the x3 filter-gradient GEMMs: one 8-wave workgroup per CU (256 slots), a workgroup of s stages costs ~s + 3 (pipeline
+// fill + epilogue); every split writes npos C K floats that the 6x6 -> 3x3 kernel reads back.  Returns the splits; *sps = stages per split (even)
+int wgrad_split_x3(int T, int C, int K, int npos, int* sps) {
+    const int nchunks = x3_tp(T) / 64;
+    const long long tiles = (long long)pnp_cdiv(C, 128) * pnp_cdiv(K, K <= 64 ? 64 : 128) * npos;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int ns = 1; ns <= 32 && ns <= nchunks; ++ns) {
+        const int cps = pnp_cdiv(nchunks, ns);
+        if (pnp_cdiv(nchunks, cps) != ns) continue;
+        if (ns > 1 && cps < 2) break;
+        const int rounds = pnp_cdiv(tiles * ns, 256);
+        const double cost = rounds * (2.0 * cps + 3.0) + ns * 1.5e-6 * npos * (double)C * K;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = ns; }
+    }
+    const int cps = pnp_cdiv(nchunks, best);
+    *sps = 2 * cps;
+    return pnp_cdiv(nchunks, cps);
+}
+
 static size_t wgrad_ws_bytes(const WinoGeom& w, int C, int K) {
     const int np = (w.m + 2) * (w.m + 2);
+    if (use_x3_wgrad(w.T, C, K)) {
+        int sps;
+        const int ns = wgrad_split_x3(w.T, C, K, np, &sps);
+        const size_t tp = (size_t)x3_tp(w.T);
+        return al256((size_t)np * tp * C * 6) + al256((size_t)np * tp * K * 6) + al256((size_t)ns * np * C * K * 4);
+    }
     int cps;
     const int ns = wgrad_split(w.T, C, K, np, &cps);
     return al256((size_t)np * w.T * C * 4) + al256((size_t)np * w.T * K * 4) + al256((size_t)ns * np * C * K * 4);
@@ -1348,6 +1545,48 @@ template <int M>
 static int launch_wino_wgrad_m(const ConvArgs& a, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int NP = (M + 2) * (M + 2);
     const WinoGeom w = make_wgeom(a.N, a.H, a.W, a.OH, a.OW, a.dil, a.pad_t, M);
+    if (use_x3_wgrad(w.T, a.C, a.K)) {
+        int sps;
+        const int ns = wgrad_split_x3(w.T, a.C, a.K, NP, &sps);
+        const int tp = x3_tp(w.T), ntb = tp / 32;
+        const size_t vb = al256((size_t)NP * tp * a.C * 6), yb = al256((size_t)NP * tp * a.K * 6), sb = al256((size_t)ns * NP * a.C * a.K * 4);
+        if (!ws || ws_bytes < vb + yb + sb) {
+            pnp_set_error("launch_wino_wgrad: workspace too small (%zu < %zu)", ws_bytes, vb + yb + sb);
+            return PNP_EWORKSPACE;
+        }
+        __bf16* V3 = (__bf16*)ws;
+        __bf16* Y3 = (__bf16*)((char*)ws + vb);
+        float* S = (float*)((char*)ws + vb + yb);
+        {
+            WinoTArgs ta{};
+            ta.src = a.x; ta.out = V3; ta.g = w; ta.rows = a.C; ta.src_bytes = a.x_bytes; ta.ntb = ntb;
+            PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * (double)a.N * a.H * a.W * a.C + 6.0 * NP * tp * a.C, "wino_in_t_kernel<%d>", M);
+            hipLaunchKernelGGL(wino_in_t_kernel<M>, dim3((unsigned)ntb, (unsigned)(a.C / 32)), dim3(NT), 0, st, ta);
+            PNP_CHECK_LAUNCH("wino_in_t_kernel");
+        }
+        {
+            WinoTArgs ta{};
+            ta.src = a.w; ta.out = Y3; ta.g = w; ta.rows = a.K; ta.src_bytes = 0; ta.ntb = ntb;
+            PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * (double)a.M * a.K + 6.0 * NP * tp * a.K, "wino_dy_t_kernel<%d>", M);
+            hipLaunchKernelGGL(wino_dy_t_kernel<M>, dim3((unsigned)ntb, (unsigned)pnp_cdiv(a.K, 32)), dim3(NT), 0, st, ta);
+            PNP_CHECK_LAUNCH("wino_dy_t_kernel");
+        }
+        const int rc = launch_wino_gemm_x3((const unsigned short*)V3, (const unsigned short*)Y3, S, a.C, tp, a.K, NP, M == 4 ? 5 : 4, 0, a.xcd_swizzle ? 1 : 0, ns, sps, st);
+        if (rc != PNP_OK) return rc;
+        int ns_out = ns;
+        if (ns > 2 && (size_t)a.C * (a.K / 4) < (size_t)NT * 512) {
+            const size_t nv = (size_t)NP * a.C * (a.K / 4);
+            PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)ns + 1.0) * NP * a.C * a.K, "wino_splitsum_kernel");
+            hipLaunchKernelGGL(wino_splitsum_kernel, dim3((unsigned)((nv + NT - 1) / NT)), dim3(NT), 0, st, S, nv, ns);
+            PNP_CHECK_LAUNCH("wino_splitsum_kernel");
+            ns_out = 1;
+        }
+        const size_t nvec = (size_t)a.C * (a.K / 4);
+        PnpProfScope ps(PNP_PROF_CONV_WGRAD, st, 0.0, 4.0 * ((double)ns_out * NP + 9.0 * (1 + (accumulate != 0))) * a.C * a.K, "wino_wgrad_out_kernel<%d>", M);
+        hipLaunchKernelGGL(wino_wgrad_out_kernel<M>, dim3((unsigned)((nvec + NT - 1) / NT)), dim3(NT), 0, st, (const float*)S, dw, a.C, a.K, ns_out, accumulate);
+        PNP_CHECK_LAUNCH("wino_wgrad_out_kernel");
+        return PNP_OK;
+    }
     int cps;
     const int ns = wgrad_split(w.T, a.C, a.K, NP, &cps);
     const size_t vb = al256((size_t)NP * w.T * a.C * 4), yb = al256((size_t)NP * w.T * a.K * 4), sb = al256((size_t)ns * NP * a.C * a.K * 4);

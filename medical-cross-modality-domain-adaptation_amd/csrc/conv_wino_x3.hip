@@ -55,9 +55,10 @@ __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 struct X3Args {
     const unsigned short* V;      // [npos][C / 32][3][T][32]
     const unsigned short* U;      // [npos][C / 32][3][K][32]
-    float* Mm;                    // [npos][T][K]
-    int T, C, K, npos;
+    float* Mm;                    // [nsplit][npos][T][K]
+    int T, C, K, npos;            // rows of A, reduction length, rows of B (= output columns), transform points
     int nblk_m, nblk_n, gn, xcd;
+    int nsplit, spz;              // reduction splits (filter gradient: the reduction runs over the tiles), 32-channel stages per split (even)
 };
 
 // 8 waves: consumers 0..3 (2 x 2 wave tiles of BM/2 x BN/2), loaders 4..7.  C a multiple of 64 (a chunk = two stages).
@@ -82,11 +83,13 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
     const int nblk = g.nblk_m * g.nblk_n;
     int lid = (int)blockIdx.x;
     if (g.xcd) lid = xcd_remap(lid, (int)gridDim.x);          // an XCD owns a contiguous range of tiles = whole transform points (one L2 holds U[pos], V[pos])
-    const int pos = lid / nblk;
+    const int pz = lid / nblk;
+    const int pos = pz / g.nsplit, z = pz - pos * g.nsplit;       // consecutive logical ids = the tiles of one (point, split): one XCD's L2
     int mt, nt;
-    tile_coords(lid - pos * nblk, g.nblk_m, g.nblk_n, g.gn, mt, nt);
+    tile_coords(lid - pz * nblk, g.nblk_m, g.nblk_n, g.gn, mt, nt);
     const int m0 = mt * BM, n0 = nt * BN;
-    const int nst = g.C / 32;
+    const int s0 = z * g.spz;                                     // first stage of this split
+    const int nst = min(g.spz, g.C / 32 - s0);                    // its stages (even: host)
 
     if (wave >= 4) {
         // ================================================= loader =================================================
@@ -121,13 +124,13 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
 #pragma unroll
             for (int i = 0; i < NRB; ++i) dma16(ru, (lds_void*)(base + bdst[i]), bvo[i], cc * sstrideU);
         };
-        issue(0, 0);
-        issue(min(1, nst - 1), 1);
+        issue(s0, 0);
+        issue(s0 + min(1, nst - 1), 1);
         int nb = 2;
         for (int j = 0; j < nst; ++j) {
             wait_vm<LPS>();                      // stage j has landed (stage j + 1 may be in flight)
             __builtin_amdgcn_s_barrier();        // consumers: done with stage j - 1, i.e. with buffer (j + 2) % 3
-            issue(min(j + 2, nst - 1), nb);      // (past the end: the last stage again, into a buffer nobody reads any more)
+            issue(s0 + min(j + 2, nst - 1), nb);      // (past the end: the last stage again, into a buffer nobody reads any more)
             nb = nb == 2 ? 0 : nb + 1;
         }
         wait_vm<0>();
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
     e.M = g.T;
     e.K = g.K;
     e.nsplit = 1;
-    conv_epilogue<TM, TN>(e, total, g.Mm + (size_t)pos * g.T * g.K, m0, n0, wm0, wn0, lane, 0);
+    conv_epilogue<TM, TN>(e, total, g.Mm + ((size_t)z * g.npos + pos) * g.T * g.K, m0, n0, wm0, wn0, lane, 0);
 }
 
 }  // namespace
@@ -204,35 +207,44 @@ bool wino_x3_dims_ok(int T, int C, int K) {
     return (C % 64) == 0 && (double)T * C * 6.0 < 2147483648.0 && (double)K * C * 6.0 < 2147483648.0;
 }
 
-// sym = 0 / 1: F(2x2) forward / data gradient, 2 / 3: F(4x4) (names the symbol like wino_gemm_kernel's last template argument)
+// sym = 0 / 1: F(2x2) forward / data gradient, 2 / 3: F(4x4) (names the symbol like wino_gemm_kernel's last template argument), 4 / 5: the
+// filter gradient's GEMMs S[pos] = V[pos]^T x Y[pos] of F(2x2) / F(4x4) (T := channels, C := tiles padded to 64, K := filters; the
+// reduction over the tiles is split nsplit ways, stages_per_split 32-tile stages each: M = [nsplit][npos][T][K])
 int launch_wino_gemm_x3(const unsigned short* V3, const unsigned short* U3, float* Mm, int T, int C, int K, int npos, int sym, int gn, int xcd,
-                        hipStream_t st) {
+                        int nsplit, int stages_per_split, hipStream_t st) {
     PNP_REQUIRE(wino_x3_dims_ok(T, C, K), "launch_wino_gemm_x3: operands too large for one buffer descriptor per transform point");
-    PNP_REQUIRE(sym >= 0 && sym < 4, "launch_wino_gemm_x3: bad symbol index");
+    PNP_REQUIRE(sym >= 0 && sym < 6, "launch_wino_gemm_x3: bad symbol index");
+    PNP_REQUIRE(nsplit >= 1 && (stages_per_split % 2) == 0 && (long long)nsplit * stages_per_split >= C / 32 && (long long)(nsplit - 1) * stages_per_split < C / 32,
+                "launch_wino_gemm_x3: bad reduction split");
     X3Args g{};
     g.V = V3; g.U = U3; g.Mm = Mm; g.T = T; g.C = C; g.K = K; g.npos = npos;
     const bool narrow = K <= 64;
     g.nblk_m = pnp_cdiv(T, 128); g.nblk_n = pnp_cdiv(K, narrow ? 64 : 128);
     g.gn = gn; g.xcd = xcd ? 1 : 0;
-    const dim3 grid((unsigned)(g.nblk_m * g.nblk_n * npos));
+    g.nsplit = nsplit; g.spz = stages_per_split;
+    const dim3 grid((unsigned)(g.nblk_m * g.nblk_n * npos * nsplit));
     // flops = the bf16 MFMA flops the kernel EXECUTES (six products per fp32 multiply-add): its roof is the dense bf16 peak
     const double fl = 6.0 * 2.0 * npos * (double)T * C * K;
-    const double by = (double)npos * (6.0 * ((double)T * C + (double)C * K) + 4.0 * (double)T * K);
-    PnpProfScope ps(prof_class(sym & 1), st, fl, by, "wino_gemm_x3_kernel<128, %d, %d>", narrow ? 64 : 128, sym);
+    const double by = (double)npos * (6.0 * ((double)T * C + (double)C * K) + 4.0 * (double)nsplit * T * K);
+    PnpProfScope ps(sym >= 4 ? PNP_PROF_CONV_WGRAD : prof_class(sym & 1), st, fl, by, "wino_gemm_x3_kernel<128, %d, %d>", narrow ? 64 : 128, sym);
 #define PNP_X3_LAUNCH(BN_, SYM_) hipLaunchKernelGGL((wino_gemm_x3_kernel<128, BN_, SYM_>), grid, dim3(512), 0, st, g)
     if (narrow) {
         switch (sym) {
             case 0: PNP_X3_LAUNCH(64, 0); break;
             case 1: PNP_X3_LAUNCH(64, 1); break;
             case 2: PNP_X3_LAUNCH(64, 2); break;
-            default: PNP_X3_LAUNCH(64, 3); break;
+            case 3: PNP_X3_LAUNCH(64, 3); break;
+            case 4: PNP_X3_LAUNCH(64, 4); break;
+            default: PNP_X3_LAUNCH(64, 5); break;
         }
     } else {
         switch (sym) {
             case 0: PNP_X3_LAUNCH(128, 0); break;
             case 1: PNP_X3_LAUNCH(128, 1); break;
             case 2: PNP_X3_LAUNCH(128, 2); break;
-            default: PNP_X3_LAUNCH(128, 3); break;
+            case 3: PNP_X3_LAUNCH(128, 3); break;
+            case 4: PNP_X3_LAUNCH(128, 4); break;
+            default: PNP_X3_LAUNCH(128, 5); break;
         }
     }
 #undef PNP_X3_LAUNCH

@@ -127,8 +127,12 @@ def test_winograd_fwd_dgrad_vs_float64_and_direct(dev, wino, case):
     assert K.wino_chosen(g, 2) == wino.tile
     dw1, names3 = _ran(L, lambda: K.conv2d_wgrad(xd, dyd, g), L.PROF_CONV_WGRAD)
     # (+ wino_splitsum_kernel where a narrow layer's reduction is split many ways)
-    assert sorted(n for n in names3 if n != "wino_splitsum_kernel") == [n % wino.tile for n in (
-        "wino_dy_kernel<%d>", "wino_in_kernel<%d, false>", "wino_wgrad_gemm_kernel<128, 128, 2, 2, %d>", "wino_wgrad_out_kernel<%d>")], names3
+    if wino.x3:        # split-bf16 GEMMs (sym 4 / 5 = F(2x2) / F(4x4)) on operands transposed by the transforms (the reduction runs over the tiles)
+        want3 = sorted(["wino_dy_t_kernel<%d>" % wino.tile, "wino_in_t_kernel<%d>" % wino.tile, "wino_wgrad_out_kernel<%d>" % wino.tile,
+                        "wino_gemm_x3_kernel<128, %d, %d>" % (64 if Kf <= 64 else 128, 4 if wino.tile == 2 else 5)])
+    else:
+        want3 = [n % wino.tile for n in ("wino_dy_kernel<%d>", "wino_in_kernel<%d, false>", "wino_wgrad_gemm_kernel<128, 128, 2, 2, %d>", "wino_wgrad_out_kernel<%d>")]
+    assert sorted(n for n in names3 if n != "wino_splitsum_kernel") == want3, names3
     held = torch.from_numpy(rng.standard_normal(w.shape).astype(np.float32)).to(dev)
     dwa = K.conv2d_wgrad(xd, dyd, g, into=held.clone())
     errs = {"y direct": _rel(y0, yo), "y wino": _rel(y1, yo), "dx direct": _rel(dx0, xg.grad), "dx wino": _rel(dx1, xg.grad),
@@ -208,7 +212,7 @@ def test_segmenter_step_on_the_winograd_route(dev, wino):
         res[mode] = (loss, net.store.grad_arena.clone(), net.store.arena.clone(), names)
     (l0, g0, w0, n0), (l1, g1, w1, n1) = res[0], res[1]
     assert not any("wino" in n for n in n0)
-    assert any(n.startswith("wino_wgrad_gemm_kernel") for n in n1), sorted(set(n1))
+    assert any(n.startswith("wino_gemm_x3_kernel<128, 128, %d>" % (4 if wino.tile == 2 else 5) if wino.x3 else "wino_wgrad_gemm_kernel") for n in n1), sorted(set(n1))
     kb = 0 if wino.tile == 2 else 2
     gk = "wino_gemm_x3_kernel<128, 128, %d>" if wino.x3 else "wino_gemm_kernel<128, 128, 2, 2, %d>"
     assert any(n.startswith(gk % kb) for n in n1) and any(n.startswith(gk % (kb + 1)) for n in n1), sorted(set(n1))
