@@ -62,6 +62,11 @@ struct X3Args {
 };
 
 // 8 waves: consumers 0..3 (2 x 2 wave tiles of BM/2 x BN/2), loaders 4..7.  C a multiple of 64 (a chunk = two stages).
+// PERSISTENT: one workgroup per CU (grid = min(items, 256)); hardware puts workgroup b on XCD b % 8 and every XCD owns a contiguous range of
+// the logical item ids (whole transform points / reduction splits: V3[pos], U3[pos] in ONE L2), of which workgroup j of the XCD works
+// through items j, j + 32, ...  The loaders run AHEAD across item boundaries: the stage stream never stops, so while the consumers store a
+// finished tile the first two stages of the next one are already on their way (a non-persistent launch paid ~2 us of store + ~2 us of
+// first-load latency per 20 us tile).  One descriptor per operand for the whole launch (host: all points below 2 GiB).
 template <int BM, int BN, int KIND>
 __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
     constexpr int NBUF = 3;
@@ -81,15 +86,36 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nblk = g.nblk_m * g.nblk_n;
-    int lid = (int)blockIdx.x;
-    if (g.xcd) lid = xcd_remap(lid, (int)gridDim.x);          // an XCD owns a contiguous range of tiles = whole transform points (one L2 holds U[pos], V[pos])
-    const int pz = lid / nblk;
-    const int pos = pz / g.nsplit, z = pz - pos * g.nsplit;       // consecutive logical ids = the tiles of one (point, split): one XCD's L2
-    int mt, nt;
-    tile_coords(lid - pz * nblk, g.nblk_m, g.nblk_n, g.gn, mt, nt);
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int s0 = z * g.spz;                                     // first stage of this split
-    const int nst = min(g.spz, g.C / 32 - s0);                    // its stages (even: host)
+    const int nitems = nblk * g.npos * g.nsplit;
+    // this workgroup's items: base + first, base + first + step, ... < base + cnt
+    int base = 0, cnt = nitems, first = (int)blockIdx.x, step = (int)gridDim.x;
+    if (g.xcd) {
+        const int NX = 8, x = (int)blockIdx.x % NX, q = nitems / NX, r = nitems % NX;
+        base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        cnt = q + (x < r ? 1 : 0);
+        first = (int)blockIdx.x / NX;
+        step = ((int)gridDim.x - x + NX - 1) / NX;
+    }
+    if (first >= cnt) return;                 // (uniform for the workgroup)
+    const int nstage_all = g.C / 32;
+    // item -> (point, split, tile origin, first stage, stages)
+    auto decode = [&](int item, int& pos, int& z, int& m0, int& n0, int& s0, int& nst) {
+        const int pz = item / nblk;
+        pos = pz / g.nsplit;
+        z = pz - pos * g.nsplit;
+        int mt, nt;
+        tile_coords(item - pz * nblk, g.nblk_m, g.nblk_n, g.gn, mt, nt);
+        m0 = mt * BM;
+        n0 = nt * BN;
+        s0 = z * g.spz;
+        nst = min(g.spz, nstage_all - s0);   // (even: host)
+    };
+    int gstages = 0;                          // stages of all items of this workgroup (both roles count the same barriers)
+    for (int it = first; it < cnt; it += step) {
+        int pos, z, m0, n0, s0, nst;
+        decode(base + it, pos, z, m0, n0, s0, nst);
+        gstages += nst;
+    }
 
     if (wave >= 4) {
         // ================================================= loader =================================================
@@ -97,40 +123,66 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
         // piece moves 16 bytes: global chunk lchk ^ swz(row) of row lrow (64 contiguous bytes per row) -> LDS lane-linear
         const int lw = wave - 4;
         const int lrow = lane >> 2, lchk = lane & 3;
+        const size_t planeV = (size_t)3 * g.T * g.C, planeU = (size_t)3 * g.K * g.C;       // elements per transform point
+        const __amdgpu_buffer_rsrc_t rv = make_rsrc(reinterpret_cast<const float*>(g.V), (unsigned)(planeV * g.npos * 2));
+        const __amdgpu_buffer_rsrc_t ru = make_rsrc(reinterpret_cast<const float*>(g.U), (unsigned)(planeU * g.npos * 2));
+        const int sstrideV = 3 * g.T * 64, sstrideU = 3 * g.K * 64;          // bytes per stage (32 channels of the three planes)
         unsigned avo[NRA], bvo[NRB];
         int adst[NRA], bdst[NRB];
 #pragma unroll
         for (int i = 0; i < NRA; ++i) {
-            const int q = i * NL + lw, plane = q / (BM / RPI), rb = q % (BM / RPI);
-            const int r = rb * RPI + lrow, m = m0 + r;
-            avo[i] = (m < g.T) ? (unsigned)((plane * g.T + m) * 64 + ((lchk ^ swz(r)) << 4)) : OOB2;
-            adst[i] = plane * APL + rb * (RPI * ROWB);
+            const int q = i * NL + lw;
+            adst[i] = (q / (BM / RPI)) * APL + (q % (BM / RPI)) * (RPI * ROWB);
         }
 #pragma unroll
         for (int i = 0; i < NRB; ++i) {
-            const int q = i * NL + lw, plane = q / (BN / RPI), rb = q % (BN / RPI);
-            const int r = rb * RPI + lrow, n = n0 + r;
-            bvo[i] = (n < g.K) ? (unsigned)((plane * g.K + n) * 64 + ((lchk ^ swz(r)) << 4)) : OOB2;
-            bdst[i] = 3 * APL + plane * BPL + rb * (RPI * ROWB);
+            const int q = i * NL + lw;
+            bdst[i] = 3 * APL + (q / (BN / RPI)) * BPL + (q % (BN / RPI)) * (RPI * ROWB);
         }
-        const size_t planeV = (size_t)3 * g.T * g.C, planeU = (size_t)3 * g.K * g.C;
-        const __amdgpu_buffer_rsrc_t rv = make_rsrc(reinterpret_cast<const float*>(g.V + (size_t)pos * planeV), (unsigned)(planeV * 2));
-        const __amdgpu_buffer_rsrc_t ru = make_rsrc(reinterpret_cast<const float*>(g.U + (size_t)pos * planeU), (unsigned)(planeU * 2));
-        const int sstrideV = 3 * g.T * 64, sstrideU = 3 * g.K * 64;          // bytes per stage (32 channels of the three planes)
-        auto issue = [&](int cc, int buf) {
-            unsigned char* base = lds + buf * STG;
+        // the cursor: item `c_it` (index into this workgroup's list), its next stage `c_j` of `c_nst`; offsets of the item's rows
+        int c_it = first, c_j = 0, c_nst = 0, c_s0 = 0;
+        auto setup = [&](int it) {
+            int pos, z, m0, n0;
+            decode(base + it, pos, z, m0, n0, c_s0, c_nst);
+            const unsigned pv = (unsigned)(pos * planeV * 2), pu = (unsigned)(pos * planeU * 2);
 #pragma unroll
-            for (int i = 0; i < NRA; ++i) dma16(rv, (lds_void*)(base + adst[i]), avo[i], cc * sstrideV);
+            for (int i = 0; i < NRA; ++i) {
+                const int q = i * NL + lw, plane = q / (BM / RPI), rb = q % (BM / RPI);
+                const int r = rb * RPI + lrow, m = m0 + r;
+                avo[i] = (m < g.T) ? pv + (unsigned)((plane * g.T + m) * 64 + ((lchk ^ swz(r)) << 4)) : OOB2;
+            }
 #pragma unroll
-            for (int i = 0; i < NRB; ++i) dma16(ru, (lds_void*)(base + bdst[i]), bvo[i], cc * sstrideU);
+            for (int i = 0; i < NRB; ++i) {
+                const int q = i * NL + lw, plane = q / (BN / RPI), rb = q % (BN / RPI);
+                const int r = rb * RPI + lrow, n = n0 + r;
+                bvo[i] = (n < g.K) ? pu + (unsigned)((plane * g.K + n) * 64 + ((lchk ^ swz(r)) << 4)) : OOB2;
+            }
         };
-        issue(s0, 0);
-        issue(s0 + min(1, nst - 1), 1);
+        setup(c_it);
+        // issues the cursor's stage into buffer `buf` and advances; past the last item: the last stage again (into a buffer nobody reads
+        // any more) so that every iteration issues exactly LPS pieces and the vmcnt arithmetic stays uniform
+        auto issue_next = [&](int buf) {
+            unsigned char* bp = lds + buf * STG;
+            const int cc = c_s0 + c_j;
+#pragma unroll
+            for (int i = 0; i < NRA; ++i) dma16(rv, (lds_void*)(bp + adst[i]), avo[i], cc * sstrideV);
+#pragma unroll
+            for (int i = 0; i < NRB; ++i) dma16(ru, (lds_void*)(bp + bdst[i]), bvo[i], cc * sstrideU);
+            if (c_j + 1 < c_nst) {
+                ++c_j;
+            } else if (c_it + step < cnt) {
+                c_it += step;
+                c_j = 0;
+                setup(c_it);
+            }
+        };
+        issue_next(0);
+        issue_next(1);
         int nb = 2;
-        for (int j = 0; j < nst; ++j) {
-            wait_vm<LPS>();                      // stage j has landed (stage j + 1 may be in flight)
-            __builtin_amdgcn_s_barrier();        // consumers: done with stage j - 1, i.e. with buffer (j + 2) % 3
-            issue(s0 + min(j + 2, nst - 1), nb);      // (past the end: the last stage again, into a buffer nobody reads any more)
+        for (int gsi = 0; gsi < gstages; ++gsi) {
+            wait_vm<LPS>();                      // stage gsi has landed (stage gsi + 1 may be in flight)
+            __builtin_amdgcn_s_barrier();        // consumers: done with stage gsi - 1, i.e. with buffer (gsi + 2) % 3
+            issue_next(nb);
             nb = nb == 2 ? 0 : nb + 1;
         }
         wait_vm<0>();
@@ -145,10 +197,9 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
     for (int ks = 0; ks < 2; ++ks) foff[ks] = l31 * ROWB + (((2 * ks + h) ^ swz(l31)) << 4);
 
     Acc<TM, TN> cur, total;
-    total.zero();
     int buf = 0;
     auto stage = [&](auto fc) {
-        constexpr bool first = decltype(fc)::value;
+        constexpr bool first_ = decltype(fc)::value;
         wait_lgkm0();                        // own fragment reads of the previous stage have retired
         __builtin_amdgcn_s_barrier();        // the loaders' part of this stage is in LDS
         asm volatile("" ::: "memory");
@@ -173,7 +224,7 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
-                        if (first && ks == 0 && tr == 0) {
+                        if (first_ && ks == 0 && tr == 0) {
                             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                             cur.v[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][pa][tm], bfr[ks][pb][tn], z, 0, 0, 0);
                         } else {
@@ -183,19 +234,24 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
             }
         buf = buf == 2 ? 0 : buf + 1;
     };
-    for (int j = 0; j < nst; j += 2) {          // one accumulation chunk = two stages = 64 channels (host: C % 64 == 0)
-        stage(std::true_type{});
-        stage(std::false_type{});
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) total.v[tm][tn] += cur.v[tm][tn];
-    }
     ConvArgs e{};            // plain [T][K] rows of a transform point: conv_epilogue with every feature off
     e.M = g.T;
     e.K = g.K;
     e.nsplit = 1;
-    conv_epilogue<TM, TN>(e, total, g.Mm + ((size_t)z * g.npos + pos) * g.T * g.K, m0, n0, wm0, wn0, lane, 0);
+    for (int it = first; it < cnt; it += step) {
+        int pos, z, m0, n0, s0, nst;
+        decode(base + it, pos, z, m0, n0, s0, nst);
+        total.zero();
+        for (int j = 0; j < nst; j += 2) {          // one accumulation chunk = two stages = 64 channels (host: C % 64 == 0)
+            stage(std::true_type{});
+            stage(std::false_type{});
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) total.v[tm][tn] += cur.v[tm][tn];
+        }
+        conv_epilogue<TM, TN>(e, total, g.Mm + ((size_t)z * g.npos + pos) * g.T * g.K, m0, n0, wm0, wn0, lane, 0);
+    }
 }
 
 }  // namespace
@@ -203,8 +259,8 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
 namespace pnpconv {
 
 bool wino_x3_dims_ok(int T, int C, int K) {
-    // one buffer descriptor per operand and transform point: 3 planes of T x C (K x C) bf16 below 2 GiB
-    return (C % 64) == 0 && (double)T * C * 6.0 < 2147483648.0 && (double)K * C * 6.0 < 2147483648.0;
+    // ONE buffer descriptor per operand for the whole launch: up to 36 transform points x 3 planes of T x C (K x C) bf16 below 2 GiB
+    return (C % 64) == 0 && 36.0 * T * C * 6.0 < 2147483648.0 && 36.0 * K * C * 6.0 < 2147483648.0;
 }
 
 // sym = 0 / 1: F(2x2) forward / data gradient, 2 / 3: F(4x4) (names the symbol like wino_gemm_kernel's last template argument), 4 / 5: the
@@ -222,7 +278,9 @@ int launch_wino_gemm_x3(const unsigned short* V3, const unsigned short* U3, floa
     g.nblk_m = pnp_cdiv(T, 128); g.nblk_n = pnp_cdiv(K, narrow ? 64 : 128);
     g.gn = gn; g.xcd = xcd ? 1 : 0;
     g.nsplit = nsplit; g.spz = stages_per_split;
-    const dim3 grid((unsigned)(g.nblk_m * g.nblk_n * npos * nsplit));
+    const long long nitems = (long long)g.nblk_m * g.nblk_n * npos * nsplit;
+    static const int persist = getenv("PNP_X3_PERSIST") ? atoi(getenv("PNP_X3_PERSIST")) : 1;      // (0: one item per workgroup, for A/B runs)
+    const dim3 grid((unsigned)((persist && nitems > 256) ? 256 : nitems));
     // flops = the bf16 MFMA flops the kernel EXECUTES (six products per fp32 multiply-add): its roof is the dense bf16 peak
     const double fl = 6.0 * 2.0 * npos * (double)T * C * K;
     const double by = (double)npos * (6.0 * ((double)T * C + (double)C * K) + 4.0 * (double)nsplit * T * K);
