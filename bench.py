@@ -51,10 +51,18 @@ GAN_NETCFG = {"mr_front_trainable": False, "joint_trainable": False, "ct_front_t
 ALG_GFLOP_PER_SLICE = {"joint": 399.8 + 256.2, "segmenter": 248.95}
 
 
+def is_x3(name):
+    """the split-bf16 GEMMs of the Winograd route (csrc/conv_wino_x3.hip): bf16 matrix pipe, six plane products per fp32 multiply-add"""
+    return name.startswith("wino_gemm_x3_kernel")
+
+
 def wino_alg_factor(name):
-    """a Winograd GEMM row counts the flops it EXECUTES; the convolution's algorithmic flops are 9 M^2 / (M + 2)^2 times that
-    (F(2x2, 3x3): 2.25, F(4x4, 3x3): 4; exact for full tiles).  Symbols: wino_gemm_kernel<.., 0 / 1> F(2x2), <.., 2 / 3> F(4x4);
-    wino_wgrad_gemm_kernel<.., TILE>."""
+    """a Winograd GEMM row counts the flops it EXECUTES; the convolution's algorithmic flops are 9 M^2 / (M + 2)^2 times the fp32
+    multiply-adds of the transform domain (F(2x2, 3x3): 2.25, F(4x4, 3x3): 4; exact for full tiles).  Symbols: wino_gemm_kernel<.., 0 / 1>
+    F(2x2), <.., 2 / 3> F(4x4); wino_wgrad_gemm_kernel<.., TILE>; wino_gemm_x3_kernel<.., 0 / 1 / 4> F(2x2), <.., 2 / 3 / 5> F(4x4) — the x3
+    kernel EXECUTES six bf16 MFMA products per fp32 multiply-add, so its factor is a sixth of the fp32 kernels'."""
+    if is_x3(name):
+        return (4.0 if name.rstrip(">").split(",")[-1].strip() in ("2", "3", "5") else 2.25) / 6.0
     if name.startswith("wino_gemm_kernel"):
         return 4.0 if name.rstrip(">").split(",")[-1].strip() in ("2", "3") else 2.25
     if name.startswith("wino_wgrad_gemm_kernel"):
@@ -207,8 +215,8 @@ def compact_record(res):
         r = res["roofline"]
         out["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                                  "launches", "avg_launch_ms", "share_of_conv_time", "flops_counted", "gflop_per_launch",
-                                                 "achieved_algorithmic", "algorithmic_mbytes_per_launch")}
-    for k in ("roofline_all_mfma_convs", "step_algorithmic", "segmenter_step", "joint_step", "bf16_step"):
+                                                 "achieved_algorithmic", "achieved_fp32_equivalent", "algorithmic_mbytes_per_launch") if k in r}
+    for k in ("roofline_all_mfma_convs", "step_algorithmic", "segmenter_step", "joint_step", "fp32_mfma_step", "bf16_step"):
         if k in res:
             out[k] = {a: b for a, b in res[k].items() if a not in ("workload", "unit", "steps", "warmup", "peak", "probed_steps")}
     if "cpu_baseline" in res:
@@ -287,11 +295,15 @@ def roofline_records(rows, peak):
             continue
         ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
         wf = wino_alg_factor(r["name"])
-        out.append({"kernel": r["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        x3 = is_x3(r["name"])
+        kpeak = PEAK_BF16_MFMA_TFLOPS if x3 else peak            # the x3 GEMMs run on the bf16 matrix pipe: THEIR roof is the dense bf16 peak
+        out.append({"kernel": r["name"], "bound": "mfma", "achieved": ach, "peak": kpeak, "unit": "TFLOP/s", "frac": ach / kpeak,
                     "traffic": traffic, "traffic_source": src, "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
                     "share_of_conv_time": r["ms"] / tot_ms,
-                    # direct kernels: executed = algorithmic (2*N*OH*OW*R*S*C*K); Winograd GEMMs execute 2.25x / 4x fewer
-                    "flops_counted": "executed" if wf != 1.0 else "algorithmic",
+                    # direct kernels: executed = algorithmic (2*N*OH*OW*R*S*C*K); Winograd GEMMs execute 2.25x / 4x fewer fp32
+                    # multiply-adds; the split-bf16 GEMMs execute six bf16 MFMA products for each of those
+                    "flops_counted": ("executed bf16 MFMA flops (6 plane products per fp32 multiply-add)" if x3 else "executed") if wf != 1.0 else "algorithmic",
+                    **({"achieved_fp32_equivalent": ach / 6.0} if x3 else {}),
                     "gflop_per_launch": r["flops"] / r["launches"] / 1e9,
                     "achieved_algorithmic": ach * wf,
                     "algorithmic_mbytes_per_launch": r["bytes"] / r["launches"] / 1e6})
@@ -339,6 +351,7 @@ def main():
     dev = torch.device("cuda", local)
 
     L = importlib.import_module(PKG + "._lib")
+    K = importlib.import_module(PKG + ".kernels")
     if args.dtype == "bf16":
         importlib.import_module(PKG + ".functional").set_conv_dtype("bf16")
     B = args.batch
@@ -483,6 +496,23 @@ def main():
         sub = {"workload": names[other][1], "value": world * B * sub_steps / el2, "unit": "slices/s", "ms_per_step": 1e3 * el2 / sub_steps,
                "steps": sub_steps, "warmup": sub_warm, "final_loss": loss2}
 
+    # The headline's Winograd GEMMs run on split-bf16 operands (csrc/conv_wino_x3.hip: every fp32 value as three bf16 planes, six products,
+    # fp32 accumulation in 64-channel chunks — fp32 results, measured CLOSER to float64 than the fp32 matrix pipe's: DESIGN.md §2).  The
+    # same step with every GEMM on the native fp32 MFMA pipe (PNP_WINOGRAD_X3=0, round 5's arithmetic) stays selectable and is reported
+    # beside the headline: 2 warm-up + 8 timed steps
+    sub_fp32 = None
+    if not args.no_sub and args.dtype == "f32" and world == 1 and K.wino_x3(-1) != 0:
+        prev_x3 = K.wino_x3(0)
+        try:
+            K.weights_changed()
+            nf = 8
+            el4, loss4 = timed_loop(makers[args.workload](), 2, nf, world, dev, None)
+            sub_fp32 = {"workload": "the headline step with the Winograd GEMMs on the fp32 matrix pipe (PNP_WINOGRAD_X3=0)", "value": world * B * nf / el4,
+                        "unit": "slices/s", "ms_per_step": 1e3 * el4 / nf, "steps": nf, "warmup": 2, "final_loss": loss4}
+        finally:
+            K.wino_x3(prev_x3)
+            K.weights_changed()
+
     # BASELINE configs[4] arithmetic (bf16 MFMA operands, fp32 accumulation / master weights / BN) on the headline workload, as a
     # sub-record of the driver's own line: same step definition, 2 warm-up + 10 timed steps
     sub_bf16 = None
@@ -519,10 +549,12 @@ def main():
                                         "`traffic_source` names the file), null if absent.  Symbols of the Winograd route (csrc/conv_wino.hip): `wino_gemm_kernel` / "
                                         "`wino_wgrad_gemm_kernel` are priced at the flops they EXECUTE (`flops_counted`: 2*P^2*T*C*K, T = tiles of MxM outputs, "
                                         "P = M + 2: 2.25x (F(2x2)) / 4x (F(4x4)) fewer than the convolution's 2*N*OH*OW*9*C*K — `achieved_algorithmic` is the "
-                                        "same launch priced at SURVEY 8(d)'s convolution flops), their transform kernels appear as HBM-bound rows (bytes / "
+                                        "same launch priced at SURVEY 8(d)'s convolution flops); `wino_gemm_x3_kernel` (csrc/conv_wino_x3.hip: the same GEMMs on split-bf16 operands) is priced "
+                                        "at the bf16 MFMA flops it executes — six plane products per fp32 multiply-add — against the dense bf16 peak, `achieved_fp32_equivalent` = a sixth "
+                                        "of that; the transform kernels appear as HBM-bound rows (bytes / "
                                         "duration against 8 TB/s).  `step_algorithmic`: SURVEY 8(d) flops of the whole step / the step's wall time" % PROBE_STEPS)
                 res["roofline_kernels"] = recs
-                fl, ms = sum(r["flops"] for r in rows), sum(r["ms"] for r in rows)
+                fl, ms = sum(r["flops"] / (6.0 if is_x3(r["name"]) else 1.0) for r in rows), sum(r["ms"] for r in rows)      # (fp32-equivalent executed flops)
                 # `achieved`: flops the kernels EXECUTE / all convolution kernel time (Winograd transforms included: time, no flops);
                 # `achieved_algorithmic`: SURVEY.md §8(d) convolution flops of the step / the same time — comparable across rounds whatever
                 # the route (it exceeds the fp32 MFMA peak when the Winograd routes skip enough multiplications)
@@ -536,6 +568,8 @@ def main():
         res["step_algorithmic"] = {"tflop_per_step": tfl, "achieved": tfl / (el / args.steps), "frac_of_mfma_peak": tfl / (el / args.steps) / peak}
         if sub is not None:
             res["segmenter_step" if other == "segmenter" else "joint_step"] = sub
+        if sub_fp32 is not None:
+            res["fp32_mfma_step"] = sub_fp32
         if sub_bf16 is not None:
             res["bf16_step"] = sub_bf16
         if world == 1 and not args.no_cpu_baseline:
