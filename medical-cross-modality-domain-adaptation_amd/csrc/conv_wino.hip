@@ -1202,6 +1202,10 @@ float* filter_slot(const float* w, int kind, int tile, int C, int K, int x3, siz
     if (e.valid && e.tile == tile && e.C == C && e.K == K && e.st == st && e.x3 == x3) {
         *run = false;
         g_ucache_hits.fetch_add(1, std::memory_order_relaxed);
+    } else if (e.valid && e.st != st) {
+        // a valid entry filled on ANOTHER stream: that stream's GEMM may still be reading it — do not overwrite it (and do not let two
+        // streams refill it alternately): this launch transforms into its own workspace
+        return ws_u;
     } else {
         e.valid = true; e.tile = tile; e.C = C; e.K = K; e.st = st; e.x3 = x3;
         g_ucache_fills.fetch_add(1, std::memory_order_relaxed);
@@ -1345,7 +1349,7 @@ bool wino_chosen(const pnp_conv_geom* g) { return plan_tile(g, false) != 0; }
 // workgroup); cutting each tail tile into s pieces of the reduction (s R <= 64, >= 2 stages per piece) hands every workgroup 1 / s of a tile
 // instead.  Pieces 1 .. s-1 leave their partial products in Px, summed by the output transform in a fixed order.
 static GemmPlan gemm_plan(int T, int C, int K, int NP, bool xcd) {
-    // (the tail split is OFF by default: measured within one run, tools/experiments/r5_run9.sh — the GEMMs gain 4-16 % (512->512 163 ->
+    // (the tail split is OFF by default: measured within one run, round 5: tools/experiments/README.md — the GEMMs gain 4-16 % (512->512 163 ->
     // 156 us, 256->256 59.7 -> 49.9, 256->512 data gradient 106.5 -> 88.4) but the output transform pays for finding and summing the pieces
     // (512->512 20.0 -> 26.0 us, g10 95 -> 113): joint step 248.6 -> 249.5 slices/s, inside the noise.  Kept, parity-tested, as the measured
     // answer to "balance the 2.25 tiles per workgroup": a lone workgroup on a CU already runs its extra tile at nearly twice the speed)

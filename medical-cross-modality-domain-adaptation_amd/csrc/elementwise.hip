@@ -424,7 +424,7 @@ int colreduce_plan(long long P, int C, int* nblk, int* rpb) {
 // handed out round-robin (a slot is busy for the lifetime of ONE launch and re-arms itself: two launches share a slot only if
 // TICKET_SLOTS launches are in flight at once).  Allocated at the first un-captured use (hipMalloc is not legal inside a stream
 // capture: a recording that comes first falls back to the separate combine launches).
-// OFF by default (PNP_BN_ONE_LAUNCH=1 switches it on): measured within one run on the joint step (tools/experiments/r5_run5.sh), 242.4 ->
+// OFF by default (PNP_BN_ONE_LAUNCH=1 switches it on): measured within one run on the joint step (round 5: tools/experiments/README.md), 242.4 ->
 // 208.3 slices/s — colreduce_kernel<1> 32 -> 141 us per launch: the device-scope release / acquire every workgroup needs around its
 // ticket (buffer_wbl2 + buffer_inv sc1 on a part whose 8 L2s are only coherent through them) costs far more than the two ~8 us combine
 // launches it removes.  Kept as the measured answer to VERDICT r4 #5c; parity-tested (tests/test_gpu_elementwise.py).

@@ -105,9 +105,12 @@ class ResLink(object):
 # it), so it runs next to the data gradient of the same layer and fills the partially empty dispatch rounds either kernel leaves on its
 # own (round 4, within-run A/B at B = 16: fp32 joint 166.9 -> 168.5 slices/s, segmenter 459 -> 472, bf16 joint 436.6 -> 452.3).  Only
 # inside `with wgrad_overlap():` (the step functions wrap their backward pass in it and join on exit — code that drives autograd by hand
-# keeps everything on its own stream), only for gradients that go straight into the arena, only without data parallelism (the bucket
-# hooks fire when a gradient is COMPLETE on the stream they launch from).  PNP_WGRAD_STREAM=0: off.
+# keeps everything on its own stream), only for gradients that go straight into the arena.  Under data parallelism too (round 6): a
+# bucket's all-reduce is fenced behind BOTH the compute stream and this side stream (parallel.GradReducer._launch asks
+# wgrad_side_stream()), so a gradient announced by its sink right after its kernel was queued here is complete before RCCL reads it.
+# PNP_WGRAD_STREAM=0: off.
 WGRAD_STREAM = os.environ.get("PNP_WGRAD_STREAM", "1") != "0"
+DP_WGRAD_STREAM = os.environ.get("PNP_WGRAD_STREAM_DP", "1") != "0"      # (0: round 5's behaviour — compute stream only while bucket hooks are set)
 _wgrad_side = {}
 _overlap = [0]
 
@@ -133,6 +136,13 @@ def _side_stream():
     return s
 
 
+def wgrad_side_stream():
+    """the side stream filter gradients of this device have been queued on so far (None: none yet / experiment off)"""
+    if not (WGRAD_STREAM and _wgrad_side and torch.cuda.is_available()):
+        return None
+    return _wgrad_side.get(torch.cuda.current_device())
+
+
 def join_wgrad_stream():
     """the compute stream waits for the filter gradients queued on the side stream (no-op when the experiment is off)"""
     if WGRAD_STREAM and _wgrad_side and torch.cuda.is_available():
@@ -149,7 +159,7 @@ def _wgrad(ctx, x, dy, sink):
     res = xh is not None and K.bf16r(g, 2)
     if sink is not None and sink.grad() is not None:
         into = sink.grad().view(g.R, g.S, g.C, g.K)
-        side = _side_stream() if (WGRAD_STREAM and _overlap[0] > 0 and not gradsink.has_ready_hooks()) else None
+        side = _side_stream() if (WGRAD_STREAM and _overlap[0] > 0 and (DP_WGRAD_STREAM or not gradsink.has_ready_hooks())) else None
         if side is not None:
             dyh = K.bf16_of(dy) if res else None
             side.wait_stream(torch.cuda.current_stream())        # dy (and x) are complete on the compute stream up to here

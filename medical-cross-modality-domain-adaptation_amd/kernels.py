@@ -178,9 +178,12 @@ def _wino_u(w, g, kind):
             if ent[1] is not None:
                 _lib.load().pnp_weights_changed(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(w.data_ptr() + 4 * w.numel()))
             ent[2] = w._version
-        return
+        if ent[1] is not None or not (g.R == 3 and g.S == 3 and wino_chosen(g, kind)):
+            return
+        # no buffer was bound when this filter was first seen (a small-batch forward the planner declined, a policy change): the route
+        # takes it NOW — bind one instead of leaving the cache silently off for the lifetime of the tensor
     lib = _lib.load()
-    if ent is not None:
+    if ent is not None and not (ent[0]() is w and ent[1] is None):
         _u_drop(key)
     U = None
     if g.R == 3 and g.S == 3 and wino_chosen(g, kind):          # (decided once per filter and pass: a later policy change runs un-cached)

@@ -409,6 +409,14 @@ class GradReducer(object):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.side.wait_event(ev)
+        # filter gradients run on functional's own side stream (wgrad_overlap): their sinks announce them as soon as the kernel is QUEUED
+        # there, so the all-reduce is fenced behind that stream's tail as well
+        from .functional import wgrad_side_stream
+        ws = wgrad_side_stream()
+        if ws is not None:
+            ev2 = torch.cuda.Event()
+            ev2.record(ws)
+            self.side.wait_event(ev2)
         if self.native is not None:
             self.native.allreduce_(view, self.side)       # RCCL's kernel is enqueued on the side stream itself: the event above is the fence
         else:

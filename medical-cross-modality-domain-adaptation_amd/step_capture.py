@@ -86,6 +86,9 @@ class CapturedStep(object):
         if self.adam is not None:
             self.adam.t += 1
         self._pre(seed)
+        # a replay rewrites the weights (optimiser / clip nodes) behind torch's back: ctypes writes do not bump version counters, so the
+        # transformed-filter cache and the bf16 shadows are told here, not by every caller
+        K.weights_changed()
         self.graph.replay()
         self.replays += 1
         return self.out.clone()          # (the static output tensor is overwritten by the next replay: callers may keep what they get)
