@@ -474,7 +474,49 @@ def wino_tile_coords(t, dil, th, tw):
     return t // dil, a, b, ti, tj
 
 
-def conv3x3_winograd_np(x, w, dil=1, flip_transpose=False, dtype=np.float32, pad=None, m=2):
+# ---- the split-bf16 ("x3") GEMM of csrc/conv_wino_x3.hip, restated ------------------------------------------------------------------
+def bf16_rne(a):
+    """float32 -> nearest bfloat16 (ties to even; v_cvt_pk_bf16_f32), returned as float32"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
+def split3_bf16(a):
+    """a == hi + mid + lo EXACTLY, each a bfloat16 value: hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid) (3 x 8 significand
+    bits; both differences are exact in float32) — what wino_in_kernel<M, true> / wino_filter_kernel<.., true> store"""
+    a = np.asarray(a, np.float32)
+    hi = bf16_rne(a)
+    r1 = a - hi
+    mid = bf16_rne(r1)
+    lo = bf16_rne(r1 - mid)
+    return hi, mid, lo
+
+
+X3_TERMS = ((2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0))      # (plane of A, plane of B): smallest first; mid.lo, lo.mid, lo.lo (<= 2^-26 of the product) dropped
+
+
+def gemm_x3_np(A, B, chunk=64, block=16):
+    """A [.., M, C] @ B [.., C, K] the way wino_gemm_x3_kernel contracts it: both operands as three bf16 planes, the six kept plane products
+    of a 16-deep MFMA block summed (each product is exact in float32; the block sum here in float64, rounded once — the optimistic model
+    of one v_mfma_f32_32x32x16_bf16) into a float32 accumulator that is RESTARTED every `chunk` channels, the chunk sums added into a
+    second float32 accumulator.  C must be a multiple of `chunk`."""
+    Ap = [p.astype(np.float64) for p in split3_bf16(A)]
+    Bp = [p.astype(np.float64) for p in split3_bf16(B)]
+    C = A.shape[-1]
+    assert C % chunk == 0 and chunk % (2 * block) == 0
+    total = np.zeros(A.shape[:-1] + (B.shape[-1],), np.float32)
+    for c0 in range(0, C, chunk):
+        cur = np.zeros_like(total)
+        for s0 in range(c0, c0 + chunk, 2 * block):          # a 32-channel stage = two 16-deep slices; within a slice the six terms in order
+            for k0 in (s0, s0 + block):
+                for (i, j) in X3_TERMS:
+                    cur = (cur.astype(np.float64) + Ap[i][..., k0:k0 + block] @ Bp[j][..., k0:k0 + block, :]).astype(np.float32)
+        total = total + cur
+    return total
+
+
+def conv3x3_winograd_np(x, w, dil=1, flip_transpose=False, dtype=np.float32, pad=None, m=2, x3=False):
     """Stride-1 3x3 (dilated) convolution with zero padding `pad` on every side (default dil = TF SAME; 0 = VALID, the model's g10 on its
     mirror-padded input; 2 dil = the data gradient of a VALID convolution) in the four steps of the HIP path, intermediates in `dtype`:
       V[pos][t][c] = (B^T d B)[pos]   input transform of the 4x4 patch of tile t (zeros outside the image)
@@ -482,6 +524,7 @@ def conv3x3_winograd_np(x, w, dil=1, flip_transpose=False, dtype=np.float32, pad
       M[pos] = V[pos] @ U[pos]        16 GEMMs [T x C] x [C x K]
       y tile  = A^T M A               output transform, scattered to the tile's 2x2 pixels (those inside the image)
     m = 4: F(4x4, 3x3) — 6x6 patches, 36 transform points, 4x4 output tiles, otherwise the same four steps.
+    x3: the GEMMs on split-bf16 operands with chunked accumulation (gemm_x3_np; float32 only, C % 64 == 0).
     x: [N][H][W][C] numpy, w: [3][3][C][K] numpy."""
     x = np.asarray(x, dtype)
     w = np.asarray(w, dtype)
@@ -512,7 +555,7 @@ def conv3x3_winograd_np(x, w, dil=1, flip_transpose=False, dtype=np.float32, pad
         V[:, t, :] = np.einsum("ipc,jp->ijc", r, BT).astype(dtype).reshape(n_ * n_, C)
     g1 = np.einsum("ir,rsck->isck", G, w).astype(dtype)
     U = np.einsum("isck,js->ijck", g1, G).astype(dtype).reshape(n_ * n_, C, K)
-    Mm = np.stack([V[p] @ U[p] for p in range(n_ * n_)]).astype(dtype)
+    Mm = gemm_x3_np(V, U) if x3 else np.stack([V[p] @ U[p] for p in range(n_ * n_)]).astype(dtype)
     y = np.zeros((N, Ho, Wo, K), dtype)
     for t in range(T):
         n, a, b, ti, tj = wino_tile_coords(t, dil, th, tw)
@@ -527,7 +570,7 @@ def conv3x3_winograd_np(x, w, dil=1, flip_transpose=False, dtype=np.float32, pad
     return y
 
 
-def wgrad3x3_winograd_np(x, dy, dil=1, dtype=np.float32, pad=None, nsplit=1, m=2):
+def wgrad3x3_winograd_np(x, dy, dil=1, dtype=np.float32, pad=None, nsplit=1, m=2, x3=False):
     """Filter gradient of the same convolution the way csrc/conv_wino.hip computes it — the transposition of F(2x2, 3x3):
       V[pos][t][c] = (B^T d B)[pos]                  the forward's input transform
       Y[pos][t][k] = (A y A^T)[pos]                  the 2x2 tile of dy spread to the 16 transform points (zeros for pixels outside the image)
@@ -567,6 +610,13 @@ def wgrad3x3_winograd_np(x, dy, dil=1, dtype=np.float32, pad=None, nsplit=1, m=2
     S = np.zeros((n_ * n_, C, K), dtype)
     for z in range(nsplit):
         sl = slice(z * rows, min((z + 1) * rows, T))
-        S += np.stack([V[p, sl].T @ Y[p, sl] for p in range(n_ * n_)]).astype(dtype)
+        if x3:          # split-bf16 GEMM over the tiles of this split, zero-padded to a multiple of 64 like the kernel's operands
+            Vz, Yz = V[:, sl], Y[:, sl]
+            padn = (-Vz.shape[1]) % 64
+            Vz = np.concatenate([Vz, np.zeros((Vz.shape[0], padn, C), dtype)], 1)
+            Yz = np.concatenate([Yz, np.zeros((Yz.shape[0], padn, K), dtype)], 1)
+            S += gemm_x3_np(np.ascontiguousarray(Vz.transpose(0, 2, 1)), Yz)
+        else:
+            S += np.stack([V[p, sl].T @ Y[p, sl] for p in range(n_ * n_)]).astype(dtype)
     S = S.reshape(n_, n_, C, K)
     return np.einsum("rjck,js->rsck", np.einsum("ir,ijck->rjck", G, S).astype(dtype), G).astype(dtype)

@@ -631,6 +631,53 @@ def test_winograd_restatement_equals_the_direct_convolution(m):
     assert (e_w < 5e-6 and e_w < 4 * e_d + 1e-6) if m == 2 else e_w < 2e-5, (e_w, e_d)
 
 
+def test_split_bf16_gemm_restatement():
+    """round 6: the arithmetic of csrc/conv_wino_x3.hip restated (oracle.tf_ops.split3_bf16 / gemm_x3_np): a float32 value IS the sum of its
+    three bf16 planes; the six kept plane products with fp32 accumulation in 64-channel chunks land closer to the float64 product than a
+    float32 chain does; and the F(4x4, 3x3) layer on that GEMM — forward, data gradient (a 2 560-channel reduction: the case F(4x4) on the
+    fp32 pipe was capped for) and filter gradient — is closer to the float64 convolution than on plain float32 GEMMs"""
+    rng = np.random.default_rng(23)
+    a = (rng.standard_normal(4096) * np.exp(rng.uniform(-30, 30, 4096))).astype(np.float32)
+    hi, mid, lo = T.split3_bf16(a)
+    for p in (hi, mid, lo):          # each plane is a bfloat16 value: the low 16 bits of its float32 pattern are zero
+        assert not (p.view(np.uint32) & 0xFFFF).any()
+    assert np.array_equal((hi.astype(np.float64) + mid + lo).astype(np.float32), a) and np.array_equal(hi + mid + lo, a)
+    assert np.abs(mid).max() <= np.abs(hi).max() * 2.0 ** -8 and (np.abs(lo) <= np.abs(a) * 2.0 ** -16).all()
+    A = rng.standard_normal((3, 64, 512)).astype(np.float32)
+    B = (rng.standard_normal((3, 512, 48)) * 0.05).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    seq = np.zeros(ref.shape, np.float32)
+    for c in range(512):             # one fp32 rounding per multiply-add: the fp32 matrix pipe's chain
+        seq = (seq.astype(np.float64) + A[..., c:c + 1].astype(np.float64) * B[:, c:c + 1, :]).astype(np.float32)
+    e_x3 = np.abs(T.gemm_x3_np(A, B) - ref).max() / np.abs(ref).max()
+    e_seq = np.abs(seq - ref).max() / np.abs(ref).max()
+    print("GEMM over 512 channels vs float64: fp32 chain %.2e, split-bf16 six products in 64-channel chunks %.2e" % (e_seq, e_x3))
+    assert e_x3 < 2e-7 and e_x3 < 0.5 * e_seq
+    # the whole layer
+    x = rng.standard_normal((1, 8, 8, 512)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 512, 32)) * 0.02).astype(np.float32)
+    ref = T.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), 1, 1, "SAME").numpy()
+    rel = lambda got, r: float(np.abs(got - r).max() / np.abs(r).max())
+    e4, e4x = rel(T.conv3x3_winograd_np(x, w, 1, dtype=np.float32, m=4), ref), rel(T.conv3x3_winograd_np(x, w, 1, dtype=np.float32, m=4, x3=True), ref)
+    print("F(4x4) 512->32 forward vs float64: float32 GEMMs %.2e, split-bf16 GEMMs %.2e" % (e4, e4x))
+    assert e4x < 3e-6 and e4x < e4
+    dy = rng.standard_normal((1, 8, 8, 2560)).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, 32, 2560)) * 0.01).astype(np.float32)
+    dyt = torch.from_numpy(dy).double()
+    xg = torch.zeros((1, 8, 8, 32), dtype=torch.float64, requires_grad=True)
+    T.conv2d(xg, torch.from_numpy(wd).double(), 1, 1, "SAME").backward(dyt)
+    ed, edx = (rel(T.conv3x3_winograd_np(dy, wd, 1, flip_transpose=True, dtype=np.float32, m=4, x3=f), xg.grad.numpy()) for f in (False, True))
+    print("F(4x4) data gradient over 2 560 channels vs float64: float32 GEMMs %.2e, split-bf16 GEMMs %.2e" % (ed, edx))
+    assert edx < 3e-6 and edx < ed
+    xs = rng.standard_normal((2, 16, 16, 32)).astype(np.float32)
+    dys = rng.standard_normal((2, 16, 16, 48)).astype(np.float32)
+    wt = torch.zeros((3, 3, 32, 48), dtype=torch.float64, requires_grad=True)
+    T.conv2d(torch.from_numpy(xs).double(), wt, 1, 1, "SAME").backward(torch.from_numpy(dys).double())
+    ew, ewx = (rel(T.wgrad3x3_winograd_np(xs, dys, 1, dtype=np.float32, nsplit=1, m=4, x3=f), wt.grad.numpy()) for f in (False, True))
+    print("F(4x4) filter gradient over 32 tiles (padded to 64) vs float64: float32 GEMMs %.2e, split-bf16 GEMMs %.2e" % (ew, ewx))
+    assert ewx < 3e-6
+
+
 def test_written_ranges_of_an_optimiser_mask():
     """VariableStore.written_ranges: the byte ranges kernels.weights_changed hands to pnp_weights_changed — maximal runs of selected
     chunks of the trainable arena (an optimiser over a var_list writes exactly those)"""
