@@ -38,6 +38,9 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
+#ifndef PNP_X3_AUX
+#define PNP_X3_AUX 0      // cache policy bits of the LDS-DMA loads (experiment: 1 = sc0, 2 = nt, 3 = both: no measurable difference, tools/experiments/README.md)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -46,7 +49,7 @@ __device__ __forceinline__ void wait_vm() {
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_void* dst, unsigned voff, int soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, PNP_X3_AUX);
 #endif
 }
 // 16-byte chunk swizzle of a 64-byte LDS row (conv_bf16r.hip, BKC = 32)

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Regenerates the evidence under profiles/ for the current round on a GPU box:  R=r5z bash tools/collect_round.sh   (raw output gpurun_out/$R/; copy
-# the summaries to profiles/rNN_*).  Round 5's version (the round-4 script it replaces is in the history up to bca3388).
+# Regenerates the evidence under profiles/ for the current round on a GPU box:  R=r6z bash tools/collect_round.sh   (raw output gpurun_out/$R/; copy
+# the summaries to profiles/rNN_*).  Round 6's version (round 5's is in the history at a60837a).
 # PART=A: smoke, the driver's line (with cpu_baseline), segmenter / bf16 lines, kernel traces, per-layer tables, PMC passes (library symbols only:
 # the joint step segfaults rocprofv3's counter collection otherwise), 8-rank same-device rehearsal.  PART=B: the whole -m gpu suite serially.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-R=${R:-r5z}; O=gpurun_out/$R; mkdir -p $O
+R=${R:-r6z}; O=gpurun_out/$R; mkdir -p $O
 PART=${PART:-AB}
 if [[ $PART == *A* ]]; then
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -3 $O/smoke.log
@@ -23,6 +23,9 @@ head -14 $O/joint_kernel_stats.txt | cut -c1-170
 rm -rf $O/prof_joint $O/prof_seg
 timeout 300 python tools/bench_conv.py > $O/conv_layers_f32.txt 2>/dev/null
 PROF=1 ONLY="g5/6,g7,g8,g10,cls2 128,cls3 256,cls5" timeout 200 python tools/bench_conv.py 2>/dev/null > $O/per_kernel_layers.txt
+# the route's GEMMs on the fp32 matrix pipe (X3=0) and on split-bf16 operands (X3=1: planner; X3=2: wherever the shapes allow), per kernel
+for x3 in 0 1 2; do echo "== X3=$x3 (pnp_conv2d_wino_x3)"; X3=$x3 PROF=1 ONLY="g4 128,g5,g7,g8,g10,cls1 64,cls2 64,cls2 128,cls3 128,cls3 256,cls5" WINO=1 WINO_WGRAD=1 TILE=4 timeout 300 python tools/bench_conv.py 2>/dev/null; done > $O/x3_layers_B16.txt
+timeout 400 python -m pytest tests/test_gpu_trajectory.py -q -m gpu -s -p no:cacheprovider 2>&1 | grep -vE "amdgpu.ids|^make" > $O/trajectory.log
 pmc() { local d=$1 o=$2 s=$3 rx=$4; shift 4; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
   timeout -k 10 $s rocprofv3 --pmc "${ctr[@]}" --kernel-trace --kernel-include-regex "$rx" --output-format csv -d $d -o $o -- "$@" > $d.log 2>&1; echo "PMC pass $d rc=$?"; }
 SQ="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES"
