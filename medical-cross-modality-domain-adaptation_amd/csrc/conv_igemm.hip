@@ -1161,6 +1161,35 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
         out[i] = accumulate ? out[i] + s : s;
     }
 }
+// The same sum for MANY partials of a SMALL gradient (cls1's 64->64 @256^2 filter gradient at N = 32: 300+ partials of 36 864 values —
+// one thread per value walking all of them serially ran at 0.3 TB/s, 247 us; r06 trace), in two deterministic levels and 16 bytes per lane:
+// level 1 (blockIdx.y = group g): the partials [g zg, (g + 1) zg) summed in order into the group's FIRST partial (in place: that row is read
+// by this thread only); level 2: the group rows summed in order into out.  n % 4 == 0, 16-byte aligned.
+__global__ void __launch_bounds__(256) splitk_reduce_group_kernel(float* __restrict__ part, size_t n4, int nsplit, size_t stride, int zg) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int z0 = blockIdx.y * zg, z1 = min(z0 + zg, nsplit);
+    f32x4 s = *reinterpret_cast<const f32x4*>(part + (size_t)z0 * stride + i * 4);
+    for (int z = z0 + 1; z < z1; ++z) s += *reinterpret_cast<const f32x4*>(part + (size_t)z * stride + i * 4);
+    *reinterpret_cast<f32x4*>(part + (size_t)z0 * stride + i * 4) = s;
+}
+static int launch_splitk_reduce(float* ws, float* out, size_t n, int nsplit, int accumulate, hipStream_t st) {
+    static const int two_level = getenv("PNP_SPLITK_TWO_LEVEL") ? atoi(getenv("PNP_SPLITK_TWO_LEVEL")) : 1;
+    int nz = nsplit;
+    size_t stride = n;
+    if (two_level && nsplit >= 32 && (n % 4) == 0 && ((uintptr_t)ws % 16) == 0 && n / 4 * (size_t)nsplit >= (size_t)1 << 18) {
+        const int zg = 16, ng = pnp_cdiv(nsplit, zg);
+        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)pnp_cdiv((long long)(n / 4), 256), (unsigned)ng), dim3(256), 0, st, ws, n / 4, nsplit, n, zg);
+        PNP_CHECK_LAUNCH("splitk_reduce_group_kernel");
+        nz = ng;
+        stride = n * zg;
+    }
+    int nb = pnp_cdiv((long long)n, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, out, n, nz, stride, accumulate);
+    PNP_CHECK_LAUNCH("splitk_reduce_kernel");
+    return PNP_OK;
+}
 
 // ===================================== direct forward conv for narrow outputs ============================================
 // K <= 16 output channels at stride 1 (the 40->5 logits conv and g1's 16->16 convs at 256^2, and their data gradients when the INPUT
@@ -1931,12 +1960,7 @@ int launch_wgrad_tile(ConvArgs& a, float* dw, float* ws, size_t ws_bytes, hipStr
         else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 2, VECB>), grid, dim3(NTHREADS), 0, st, a);
     }
     PNP_CHECK_LAUNCH("conv_wgrad_kernel");
-    if (nsplit > 1) {
-        int nb = pnp_cdiv((long long)nout, 256);
-        if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, dw, nout, nsplit, nout, accumulate);
-        PNP_CHECK_LAUNCH("splitk_reduce_kernel");
-    }
+    if (nsplit > 1) return launch_splitk_reduce(ws, dw, (size_t)nout, nsplit, accumulate, st);
     return PNP_OK;
 }
 
@@ -2610,12 +2634,7 @@ int pnp_conv2d_wgrad_bf16r(const void* xh, const void* dyh, float* dw, int32_t a
     dim3 grid((unsigned)(a.nblk_m * a.nblk_n * nsplit));
     PNP_REQUIRE(launch_wgrad_bf16r(a, wgrad_bf16r_tile(g), grid, st), "conv_wgrad_bf16r_kernel: no instance");
     PNP_CHECK_LAUNCH("conv_wgrad_bf16r_kernel");
-    if (nsplit > 1) {
-        int nb = pnp_cdiv((long long)nout, 256);
-        if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, dw, nout, nsplit, nout, (int)accumulate);
-        PNP_CHECK_LAUNCH("splitk_reduce_kernel");
-    }
+    if (nsplit > 1) return launch_splitk_reduce(ws, dw, (size_t)nout, nsplit, (int)accumulate, st);
     return PNP_OK;
 }
 
