@@ -16,8 +16,21 @@ from ._lib import ConvGeom, PAD_SYMMETRIC, PAD_ZERO, check
 _ws_cache = {}
 
 
+# the current stream's raw handle straight from the C extension: torch.cuda.current_stream() walks is_available() -> os.environ.get on every
+# call — 36 % of a joint step's host time at ~700 launches per step (cProfile, tools/experiments/r6_hostprof.py), and the bf16 step is
+# host-bound
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _stream_ptr():
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_stream_ptr())
 
 
 def _p(t):
@@ -41,7 +54,7 @@ def _ph(t):
 
 def workspace(nbytes, device, slot="main"):
     """Grow-only scratch buffer per (device, slot). All kernels are stream-ordered on the current stream."""
-    key = (str(device), slot, torch.cuda.current_stream().cuda_stream)
+    key = (device.index if isinstance(device, torch.device) else str(device), slot, _stream_ptr())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
