@@ -299,6 +299,8 @@ def filter_bf16(w, want_io=True, want_oi=True):
 # kernel without a bf16 output) is cast on demand.  Filter shadows are cached per filter and weight epoch: every kernel that writes
 # weights (optimisers, clip) and every host-side load bumps the epoch.
 _WEIGHT_EPOCH = [0]
+_CHANGES = []              # (epoch, ((lo, hi), ...)) of the range-limited weight writes since _CHANGE_FLOOR, oldest first
+_CHANGE_FLOOR = [0]        # a write of unknown extent happened at this epoch: everything older is stale
 _filter_cache = {}
 CAST_COUNT = [0]          # on-demand casts since the last reset (tests / profiling: how many producers still lack a bf16 output)
 
@@ -308,8 +310,14 @@ PINNED = [0]              # live CapturedStep objects: their hipGraphs hold the 
 
 def weights_changed(ranges=None):
     """weights were (or are queued to be) written.  ranges: [(first byte address, end address), ...] of what changed — the library drops
-    the transformed filters (Winograd route) of exactly those; None: everything.  The bf16 shadows follow one global epoch."""
+    the transformed filters (Winograd route) of exactly those; None: everything.  The bf16 shadows follow the same ranges (round 6: one
+    global epoch re-built the shadows of every FROZEN filter after every optimiser step — 102 filter_bf16_kernel launches per joint step)."""
     _WEIGHT_EPOCH[0] += 1
+    if ranges is None or len(_CHANGES) >= 64:
+        _CHANGES.clear()
+        _CHANGE_FLOOR[0] = _WEIGHT_EPOCH[0]         # everything filled before this epoch is stale
+    else:
+        _CHANGES.append((_WEIGHT_EPOCH[0], tuple((int(lo), int(hi)) for lo, hi in ranges)))
     if len(_filter_cache) > 1024 and not PINNED[0]:      # shadows of filters of stores that no longer exist (test suites): start over
         _filter_cache.clear()
     if _u_cache:
@@ -356,14 +364,27 @@ def set_bf16(t, h):
     return t
 
 
+def _changed_since(epoch, lo, hi):
+    """has a reported weight write touched [lo, hi) after `epoch`"""
+    if epoch < _CHANGE_FLOOR[0]:
+        return True
+    for ep, rs in reversed(_CHANGES):
+        if ep <= epoch:
+            break
+        for a, b in rs:
+            if a < hi and lo < b:
+                return True
+    return False
+
+
 def filter_shadows(w):
-    """(w_io, w_oi) of an fp32 filter [R,S,C,K], refreshed when the weight epoch has moved"""
+    """(w_io, w_oi) of an fp32 filter [R,S,C,K], refreshed when a reported weight write has touched the filter since they were made"""
     key = (w.data_ptr(), tuple(w.shape))
     ent = _filter_cache.get(key)
     # valid: same weight epoch (kernels that write weights), same torch version counter (an in-place torch op on the filter or the arena
     # it is a view of), same owner object (a new tensor on a recycled address is another filter)
     owner = w._base if w._base is not None else w
-    if ent is None or ent[0] != _WEIGHT_EPOCH[0] or ent[3] != w._version or ent[4]() is not owner:
+    if ent is None or ent[3] != w._version or ent[4]() is not owner or (ent[0] != _WEIGHT_EPOCH[0] and _changed_since(ent[0], key[0], key[0] + 4 * w.numel())):
         if ent is None:
             w_io, w_oi = filter_bf16(w)
         else:                   # refresh in place: same buffers, no allocation in the steady state
