@@ -1174,7 +1174,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_group_kernel(float* __restr
     *reinterpret_cast<f32x4*>(part + (size_t)z0 * stride + i * 4) = s;
 }
 static int launch_splitk_reduce(float* ws, float* out, size_t n, int nsplit, int accumulate, hipStream_t st) {
-    static const int two_level = getenv("PNP_SPLITK_TWO_LEVEL") ? atoi(getenv("PNP_SPLITK_TWO_LEVEL")) : 1;
+    // OFF by default: the filter gradients run on the side stream next to the data gradients, so the 0.2 ms per step this saves in kernel
+    // time does not show in the step (within-run A/B: 269.65 vs 270.65 slices/s), and it changes the summation ORDER of every split
+    // direct filter gradient — one more realisation of the chaotic fp32-vs-fp32 comparison of tests/test_gpu_adversarial.py for nothing
+    static const int two_level = getenv("PNP_SPLITK_TWO_LEVEL") ? atoi(getenv("PNP_SPLITK_TWO_LEVEL")) : 0;
     int nz = nsplit;
     size_t stride = n;
     if (two_level && nsplit >= 32 && (n % 4) == 0 && ((uintptr_t)ws % 16) == 0 && n / 4 * (size_t)nsplit >= (size_t)1 << 18) {

@@ -432,9 +432,17 @@ constexpr int TICKET_SLOTS = 512, TICKET_STRIDE = 32;
 unsigned* ticket_slot(hipStream_t st, int nslab) {
     static const int on = getenv("PNP_BN_ONE_LAUNCH") ? atoi(getenv("PNP_BN_ONE_LAUNCH")) : 0;
     if (!on || nslab + 1 > TICKET_STRIDE) return nullptr;
-    static std::atomic<unsigned*> buf{nullptr};
+    // one buffer per DEVICE (a process that drives several GPUs must not hand device 0's tickets to a launch on device 1)
+    constexpr int MAXDEV = 16;
+    static std::atomic<unsigned*> bufs[MAXDEV];
     static std::atomic<unsigned> seq{0};
     static std::mutex mx;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    std::atomic<unsigned*>& buf = bufs[dev];
     unsigned* b = buf.load(std::memory_order_acquire);
     if (!b) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
