@@ -394,6 +394,15 @@ size_t wino_wgrad_workspace_bytes(const pnp_conv_geom* g);
 int launch_wino_wgrad(const ConvArgs& a, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 // split-bf16 GEMMs of the route (conv_wino_x3.hip): M[pos] = V3[pos] x U3[pos]^T, V3 [npos][3][T][C] / U3 [npos][3][K][C] bf16 planes
 // (hi, mid, lo: their sum is the fp32 value), M [npos][T][K] fp32.  dims_ok: one buffer descriptor per operand and transform point.
+// X3_SW = reduction elements (channels; tiles for the filter gradient) per STAGE of the GEMM = the innermost extent of the operand layout
+// [pos][red / X3_SW][plane][rows][X3_SW].  32 (shipped): LDS rows of 64 bytes, two 16-deep MFMA slices per stage, three LDS stages of 48 KB.
+// 16 (-DPNP_X3_SW=16; measured, tools/experiments/README.md round 6): rows of 32 bytes, six stages of 24 KB — the GEMM is no faster (108.0
+// vs 107.7 us on 512->512: it is not the bytes in flight that bound it) and the input transform, writing 32-byte runs, is slower (30 -> 42 us).
+#ifndef PNP_X3_SW
+#define PNP_X3_SW 32
+#endif
+constexpr int X3_SW = PNP_X3_SW;
+static_assert(X3_SW == 16 || X3_SW == 32, "stage width");
 bool wino_x3_dims_ok(int T, int C, int K);
 // sym 0..3: forward / data gradient of F(2x2) / F(4x4) (nsplit = 1, stages_per_split = C / 32); 4 / 5: the filter gradient's GEMMs
 // (T := channels, C := tiles padded to a multiple of 64, reduction split nsplit ways: M = [nsplit][npos][T][K])

@@ -48,7 +48,7 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 
 // ---- split-bf16 ("x3") operands of the GEMMs (conv_wino_x3.hip): v = hi + mid + lo EXACTLY, hi = bf16(v), mid = bf16(v - hi),
 // lo = bf16(v - hi - mid) (round-to-nearest-even: v_cvt_pk_bf16_f32; both differences are exact in fp32).  Operand layout ("stage-major":
-// what ONE stage of the GEMM reads of one plane is contiguous): [pos][C / 32][plane][rows][32]; pstride = rows * 32 elements between planes.
+// what ONE stage of the GEMM reads of one plane is contiguous): [pos][C / X3_SW][plane][rows][X3_SW]; pstride = rows * X3_SW elements between planes.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
     hi = (__bf16)v;
@@ -183,9 +183,9 @@ __global__ void __launch_bounds__(NT) wino_in_kernel(WinoInArgs a) {
         f32x4 r[P][P];
         float* out = a.V + (size_t)t * a.C + c;
         // X3: V3 [pos][C / 32][plane][T][32] bf16 — transform point `pos` starts 3 * plane elements behind the previous one
-        __bf16* out3 = reinterpret_cast<__bf16*>(a.V) + ((size_t)(c >> 5) * 3 * a.g.T + t) * 32 + (c & 31);
+        __bf16* out3 = reinterpret_cast<__bf16*>(a.V) + ((size_t)(c / X3_SW) * 3 * a.g.T + t) * X3_SW + (c % X3_SW);
         auto put = [&](int pos, f32x4 v) {
-            if constexpr (X3) st4x3(out3 + (size_t)pos * 3 * plane, (size_t)a.g.T * 32, v);
+            if constexpr (X3) st4x3(out3 + (size_t)pos * 3 * plane, (size_t)a.g.T * X3_SW, v);
             else st4(out + (size_t)pos * plane, v);
         };
         if constexpr (M == 2) {
@@ -282,15 +282,15 @@ __global__ void __launch_bounds__(NT) wino_filter_kernel(const float* __restrict
         }
         if (ok) {
             float* out = U + (size_t)row * cols + col;
-            __bf16* out3 = reinterpret_cast<__bf16*>(U) + ((size_t)(row >> 5) * 3 * cols + col) * 32 + (row & 31);
+            __bf16* out3 = reinterpret_cast<__bf16*>(U) + ((size_t)(row / X3_SW) * 3 * cols + col) * X3_SW + (row % X3_SW);
             auto put = [&](int pos, float v) {
                 if constexpr (X3) {
                     __bf16 hi, mid, lo;
                     split3(v, hi, mid, lo);
                     __bf16* q = out3 + (size_t)pos * 3 * plane;
                     q[0] = hi;
-                    q[(size_t)cols * 32] = mid;
-                    q[(size_t)cols * 64] = lo;
+                    q[(size_t)cols * X3_SW] = mid;
+                    q[(size_t)cols * 2 * X3_SW] = lo;
                 } else {
                     out[(size_t)pos * plane] = v;
                 }
@@ -863,7 +863,8 @@ __device__ __forceinline__ void emit_t(const f32x4 (&v)[NP], float (*tile)[32][3
             for (int p = 0; p < PG; ++p) {
                 const float* src = &tile[p][cl][4 * tq];
                 const f32x4 w = {src[0], src[1], src[2], src[3]};
-                st4x3(out + (size_t)(r0 + p) * pos_stride + ((size_t)tblk * 3 * rows + ch0 + cl) * 32 + 4 * tq, (size_t)rows * 32, w);
+                const int tg = tblk * 32 + 4 * tq;          // first of this thread's four tiles: stage group tg / X3_SW, position tg % X3_SW
+                st4x3(out + (size_t)(r0 + p) * pos_stride + ((size_t)(tg / X3_SW) * 3 * rows + ch0 + cl) * X3_SW + (tg % X3_SW), (size_t)rows * X3_SW, w);
             }
         }
         __syncthreads();

@@ -52,37 +52,50 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_void* dst, u
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, PNP_X3_AUX);
 #endif
 }
-// 16-byte chunk swizzle of a 64-byte LDS row (conv_bf16r.hip, BKC = 32)
-__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 
 struct X3Args {
-    const unsigned short* V;      // [npos][C / 32][3][T][32]
-    const unsigned short* U;      // [npos][C / 32][3][K][32]
+    const unsigned short* V;      // [npos][C / X3_SW][3][T][X3_SW]
+    const unsigned short* U;      // [npos][C / X3_SW][3][K][X3_SW]
     float* Mm;                    // [nsplit][npos][T][K]
     int T, C, K, npos;            // rows of A, reduction length, rows of B (= output columns), transform points
     int nblk_m, nblk_n, gn, xcd;
     int nsplit, spz;              // reduction splits (filter gradient: the reduction runs over the tiles), 32-channel stages per split (even)
 };
 
-// 8 waves: consumers 0..3 (2 x 2 wave tiles of BM/2 x BN/2), loaders 4..7.  C a multiple of 64 (a chunk = two stages).
-// PERSISTENT: one workgroup per CU (grid = min(items, 256)); hardware puts workgroup b on XCD b % 8 and every XCD owns a contiguous range of
-// the logical item ids (whole transform points / reduction splits: V3[pos], U3[pos] in ONE L2), of which workgroup j of the XCD works
-// through items j, j + 32, ...  The loaders run AHEAD across item boundaries: the stage stream never stops, so while the consumers store a
-// finished tile the first two stages of the next one are already on their way (a non-persistent launch paid ~2 us of store + ~2 us of
-// first-load latency per 20 us tile).  One descriptor per operand for the whole launch (host: all points below 2 GiB).
+// Consumers: BM / 32 waves, a 64 x (BN / 2) wave tile each ((BM / 64) x 2 of them); loaders: 4 waves.  BM = 128 (shipped): 8 waves; BM = 256
+// (experiment): 12 waves, 3 per SIMD.  A stage = X3_SW (32) reduction elements of all three planes of both operands, LDS image
+// [operand][plane][row][2 X3_SW bytes] with a bank swizzle applied on the source address of the DMA and again on the fragment reads; as many
+// stages as fit 144 KB (128 x 128: 3 of 48 KB), all but one of them in flight.  C a multiple of 64 (an accumulation
+// chunk).  PERSISTENT: one workgroup per CU (grid = min(items, 256)); hardware puts workgroup b on XCD b % 8 and every XCD owns a contiguous
+// range of the logical item ids (whole transform points / reduction splits: V3[pos], U3[pos] in ONE L2), of which workgroup j of the XCD
+// works through items j, j + 32, ...  The loaders run AHEAD across item boundaries: the stage stream never stops, so while the consumers store
+// a finished tile the first stages of the next one are already on their way.  One descriptor per operand for the whole launch.
+template <int SW>
+__device__ __forceinline__ int swz(int row) {          // 16-byte chunk swizzle of an LDS row of 2 SW bytes
+    return SW == 32 ? ((row >> 2) & 3) : ((row >> 3) & 1);
+}
+
+#ifndef PNP_X3_NL
+#define PNP_X3_NL 4          // loader waves (experiment: 8 — tools/experiments/README.md round 6)
+#endif
 template <int BM, int BN, int KIND>
-__global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
-    constexpr int NBUF = 3;
+__global__ void __launch_bounds__(64 * (BM / 32 + PNP_X3_NL), (BM / 32 + PNP_X3_NL) / 4) wino_gemm_x3_kernel(X3Args g) {
+    constexpr int SW = X3_SW;
+    constexpr int NCW = BM / 32;               // consumer waves
     constexpr int kTermA[6] = {2, 1, 0, 1, 0, 0}, kTermB[6] = {0, 1, 2, 0, 1, 0};      // the kept products, smallest first: (plane of A, plane of B)
-    constexpr int NL = 4;                      // loader waves
-    constexpr int ROWB = 64, RPI = 16;         // bytes per LDS row (32 bf16), rows per DMA instruction (64 lanes x 16 B = 1 KiB contiguous)
-    constexpr int NPA = 3 * BM / RPI, NPB = 3 * BN / RPI;
-    static_assert(NPA % NL == 0 && NPB % NL == 0, "pieces must split evenly over the loader waves");
-    constexpr int NRA = NPA / NL, NRB = NPB / NL, LPS = NRA + NRB;
-    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
+    constexpr int NL = PNP_X3_NL;              // loader waves
+    constexpr int ROWB = 2 * SW;               // bytes per LDS row
+    constexpr int LPR = ROWB / 16;             // 16-byte chunks (= lanes of a DMA piece) per row
+    constexpr int RPI = 64 / LPR;              // rows per DMA instruction (64 lanes x 16 B = 1 KiB contiguous)
+    constexpr int KS = SW / 16;                // 16-deep MFMA slices per stage
+    constexpr int NPA = 3 * BM / RPI, NPB = 3 * BN / RPI, NP = NPA + NPB;      // DMA pieces of a stage: A's, then B's
+    constexpr int LPS = (NP + NL - 1) / NL;    // pieces per loader wave and stage (a wave past the end of the list repeats its previous piece)
+    constexpr int TM = 2, TN = BN / 2 / 32;
     constexpr int APL = BM * ROWB, BPL = BN * ROWB;            // bytes per plane image
     constexpr int STG = 3 * (APL + BPL);
-    static_assert(LPS < 64, "vmcnt is a 6-bit counter");
+    constexpr int NBUF = (147456 / STG) < 8 ? (147456 / STG) : 8;
+    constexpr int SPC = 64 / SW;               // stages per accumulation chunk (64 channels)
+    static_assert(NBUF >= 2 && (NBUF - 2) * LPS < 64, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(256))) unsigned char lds[NBUF * STG];
 
     const int t = threadIdx.x;
@@ -100,7 +113,7 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
         step = ((int)gridDim.x - x + NX - 1) / NX;
     }
     if (first >= cnt) return;                 // (uniform for the workgroup)
-    const int nstage_all = g.C / 32;
+    const int nstage_all = g.C / SW;
     // item -> (point, split, tile origin, first stage, stages)
     auto decode = [&](int item, int& pos, int& z, int& m0, int& n0, int& s0, int& nst) {
         const int pz = item / nblk;
@@ -111,7 +124,7 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
         m0 = mt * BM;
         n0 = nt * BN;
         s0 = z * g.spz;
-        nst = min(g.spz, nstage_all - s0);   // (even: host)
+        nst = min(g.spz, nstage_all - s0);   // (a multiple of SPC: host)
     };
     int gstages = 0;                          // stages of all items of this workgroup (both roles count the same barriers)
     for (int it = first; it < cnt; it += step) {
@@ -120,27 +133,28 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
         gstages += nst;
     }
 
-    if (wave >= 4) {
+    if (wave >= NCW) {
         // ================================================= loader =================================================
-        // piece q of an operand = plane q / (rows / 16), row block q % (rows / 16); this wave owns q = i NL + lw.  Lane (lrow, lchk) of a
-        // piece moves 16 bytes: global chunk lchk ^ swz(row) of row lrow (64 contiguous bytes per row) -> LDS lane-linear
-        const int lw = wave - 4;
-        const int lrow = lane >> 2, lchk = lane & 3;
+        // piece q of an operand = plane q / (rows / RPI), row block q % (rows / RPI); this wave owns q = i NL + lw.  Lane (lrow, lchk) of a
+        // piece moves 16 bytes: global chunk lchk ^ swz(row) of row lrow (2 SW contiguous bytes per row) -> LDS lane-linear
+        const int lw = wave - NCW;
+        const int lrow = lane / LPR, lchk = lane % LPR;
         const size_t planeV = (size_t)3 * g.T * g.C, planeU = (size_t)3 * g.K * g.C;       // elements per transform point
         const __amdgpu_buffer_rsrc_t rv = make_rsrc(reinterpret_cast<const float*>(g.V), (unsigned)(planeV * g.npos * 2));
         const __amdgpu_buffer_rsrc_t ru = make_rsrc(reinterpret_cast<const float*>(g.U), (unsigned)(planeU * g.npos * 2));
-        const int sstrideV = 3 * g.T * 64, sstrideU = 3 * g.K * 64;          // bytes per stage (32 channels of the three planes)
-        unsigned avo[NRA], bvo[NRB];
-        int adst[NRA], bdst[NRB];
+        const int sstrideV = 3 * g.T * ROWB, sstrideU = 3 * g.K * ROWB;          // bytes per stage (SW channels of the three planes)
+        // this wave's pieces: q = i NL + lw (past the end: its previous piece again — the same bytes to the same place, so that every wave
+        // issues exactly LPS pieces per stage); q < NPA: A, plane q / (BM / RPI), row block q % (BM / RPI); else B likewise
+        unsigned pvo[LPS];
+        int pdst[LPS];
+        bool pisa[LPS];
 #pragma unroll
-        for (int i = 0; i < NRA; ++i) {
-            const int q = i * NL + lw;
-            adst[i] = (q / (BM / RPI)) * APL + (q % (BM / RPI)) * (RPI * ROWB);
-        }
-#pragma unroll
-        for (int i = 0; i < NRB; ++i) {
-            const int q = i * NL + lw;
-            bdst[i] = 3 * APL + (q / (BN / RPI)) * BPL + (q % (BN / RPI)) * (RPI * ROWB);
+        for (int i = 0; i < LPS; ++i) {
+            int q = i * NL + lw;
+            if (q >= NP) q -= NL;
+            pisa[i] = q < NPA;
+            const int qq = pisa[i] ? q : q - NPA, rows = pisa[i] ? BM : BN;
+            pdst[i] = (pisa[i] ? 0 : 3 * APL) + (qq / (rows / RPI)) * (pisa[i] ? APL : BPL) + (qq % (rows / RPI)) * (RPI * ROWB);
         }
         // the cursor: item `c_it` (index into this workgroup's list), its next stage `c_j` of `c_nst`; offsets of the item's rows
         int c_it = first, c_j = 0, c_nst = 0, c_s0 = 0;
@@ -149,16 +163,14 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
             decode(base + it, pos, z, m0, n0, c_s0, c_nst);
             const unsigned pv = (unsigned)(pos * planeV * 2), pu = (unsigned)(pos * planeU * 2);
 #pragma unroll
-            for (int i = 0; i < NRA; ++i) {
-                const int q = i * NL + lw, plane = q / (BM / RPI), rb = q % (BM / RPI);
-                const int r = rb * RPI + lrow, m = m0 + r;
-                avo[i] = (m < g.T) ? pv + (unsigned)((plane * g.T + m) * 64 + ((lchk ^ swz(r)) << 4)) : OOB2;
-            }
-#pragma unroll
-            for (int i = 0; i < NRB; ++i) {
-                const int q = i * NL + lw, plane = q / (BN / RPI), rb = q % (BN / RPI);
-                const int r = rb * RPI + lrow, n = n0 + r;
-                bvo[i] = (n < g.K) ? pu + (unsigned)((plane * g.K + n) * 64 + ((lchk ^ swz(r)) << 4)) : OOB2;
+            for (int i = 0; i < LPS; ++i) {
+                int q = i * NL + lw;
+                if (q >= NP) q -= NL;
+                const bool isa = q < NPA;
+                const int qq = isa ? q : q - NPA, rows = isa ? BM : BN, lim = isa ? g.T : g.K;
+                const int plane = qq / (rows / RPI), rb = qq % (rows / RPI);
+                const int r = rb * RPI + lrow, m = (isa ? m0 : n0) + r;
+                pvo[i] = (m < lim) ? (isa ? pv : pu) + (unsigned)((plane * lim + m) * ROWB + ((lchk ^ swz<SW>(r)) << 4)) : OOB2;
             }
         };
         setup(c_it);
@@ -168,9 +180,10 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
             unsigned char* bp = lds + buf * STG;
             const int cc = c_s0 + c_j;
 #pragma unroll
-            for (int i = 0; i < NRA; ++i) dma16(rv, (lds_void*)(bp + adst[i]), avo[i], cc * sstrideV);
-#pragma unroll
-            for (int i = 0; i < NRB; ++i) dma16(ru, (lds_void*)(bp + bdst[i]), bvo[i], cc * sstrideU);
+            for (int i = 0; i < LPS; ++i) {
+                if (pisa[i]) dma16(rv, (lds_void*)(bp + pdst[i]), pvo[i], cc * sstrideV);
+                else dma16(ru, (lds_void*)(bp + pdst[i]), pvo[i], cc * sstrideU);
+            }
             if (c_j + 1 < c_nst) {
                 ++c_j;
             } else if (c_it + step < cnt) {
@@ -179,25 +192,25 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
                 setup(c_it);
             }
         };
-        issue_next(0);
-        issue_next(1);
-        int nb = 2;
+#pragma unroll
+        for (int b_ = 0; b_ < NBUF - 1; ++b_) issue_next(b_);
+        int nb = NBUF - 1;
         for (int gsi = 0; gsi < gstages; ++gsi) {
-            wait_vm<LPS>();                      // stage gsi has landed (stage gsi + 1 may be in flight)
-            __builtin_amdgcn_s_barrier();        // consumers: done with stage gsi - 1, i.e. with buffer (gsi + 2) % 3
+            wait_vm<(NBUF - 2) * LPS>();         // stage gsi has landed (the NBUF - 2 younger ones may be in flight)
+            __builtin_amdgcn_s_barrier();        // consumers: done with stage gsi - 1, i.e. with buffer (gsi + NBUF - 1) % NBUF
             issue_next(nb);
-            nb = nb == 2 ? 0 : nb + 1;
+            nb = nb == NBUF - 1 ? 0 : nb + 1;
         }
         wait_vm<0>();
         return;
     }
     // ================================================= consumer =================================================
-    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (BN / 2);
     // fragment reads: lane (l31, h) reads row l31 of a 32-row block, 16-byte chunk (2 ks + h) ^ swz(row)
     const int l31 = lane & 31, h = lane >> 5;
-    int foff[2];
+    int foff[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) foff[ks] = l31 * ROWB + (((2 * ks + h) ^ swz(l31)) << 4);
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = l31 * ROWB + (((2 * ks + h) ^ swz<SW>(l31)) << 4);
 
     Acc<TM, TN> cur, total;
     int buf = 0;
@@ -208,9 +221,9 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
         asm volatile("" ::: "memory");
         const unsigned char* A = lds + buf * STG + wm0 * ROWB;
         const unsigned char* B = lds + buf * STG + 3 * APL + wn0 * ROWB;
-        bf16x8 af[2][3][TM], bfr[2][3][TN];
+        bf16x8 af[KS][3][TM], bfr[KS][3][TN];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -219,7 +232,7 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
                 for (int tn = 0; tn < TN; ++tn) bfr[ks][p][tn] = *reinterpret_cast<const bf16x8*>(B + p * BPL + tn * (32 * ROWB) + foff[ks]);
             }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int tr = 0; tr < 6; ++tr) {
                 const int pa = kTermA[tr], pb = kTermB[tr];
@@ -235,7 +248,7 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
                         }
                     }
             }
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
     };
     ConvArgs e{};            // plain [T][K] rows of a transform point: conv_epilogue with every feature off
     e.M = g.T;
@@ -245,9 +258,10 @@ __global__ void __launch_bounds__(512, 2) wino_gemm_x3_kernel(X3Args g) {
         int pos, z, m0, n0, s0, nst;
         decode(base + it, pos, z, m0, n0, s0, nst);
         total.zero();
-        for (int j = 0; j < nst; j += 2) {          // one accumulation chunk = two stages = 64 channels (host: C % 64 == 0)
+        for (int j = 0; j < nst; j += SPC) {        // one accumulation chunk = 64 channels (host: C % 64 == 0)
             stage(std::true_type{});
-            stage(std::false_type{});
+#pragma unroll
+            for (int q = 1; q < SPC; ++q) stage(std::false_type{});
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -273,12 +287,20 @@ int launch_wino_gemm_x3(const unsigned short* V3, const unsigned short* U3, floa
                         int nsplit, int stages_per_split, hipStream_t st) {
     PNP_REQUIRE(wino_x3_dims_ok(T, C, K), "launch_wino_gemm_x3: operands too large for one buffer descriptor per transform point");
     PNP_REQUIRE(sym >= 0 && sym < 6, "launch_wino_gemm_x3: bad symbol index");
-    PNP_REQUIRE(nsplit >= 1 && (stages_per_split % 2) == 0 && (long long)nsplit * stages_per_split >= C / 32 && (long long)(nsplit - 1) * stages_per_split < C / 32,
+    // (callers count stages of 32 reduction elements; the kernel's stages are X3_SW wide)
+    stages_per_split *= 32 / X3_SW;
+    PNP_REQUIRE(nsplit >= 1 && (stages_per_split % (64 / X3_SW)) == 0 && (long long)nsplit * stages_per_split >= C / X3_SW &&
+                    (long long)(nsplit - 1) * stages_per_split < C / X3_SW,
                 "launch_wino_gemm_x3: bad reduction split");
     X3Args g{};
     g.V = V3; g.U = U3; g.Mm = Mm; g.T = T; g.C = C; g.K = K; g.npos = npos;
     const bool narrow = K <= 64;
-    g.nblk_m = pnp_cdiv(T, 128); g.nblk_n = pnp_cdiv(K, narrow ? 64 : 128);
+    // 256-row tiles (8 consumer waves + 4 loaders = 3 waves per SIMD, 0.75 x the operand traffic of 128 x 128): built and measured —
+    // SLOWER (512->512 108 -> 114-123 us with two LDS stages of 72 KB as well as with four of 36 KB: the data rate per CU falls from 13 to
+    // 9 bytes per clock; tools/experiments/README.md round 6).  Off; PNP_X3_BM=256 selects it for A/B runs.
+    static const int bm_force = getenv("PNP_X3_BM") ? atoi(getenv("PNP_X3_BM")) : 0;
+    const bool tall = !narrow && bm_force == 256 && T >= 256;
+    g.nblk_m = pnp_cdiv(T, tall ? 256 : 128); g.nblk_n = pnp_cdiv(K, narrow ? 64 : 128);
     g.gn = gn; g.xcd = xcd ? 1 : 0;
     g.nsplit = nsplit; g.spz = stages_per_split;
     const long long nitems = (long long)g.nblk_m * g.nblk_n * npos * nsplit;
@@ -287,9 +309,19 @@ int launch_wino_gemm_x3(const unsigned short* V3, const unsigned short* U3, floa
     // flops = the bf16 MFMA flops the kernel EXECUTES (six products per fp32 multiply-add): its roof is the dense bf16 peak
     const double fl = 6.0 * 2.0 * npos * (double)T * C * K;
     const double by = (double)npos * (6.0 * ((double)T * C + (double)C * K) + 4.0 * (double)nsplit * T * K);
-    PnpProfScope ps(sym >= 4 ? PNP_PROF_CONV_WGRAD : prof_class(sym & 1), st, fl, by, "wino_gemm_x3_kernel<128, %d, %d>", narrow ? 64 : 128, sym);
-#define PNP_X3_LAUNCH(BN_, SYM_) hipLaunchKernelGGL((wino_gemm_x3_kernel<128, BN_, SYM_>), grid, dim3(512), 0, st, g)
-    if (narrow) {
+    PnpProfScope ps(sym >= 4 ? PNP_PROF_CONV_WGRAD : prof_class(sym & 1), st, fl, by, "wino_gemm_x3_kernel<%d, %d, %d>", tall ? 256 : 128, narrow ? 64 : 128, sym);
+#define PNP_X3_LAUNCH(BN_, SYM_) hipLaunchKernelGGL((wino_gemm_x3_kernel<128, BN_, SYM_>), grid, dim3(64 * (4 + PNP_X3_NL)), 0, st, g)
+#define PNP_X3_LAUNCH_TALL(SYM_) hipLaunchKernelGGL((wino_gemm_x3_kernel<256, 128, SYM_>), grid, dim3(64 * (8 + PNP_X3_NL)), 0, st, g)
+    if (tall) {
+        switch (sym) {
+            case 0: PNP_X3_LAUNCH_TALL(0); break;
+            case 1: PNP_X3_LAUNCH_TALL(1); break;
+            case 2: PNP_X3_LAUNCH_TALL(2); break;
+            case 3: PNP_X3_LAUNCH_TALL(3); break;
+            case 4: PNP_X3_LAUNCH_TALL(4); break;
+            default: PNP_X3_LAUNCH_TALL(5); break;
+        }
+    } else if (narrow) {
         switch (sym) {
             case 0: PNP_X3_LAUNCH(64, 0); break;
             case 1: PNP_X3_LAUNCH(64, 1); break;
@@ -309,6 +341,7 @@ int launch_wino_gemm_x3(const unsigned short* V3, const unsigned short* U3, floa
         }
     }
 #undef PNP_X3_LAUNCH
+#undef PNP_X3_LAUNCH_TALL
     PNP_CHECK_LAUNCH("wino_gemm_x3_kernel");
     return PNP_OK;
 }

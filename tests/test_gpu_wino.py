@@ -41,7 +41,8 @@ def _ran(L, fn, cls):
     out = fn()
     torch.cuda.synchronize()
     L.prof_enable(0)
-    return out, [r["name"] for r in L.prof_summary()]
+    # (the split-bf16 GEMM has a 128-row and a 256-row tile instance, chosen by the launch's shape: one name here)
+    return out, [r["name"].replace("wino_gemm_x3_kernel<256,", "wino_gemm_x3_kernel<128,") for r in L.prof_summary()]
 
 
 @pytest.fixture(params=[(2, 0), (4, 0), (2, 1), (4, 1)], ids=["F2x2", "F4x4", "F2x2-x3", "F4x4-x3"])
@@ -208,7 +209,7 @@ def test_segmenter_step_on_the_winograd_route(dev, wino):
         loss = float(tr.train_step(x, y, 0.75, 11))
         torch.cuda.synchronize()
         L.prof_enable(0)
-        names = [r["name"] for r in L.prof_summary()]
+        names = [r["name"].replace("wino_gemm_x3_kernel<256,", "wino_gemm_x3_kernel<128,") for r in L.prof_summary()]
         res[mode] = (loss, net.store.grad_arena.clone(), net.store.arena.clone(), names)
     (l0, g0, w0, n0), (l1, g1, w1, n1) = res[0], res[1]
     assert not any("wino" in n for n in n0)

@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256, 1) k(const float* __restrict__ src, size_
 
 // MODE 2: eight waves — waves 0..3 only contract (NM MFMAs per iteration + the LDS reads of the data the loaders staged), waves 4..7 only
 // stream (NL x 1 KiB each per iteration -> LDS); one barrier per iteration
-template <int NL, int NM>
+// NSET = register staging sets of a loader wave = iterations of lookahead (bytes in flight per CU = NSET x 4 waves x NL KiB)
+template <int NL, int NM, int NSET = 2>
 __global__ void __launch_bounds__(512, 2) k2(const float* __restrict__ src, size_t span_f4, float* out, int iters) {
     __shared__ f32x4 lds[2][NL * 256];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -77,22 +78,22 @@ __global__ void __launch_bounds__(512, 2) k2(const float* __restrict__ src, size
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
     float sum = 0.f;
     if (loader) {
-        f32x4 st[2][NL];
+        f32x4 st[NSET][NL];
         auto issue = [&](int set, int it) {
 #pragma unroll
             for (int i = 0; i < NL; ++i) st[set][i] = s4[((((size_t)it * nw + gw) * NL + i) * 64 + lane) % span_f4];
         };
         auto body = [&](int set, int it) {
 #pragma unroll
-            for (int i = 0; i < NL; ++i) lds[set][(i * 4 + w4) * 64 + lane] = st[set][i];
-            issue(set, it + 2);
+            for (int i = 0; i < NL; ++i) lds[it & 1][(i * 4 + w4) * 64 + lane] = st[set][i];
+            issue(set, it + NSET);
             __syncthreads();
         };
-        issue(0, 0);
-        issue(1, 1);
-        for (int it = 0; it < iters; it += 2) {
-            body(0, it);
-            body(1, it + 1);
+#pragma unroll
+        for (int s_ = 0; s_ < NSET; ++s_) issue(s_, s_);
+        for (int it = 0; it < iters; it += NSET) {
+#pragma unroll
+            for (int s_ = 0; s_ < NSET; ++s_) body(s_, it + s_);
         }
     } else {
         f32x16 acc[4];
@@ -119,16 +120,16 @@ __global__ void __launch_bounds__(512, 2) k2(const float* __restrict__ src, size
     out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
 }
 
-template <int NL, int NM>
+template <int NL, int NM, int NSET = 2>
 void run2(const float* src, size_t span_bytes, float* d, const char* what) {
-    const int iters = 512, nblk = 256;
+    const int iters = 768, nblk = 256;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL((k2<NL, NM>), dim3(nblk), dim3(512), 0, 0, src, span_bytes / 16, d, 32);
+    hipLaunchKernelGGL((k2<NL, NM, NSET>), dim3(nblk), dim3(512), 0, 0, src, span_bytes / 16, d, 48);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k2<NL, NM>), dim3(nblk), dim3(512), 0, 0, src, span_bytes / 16, d, iters);
+    hipLaunchKernelGGL((k2<NL, NM, NSET>), dim3(nblk), dim3(512), 0, 0, src, span_bytes / 16, d, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -136,7 +137,7 @@ void run2(const float* src, size_t span_bytes, float* d, const char* what) {
     const double us_it = ms * 1e3 / iters;
     const double tbs = (double)nblk * 4 * NL * 1024.0 * iters / (ms * 1e-3) / 1e12;
     const double tf = (double)nblk * 4 * NM * 32768.0 * iters / (ms * 1e-3) / 1e12;
-    printf("%-10s span %6.0f MB  loads/it %2d  mfma/it %2d  mode 2: %7.3f us per iteration  %6.2f TB/s  %7.1f TF/s\n", what, span_bytes / 1048576.0, NL, NM, us_it, tbs, tf);
+    printf("%-10s span %6.0f MB  loads/it %2d  mfma/it %2d  mode 2, %d sets (%3d KiB in flight per CU): %7.3f us per iteration  %6.2f TB/s  %7.1f TF/s\n", what, span_bytes / 1048576.0, NL, NM, NSET, NSET * 4 * NL, us_it, tbs, tf);
 }
 
 template <int NL, int NM, int MODE>
@@ -166,7 +167,7 @@ int main() {
     hipMalloc(&src, big);
     hipMemset(src, 0, big);
     hipMalloc(&d, 4096 * 256 * sizeof(float));
-    for (size_t span : {(size_t)64 << 20, (size_t)12 << 20, (size_t)2 << 20}) {
+    for (size_t span : {(size_t)160 << 20, (size_t)12 << 20}) {
         run<12, 0, 0>(src, span, d, "data");
         run<0, 48, 0>(src, span, d, "mfma");
         run<12, 48, 0>(src, span, d, "both");
@@ -179,6 +180,12 @@ int main() {
         run2<12, 48>(src, span, d, "4+4 both");
         run2<12, 96>(src, span, d, "4+4 both");
         run2<6, 48>(src, span, d, "4+4 both");
+        run2<12, 48, 3>(src, span, d, "4+4 both");
+        run2<12, 48, 4>(src, span, d, "4+4 both");
+        run2<12, 0, 3>(src, span, d, "4+4 data");
+        run2<12, 0, 4>(src, span, d, "4+4 data");
+        run2<6, 48, 4>(src, span, d, "4+4 both");
+        run2<6, 48, 8>(src, span, d, "4+4 both");
     }
     return 0;
 }
