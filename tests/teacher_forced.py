@@ -15,10 +15,7 @@ TOL = 1e-4
 EPS = 1e-3
 
 
-def rel(a, b):
-    a = torch.as_tensor(a).detach().cpu().double()
-    b = torch.as_tensor(b).detach().cpu().double()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+from parity_util import batch_moments64, rel  # noqa: E402,F401  (rel: float64 on the device the product's result lives on)
 
 
 class Checker(object):
@@ -67,9 +64,7 @@ class Checker(object):
             mm0, mv0 = self.var32(b + "/moving_mean"), self.var32(b + "/moving_variance")
             xc = f32(yd)
             if u["is_train"]:
-                y64 = yd.detach().double().reshape(P, -1)
-                m64 = y64.mean(0)
-                v64 = ((y64 - m64) ** 2).mean(0)
+                m64, v64 = batch_moments64(yd, self.dev)
                 # batch statistics the way the product gets them: from the convolution's epilogue where the planner offers it
                 mm, mv = mm0.clone(), mv0.clone()
                 if K.conv_stats_parts(g) > 0:

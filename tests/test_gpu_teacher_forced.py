@@ -69,10 +69,7 @@ def _state(seed):
     return sd
 
 
-def _rel(a, b):
-    a = torch.as_tensor(a).detach().cpu().double()
-    b = torch.as_tensor(b).detach().cpu().double()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+from parity_util import batch_moments64, rel as _rel  # noqa: E402  (float64, on the device the product's result lives on)
 
 
 def _run_units(dev, B, dtype, keep_prob, seed):
@@ -108,8 +105,7 @@ def _run_units(dev, B, dtype, keep_prob, seed):
             xc = f32(yd)
             mean_h, var_h = K.bn_stats(xc)
             P = yd.numel() // yd.shape[-1]
-            m64 = yd.detach().double().reshape(P, -1).mean(0)
-            v64 = ((yd.detach().double().reshape(P, -1) - m64) ** 2).mean(0)
+            m64, v64 = batch_moments64(yd, dev)
             errs["mean"], errs["var"] = _rel(mean_h, m64) if float(m64.abs().max()) > 1e-3 else 0.0, _rel(var_h, v64)
             mean_d, var_d = m64.float().to(dev), v64.float().to(dev)
             scd = f32(sc) if sc is not None else None
