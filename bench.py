@@ -367,11 +367,6 @@ def main():
     # captured step is no faster and loses the side-stream overlap of the filter gradients (hipGraph replay serialised the branch)
     use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and args.batch <= 4)
     assert not (use_graph and world > 1), "--graph on: step capture is single-GPU (the bucketed all-reduce runs on a side stream)"
-    if use_graph and args.dtype == "bf16" and args.batch > 4:
-        # KNOWN DEFECT (found in round 6, present in round 5's tree as well): replaying the captured bf16 joint step at B = 16 ends in a GPU
-        # memory access fault ("write access to a read-only page"); captured bf16 steps are tested and used at B <= 4 only (--graph auto)
-        print("bench: --graph on with --dtype bf16 at B > 4 is a known defect (GPU memory fault on replay): running the eager step", file=sys.stderr)
-        use_graph = False
     probing = {"on": False}
 
     captured = {"ok": None}

@@ -52,11 +52,20 @@ def _ph(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_ws_retired = []     # buffers replaced by a larger one while a recorded step exists: its hipGraph holds their ADDRESSES
+
+
 def workspace(nbytes, device, slot="main"):
-    """Grow-only scratch buffer per (device, slot). All kernels are stream-ordered on the current stream."""
+    """Grow-only scratch buffer per (device, slot, stream). All kernels are stream-ordered on the current stream.
+    A buffer that has to grow is normally dropped (the allocator recycles it in stream order).  Not while a CapturedStep is alive or a
+    stream is recording: a hipGraph replays the ADDRESS it recorded, so the replaced buffer is kept (`_ws_retired`, emptied when the last
+    recorded step dies).  Round 6: the generator step's warm-up grew the filter-gradient side stream's buffer AFTER the discriminator
+    step had been recorded with the smaller one — the bf16 joint step at B = 16 faulted on replay ("write access to a read-only page")."""
     key = (device.index if isinstance(device, torch.device) else str(device), slot, _stream_ptr())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and (PINNED[0] > 0 or torch.cuda.is_current_stream_capturing()):
+            _ws_retired.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf

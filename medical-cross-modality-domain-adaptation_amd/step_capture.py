@@ -30,6 +30,8 @@ import weakref
 
 def _unpin():
     K.PINNED[0] -= 1
+    if K.PINNED[0] <= 0:
+        del K._ws_retired[:]         # no recording left that could replay their addresses
 
 
 class CapturedStep(object):

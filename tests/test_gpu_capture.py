@@ -106,6 +106,22 @@ def test_captured_gan_steps_equal_eager_bit_for_bit(dev):
     net_c, tr_c = make()
     net_c.store.load_state_dict(sd)
     tr_c.capture_steps(mr, ct, 0.75)
+    # A workspace that has to grow AFTER a step was recorded (another batch shape, the other step's warm-up) must not pull the recorded
+    # address from under the hipGraph (round 6: the bf16 joint step at B = 16 faulted on replay — the generator step's warm-up had grown
+    # the filter-gradient side stream's buffer, and the discriminator graph still wrote into the freed one).  Force it: grow the side
+    # stream's buffer, hand every cached block back to the driver, overwrite what the allocator gives out next.
+    K, F = pkg("kernels"), pkg("functional")
+    side = F.wgrad_side_stream()
+    assert side is not None and K.PINNED[0] >= 2
+    old = K._ws_cache[(dev.index, "main", side.cuda_stream)]
+    p_old, n_old = old.data_ptr(), old.numel()
+    del old
+    with torch.cuda.stream(side):
+        K.workspace(2 * n_old + (64 << 20), dev)
+    assert any(r.data_ptr() == p_old for r in K._ws_retired)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = torch.full((n_old + (64 << 20),), 0x7F, dtype=torch.uint8, device=dev)
     net_c.store.load_state_dict(sd)
     for o in (tr_c.dis_optimizer, tr_c.gen_optimizer):          # RMSProp slots back to their initial value (ones: TF's initial ms)
         o.ms.copy_(torch.ones_like(o.ms))
@@ -113,3 +129,4 @@ def test_captured_gan_steps_equal_eager_bit_for_bit(dev):
     assert tr_c._cap["dis"].replays == 2 and tr_c._cap["gen"].replays == 2
     assert lc == le, (lc, le)
     assert torch.equal(net_c.store.arena.detach().cpu(), w_e)
+    assert int(junk.min()) == 0x7F and int(junk.max()) == 0x7F          # nothing replayed into memory the recordings no longer own
