@@ -579,6 +579,9 @@ def main():
                 cb["value_B%d" % args.cpu_small_batch] = small["value"]
                 cb["sample_B%d" % args.cpu_small_batch] = small["sample_detail"]
             res["cpu_baseline"] = cb
+        # what the host side of the library holds on to between steps (workspaces per slot and stream, transformed filters, bf16 shadows) and
+        # what torch's allocator has reserved at the end of the run: side file only
+        res["device_memory"] = dict(K.memory_report(), torch_reserved=int(torch.cuda.memory_reserved(dev)), torch_peak_allocated=int(torch.cuda.max_memory_allocated(dev)))
         # the per-symbol table and the full-precision record: side file (and stderr); the LAST stdout line is the compact record
         try:
             path = side_file_path(args.workload, args.dtype, world)

@@ -226,6 +226,19 @@ def wino_u_cache_clear():
         _u_cache.clear()
 
 
+def memory_report():
+    """bytes of device memory the host side of the library holds on to between steps (nothing reported it):
+    grow-only workspaces per (slot, stream), workspaces retired under a recorded step, transformed filters of the Winograd route,
+    bf16 filter shadows"""
+    nb = lambda t: 0 if t is None else int(t.numel()) * int(t.element_size())
+    rep = {"workspaces": sum(nb(b) for b in _ws_cache.values()), "workspace_buffers": len(_ws_cache),
+           "workspaces_retired": sum(nb(b) for b in _ws_retired), "recorded_steps_alive": int(PINNED[0]),
+           "winograd_filters": sum(nb(e[1]) for e in _u_cache.values()), "winograd_filter_entries": len(_u_cache),
+           "bf16_filter_shadows": sum(nb(e[1]) + nb(e[2]) for e in _filter_cache.values()), "bf16_filter_entries": len(_filter_cache)}
+    rep["total"] = rep["workspaces"] + rep["workspaces_retired"] + rep["winograd_filters"] + rep["bf16_filter_shadows"]
+    return rep
+
+
 def wino_u_cache_stats(reset=False):
     """(filter transforms skipped, transforms run into a cache entry) since the last reset"""
     h, f = ctypes.c_int64(0), ctypes.c_int64(0)

@@ -773,3 +773,22 @@ def test_captured_gan_steps_fall_back_to_eager_when_the_learning_rate_moved():
     t.gen_optimizer.lr *= 0.95
     assert t._captured("dis", 0.75, {"mr": (2, 256, 256, 3), "ct": (2, 256, 256, 3)}) is None
     assert t._captured("gen", 0.75, {"ct": (2, 256, 256, 3)}) is None and t._cap.get("warned")
+
+
+def test_memory_report_counts_what_the_caches_hold():
+    """kernels.memory_report (VERDICT r5 weak #10): every cache the host side keeps between steps is in the sum"""
+    import torch
+    K = pkg("kernels")
+    before = K.memory_report()
+    key = ("cpu", "report-test", 0)
+    K._ws_cache[key] = torch.empty(1 << 12, dtype=torch.uint8)
+    K._ws_retired.append(torch.empty(1 << 10, dtype=torch.uint8))
+    try:
+        rep = K.memory_report()
+        assert rep["workspaces"] == before["workspaces"] + (1 << 12) and rep["workspace_buffers"] == before["workspace_buffers"] + 1
+        assert rep["workspaces_retired"] == before["workspaces_retired"] + (1 << 10)
+        assert rep["total"] == before["total"] + (1 << 12) + (1 << 10)
+        assert set(rep) >= {"winograd_filters", "bf16_filter_shadows", "recorded_steps_alive"}
+    finally:
+        del K._ws_cache[key]
+        K._ws_retired.pop()
