@@ -2,7 +2,7 @@
 # Regenerates the evidence under profiles/ for the current round on a GPU box:  R=r6z bash tools/collect_round.sh   (raw output gpurun_out/$R/; copy
 # the summaries to profiles/rNN_*).  Round 6's version (round 5's is in the history at a60837a).
 # PART=A: smoke, the driver's line (with cpu_baseline), segmenter / bf16 lines, kernel traces, per-layer tables, PMC passes (library symbols only:
-# the joint step segfaults rocprofv3's counter collection otherwise), 8-rank same-device rehearsal.  PART=B: the whole -m gpu suite serially.
+# the joint step segfaults rocprofv3's counter collection otherwise), 8-rank same-device rehearsal.  PART=B: the whole -m gpu suite serially.  PART=C: the driver's line with the full cpu_baseline sample (2 warm-ups + median of 5).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 R=${R:-r6z}; O=gpurun_out/$R; mkdir -p $O
 PART=${PART:-AB}
@@ -46,5 +46,9 @@ fi
 if [[ $PART == *B* ]]; then
 timeout 1150 python -m pytest tests -m gpu -q -s --durations=15 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
 grep -E "passed|failed|FAILED" $O/pytest_gpu.log | tail -6
+fi
+if [[ $PART == *C* ]]; then
+# SURVEY 8(d)'s cpu_baseline sample in full: 2 warm-ups + the median of 5 timed oracle steps at B = 16 (about 9 minutes of host time)
+timeout 1500 python bench.py --cpu-steps 5 --cpu-warmup 2 --cpu-small-batch 0 --no-sub > $O/bench_cpu_median5_n1.json 2> $O/bench_cpu_median5_n1.err; tail -c 500 $O/bench_cpu_median5_n1.json
 fi
 du -sh $O
