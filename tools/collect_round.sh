@@ -12,6 +12,8 @@ timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 600 $
 timeout 300 python bench.py --workload segmenter --no-sub --no-cpu-baseline > $O/bench_segmenter_n1.json 2>/dev/null; cp gpurun_out/bench_kernels_segmenter_f32.json $O/ 2>/dev/null
 timeout 300 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16_n1.json 2>/dev/null
 timeout 300 python bench.py --dtype bf16 --batch 32 --no-cpu-baseline --no-sub > $O/bench_bf16_B32_n1.json 2>/dev/null
+# recorded steps at B = 16 (round 6: the bf16 one used to fault on replay) — slower than eager there, which is why --graph auto records at B <= 4 only
+for dt in bf16 f32; do timeout 300 python bench.py --dtype $dt --graph on --no-cpu-baseline --no-sub --no-probe 2>/dev/null | tail -1; done > $O/bench_graph_on_B16_n1.json
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub --graph off"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_joint -o joint -- $B > $O/bench_prof_joint.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_seg -o seg -- $B --workload segmenter > $O/bench_prof_seg.json 2>/dev/null
