@@ -1,14 +1,28 @@
 // Experiment (gfx950, round 6): a DIRECT 3x3 stride-1 SAME convolution 64 -> 64 channels on the bf16 matrix pipe with split operands —
 // would it beat the Winograd F(4x4) fp32-pipe route on the narrow, large-map layers (cls1 64->64 @ 256^2, B = 16: 0.59 ms forward,
-// traffic-bound on the 2.25x transformed tensors)?  Standalone: synthetic data, checked against a naive fp32 kernel, timed with HIP events.
+// traffic-bound on the 2.25x transformed tensors)?  Standalone: synthetic data, checked against a float64-accumulating kernel, timed with
+// HIP events, with ablation instances.  ANSWER (tools/experiments/README.md, round 6): yes — 0.37 ms (209 TF/s fp32-equivalent, 1.33 x the
+// fp32 MFMA peak; Winograd route 0.593 ms), 8.0e-7 of max|ref| (the direct fp32 kernel: 2.9e-6, the F(4x4) routes 1.2e-6 .. 8e-6).  Not in
+// the library: a prototype of "what comes next" (DESIGN.md section 10).
 //   * input x [N][H][W][64] fp32: a 16 x 16 output tile's 18 x 18 x 32-channel halo patch is loaded ONCE per channel half by three
-//     loader waves (global -> VGPR -> split into three bf16 planes whose sum is the fp32 value -> LDS), double-buffered across halves;
+//     loader waves (global -> VGPR -> split into three bf16 planes whose sum is the fp32 value -> LDS, the split spread over five stages),
+//     double-buffered across halves: every input value crosses L2 -> CU once per tile (1.27 x the tensor), not once per tap;
 //   * filters pre-split on the host: [half 2][tap 9][plane 3][K 64][32 ch] bf16, 12 KB per (half, tap) stage, streamed by one loader
-//     wave with LDS-DMA, double-buffered;
-//   * four consumer waves (64 pixels x 64 filters each): per stage 24 ds_read_b128 fragments, 48 v_mfma_f32_32x32x16_bf16 (six plane
-//     products per fragment pair); taps are LDS address offsets of the patch; one raw s_barrier per stage for all eight waves;
-//   * persistent workgroups (one per CU), the loaders run ahead across tiles.
-// build: hipcc --offload-arch=gfx950 -O3 tools/experiments/x3_direct_conv.hip -o gpurun_out/x3_direct_conv ; run on the GPU box.
+//     wave with LDS-DMA into three stage buffers;
+//   * four consumer waves (64 pixels x 64 filters each), MFMA roles swapped — A = filters, B = pixels, D[filter][pixel] — so that a lane
+//     ends up with four consecutive filters of one pixel (16-byte stores); per stage 12 filter-fragment reads after the barrier, the 12
+//     pixel-fragment reads of the NEXT tap issued before it (same patch: no barrier in between), 48 v_mfma_f32_32x32x16_bf16 (six plane
+//     products per fragment pair); taps are LDS address offsets of the patch; the second pixel row of a 32-pixel block is rotated by
+//     two columns so that every ds_read_b128 lane group sees 16 distinct 16-byte slots; one raw s_barrier per stage for all eight waves;
+//   * persistent workgroups (one per CU), the loaders run ahead across tiles; the 18 stages of a tile are fully unrolled (buffer
+//     indices, taps and the patch half are compile-time constants);
+//   * non-temporal output stores (the 256 workgroups run in lockstep — same work per tile — and store their 64 KB at once): 0.370 ms
+//     against 0.379 with the default policy, 0.315 without any store.  (The same policy on the x3 GEMM's M stores: the GEMM gains 2-5 %,
+//     the output transform that reads M next loses as much — tools/experiments/README.md.)
+//   Where the 0.37 ms go (ablation instances below, 40 warm-up launches each: the first kernel after an idle phase runs 25 % slower on
+//   ramping clocks): consumers alone 0.269 (MFMAs at the peak rate would be 0.184), + filter DMA 0.02, + patch loads / splits 0.06,
+//   + output stores 0.05.
+// build: hipcc --offload-arch=gfx950 -O3 tools/experiments/x3_direct_conv.hip -o /tmp/x3dc ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
@@ -29,7 +43,8 @@ constexpr int PLANE_P = NPX * ROWB;                // 20 736 B per patch plane
 constexpr int PATCH = 3 * PLANE_P;                 // 62 208 B per patch (one channel half)
 constexpr int PLANE_F = K * ROWB;                  // 4 096 B per filter plane
 constexpr int FSTG = 3 * PLANE_F;                  // 12 288 B per (half, tap) stage
-constexpr int LDS_BYTES = 2 * PATCH + 2 * FSTG;    // 148 992 B
+constexpr int NF = 3;                              // filter stage buffers: NF - 1 stages in flight
+constexpr int LDS_BYTES = 2 * PATCH + NF * FSTG;   // 161 280 B
 constexpr int NSTG = 18;                           // stages per tile: 2 halves x 9 taps
 constexpr int NPL = 192;                           // patch-loader lanes (3 waves)
 constexpr int NPI = (NPX * 8 + NPL - 1) / NPL;     // float4 loads per patch-loader lane: 14
@@ -37,6 +52,8 @@ constexpr int NPI = (NPX * 8 + NPL - 1) / NPL;     // float4 loads per patch-loa
 __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
@@ -53,6 +70,8 @@ struct Args {
     int N, H, W;
 };
 
+template <int ABL>      // ablation bits (timing only): 1 no patch loads after the first, 2 no filter DMA after the prologue, 4 no output stores,
+                        // 8 no MFMAs, 16 output stores with the DEFAULT cache policy instead of nt, 32 staggered start
 __global__ void __launch_bounds__(512, 1) x3_direct_kernel(Args a) {
     __shared__ __attribute__((aligned(256))) unsigned char lds[LDS_BYTES];
     unsigned char* const patch0 = lds;
@@ -71,6 +90,10 @@ __global__ void __launch_bounds__(512, 1) x3_direct_kernel(Args a) {
         ow0 = (r % tiles_x) * TW;
     };
 
+    if (ABL & 32) {       // phase-shift the workgroups (they run in lockstep otherwise: same work per tile, so all 256 CUs store their 64 KB at once)
+        const int ph = (int)(blockIdx.x >> 3) & 15;          // (workgroup b runs on XCD b % 8: neighbours on one XCD get different phases)
+        for (int i = 0; i < ph * 24; ++i) __builtin_amdgcn_s_sleep(32);       // ~ ph x 1.3 us (s_sleep 32 = 2048 cycles)
+    }
     if (wave == 4) {
         // ============================ filter loader: one 12 KB stage per barrier, LDS-DMA ============================
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w3, 2u * 9u * FSTG);
@@ -84,15 +107,19 @@ __global__ void __launch_bounds__(512, 1) x3_direct_kernel(Args a) {
         }
         auto issue = [&](int g) {
             const int s = g % NSTG;                                   // (half, tap) = the stage's slot of the filter image
-            unsigned char* bp = filt0 + (g & 1) * FSTG;
+            unsigned char* bp = filt0 + (g % NF) * FSTG;
 #pragma unroll
             for (int i = 0; i < 12; ++i) dma16(rw, (lds_void*)(bp + i * 1024), vo[i], s * FSTG);
         };
-        issue(0);
+#pragma unroll
+        for (int b = 0; b < NF - 1; ++b)
+            if (b < gstages) issue(b);
         for (int g = 0; g < gstages; ++g) {
-            wait_vm0();
+            // stage g has landed; up to NF - 2 younger stages stay in flight (the tail issues nothing: drain)
+            if (g + NF - 2 < gstages) wait_vm<12 * (NF - 2)>();
+            else wait_vm0();
             __builtin_amdgcn_s_barrier();
-            if (g + 1 < gstages) issue(g + 1);
+            if (!(ABL & 2) && g + NF - 1 < gstages) issue(g + NF - 1);      // into the buffer of stage g - 1: every consumer is past it
         }
         wait_vm0();
         return;
@@ -117,10 +144,11 @@ __global__ void __launch_bounds__(512, 1) x3_direct_kernel(Args a) {
                 st[i] = v;
             }
         };
-        auto store = [&](int slot) {
+        auto store = [&](int slot, int i0, int i1) {
             unsigned char* pb = patch0 + (slot & 1) * PATCH;
 #pragma unroll
             for (int i = 0; i < NPI; ++i) {
+                if (i < i0 || i >= i1) continue;
                 const int e = pl + i * NPL;
                 if (e >= NPX * 8) continue;
                 const int q = e >> 3, j = e & 7;
@@ -143,87 +171,111 @@ __global__ void __launch_bounds__(512, 1) x3_direct_kernel(Args a) {
         const int nslots = mytiles * 2;
         load(0);
         wait_vm0();
-        store(0);
+        store(0, 0, NPI);
         for (int g = 0; g < gstages; ++g) {
             const int slot = g / 9, j = g - slot * 9;
             if (j == 0) wait_lgkm0();                                  // this slot's patch is in LDS
             __builtin_amdgcn_s_barrier();
-            if (j == 0 && slot + 1 < nslots) load(slot + 1);
-            if (j == 4 && slot + 1 < nslots) {
-                wait_vm0();
-                store(slot + 1);
+            if (!(ABL & 1) && j == 0 && slot + 1 < nslots) load(slot + 1);
+            // split + LDS stores of the next patch spread over stages 3..7 (3 float4 per lane each): the vector ALU work of one stage stays
+            // well under the consumers' MFMA time, so this wave is never the last at a barrier
+            if (!(ABL & 1) && j >= 3 && j <= 7 && slot + 1 < nslots) {
+                if (j == 3) wait_vm0();
+                if (j == 3) store(slot + 1, 0, 3);
+                else if (j == 4) store(slot + 1, 3, 6);
+                else if (j == 5) store(slot + 1, 6, 9);
+                else if (j == 6) store(slot + 1, 9, 12);
+                else store(slot + 1, 12, NPI);
             }
         }
         return;
     }
     // ============================ consumers: 64 pixels (4 output rows x 16) x 64 filters per wave ============================
+    // MFMA roles: A = filters (rows = filter index), B = pixels (columns = pixel): D[filter][pixel], so a lane holds FOUR CONSECUTIVE
+    // filters of one pixel per register quad — 16-byte output stores.  Pixel of lane l31 in 32-pixel block tm: l31 < 16: row 4 w + 2 tm,
+    // column l31; else row + 1, column (l31 - 2) mod 16 — the rotation makes the patch index q of the second row congruent (mod 16) to
+    // the first row's, so that every ds_read_b128 lane group sees 16 distinct (q mod 16) = 16 distinct 16-byte slots of the bank row.
     const int l31 = lane & 31, h = lane >> 5;
-    int aoff[2];                                    // patch byte offset of this lane's pixel for tm = 0, 1 at tap (0, 0), chunk bits left out
+    const int prow = l31 >> 4, pcol = (l31 < 16) ? l31 : ((l31 - 16 + 14) & 15);
     int aq[2];
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-        aq[tm] = (4 * wave + 2 * tm + (l31 >> 4)) * PW + (l31 & 15);
-        aoff[tm] = aq[tm] * ROWB;
-    }
-    int boff[2][2];                                 // [tn][ks]
+    for (int tm = 0; tm < 2; ++tm) aq[tm] = (4 * wave + 2 * tm + prow) * PW + pcol;
+    int woff[2][2];                                 // [tn][ks]
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) boff[tn][ks] = (tn * 32 + l31) * ROWB + (((2 * ks + h) ^ swz(tn * 32 + l31)) << 4);
-    constexpr int kTermA[6] = {2, 1, 0, 1, 0, 0}, kTermB[6] = {0, 1, 2, 0, 1, 0};
-    f32x16 acc[2][2];
-    int g = 0;
+        for (int ks = 0; ks < 2; ++ks) woff[tn][ks] = (tn * 32 + l31) * ROWB + (((2 * ks + h) ^ swz(tn * 32 + l31)) << 4);
+    constexpr int kTermX[6] = {2, 1, 0, 1, 0, 0}, kTermW[6] = {0, 1, 2, 0, 1, 0};
+    f32x16 acc[2][2];                               // [tn (filter block)][tm (pixel block)]
+    size_t obase[2];                                // float offset of this lane's pixel (tm), filter 4 h
+    bf16x8 xf[2][2][3][2];                          // [double buffer][ks][plane][tm]
+    auto load_x = [&](int db, int hsel, int tap) {
+        const unsigned char* A = patch0 + hsel * PATCH;
+        const int dq = (tap / 3) * PW + (tap % 3);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    const int q = aq[tm] + dq;
+                    xf[db][ks][p][tm] = *reinterpret_cast<const bf16x8*>(A + p * PLANE_P + q * ROWB + (((2 * ks + h) ^ swz(q)) << 4));
+                }
+    };
     for (int it = 0; it < mytiles; ++it) {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
-        for (int s = 0; s < NSTG; ++s, ++g) {
-            const int slot = g / 9, tap = g - slot * 9;
-            const int tr = tap / 3, ts = tap - tr * 3;
+                for (int e = 0; e < 16; ++e) acc[tn][tm][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSTG; ++s) {
+            const int hsel = s / 9, tap = s % 9;     // (static after unrolling; the patch buffer of slot 2 it + hsel is buffer hsel, the filter
+            const int fb = s % NF;                   //  buffer of global stage 18 it + s is s mod 3)
             wait_lgkm0();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const unsigned char* A = patch0 + (slot & 1) * PATCH;
-            const unsigned char* B = filt0 + (g & 1) * FSTG;
-            const int dq = tr * PW + ts;
-            bf16x8 af[2][3][2], bfr[2][3][2];       // [ks][plane][tm / tn]
+            if (tap == 0) load_x(s & 1, hsel, 0);    // first tap of a half: the patch only became visible with this barrier
+            const unsigned char* B = filt0 + fb * FSTG;
+            bf16x8 wf[2][3][2];                      // [ks][plane][tn]
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
-                    for (int tm = 0; tm < 2; ++tm) {
-                        const int q = aq[tm] + dq;
-                        af[ks][p][tm] = *reinterpret_cast<const bf16x8*>(A + p * PLANE_P + aoff[tm] + dq * ROWB + (((2 * ks + h) ^ swz(q)) << 4));
-                    }
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) bfr[ks][p][tn] = *reinterpret_cast<const bf16x8*>(B + p * PLANE_F + boff[tn][ks]);
-                }
+                    for (int tn = 0; tn < 2; ++tn) wf[ks][p][tn] = *reinterpret_cast<const bf16x8*>(B + p * PLANE_F + woff[tn][ks]);
+            if (tap != 8) load_x((s + 1) & 1, hsel, tap + 1);       // the next tap's pixel fragments: same patch, no barrier in between
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int trm = 0; trm < 6; ++trm)
 #pragma unroll
-                    for (int tm = 0; tm < 2; ++tm)
+                    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-                        for (int tn = 0; tn < 2; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][kTermA[trm]][tm], bfr[ks][kTermB[trm]][tn], acc[tm][tn], 0, 0, 0);
+                        for (int tm = 0; tm < 2; ++tm) {
+                            if (!(ABL & 8)) acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][kTermW[trm]][tn], xf[s & 1][ks][kTermX[trm]][tm], acc[tn][tm], 0, 0, 0);
+                            else acc[tn][tm][trm] += (float)wf[ks][kTermW[trm]][tn][0] + (float)xf[s & 1][ks][kTermX[trm]][tm][0];
+                        }
         }
-        // epilogue: D[m][n], lane: n = l31 (filter), rows m = 8 (i / 4) + 4 h + (i % 4) (pixel of the 32-pixel block)
+        // D[filter m][pixel n]: lane: pixel = l31 of block tm, filters tn 32 + 8 (i / 4) + 4 h + (i % 4): quad j = i / 4 is 16 contiguous bytes
         int n, oh0, ow0;
         tile_origin(it, n, oh0, ow0);
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
+            obase[tm] = (((size_t)n * a.H + oh0 + 4 * wave + 2 * tm + prow) * a.W + ow0 + pcol) * K + 4 * h;
+        if ((ABL & 4) && acc[0][0][0] != 12345.678f) continue;
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int m = 8 * (i >> 2) + 4 * h + (i & 3);
-                    const int oh = oh0 + 4 * wave + 2 * tm + (m >> 4), ow = ow0 + (m & 15);
-                    a.y[(((size_t)n * a.H + oh) * a.W + ow) * K + tn * 32 + l31] = acc[tm][tn][i];
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][4 * j + e];
+                    if (!(ABL & 16)) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.y + obase[tm] + tn * 32 + 8 * j));
+                    else *reinterpret_cast<f32x4*>(a.y + obase[tm] + tn * 32 + 8 * j) = v;
                 }
     }
 }
@@ -293,7 +345,7 @@ int main() {
         hipMemcpy(dw3, hw3.data(), hw3.size() * 2, hipMemcpyHostToDevice);
         hipMemset(dy, 0, nx * 4);
         Args a{dx, dw3, dy, N, H, W};
-        hipLaunchKernelGGL(x3_direct_kernel, dim3(256), dim3(512), 0, 0, a);
+        hipLaunchKernelGGL(x3_direct_kernel<0>, dim3(256), dim3(512), 0, 0, a);
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(e)); return 1; }
         if (N == 2) {
@@ -306,19 +358,32 @@ int main() {
             for (size_t i = 0; i < nx; ++i) { emax = fmax(emax, fabs((double)y[i] - r[i])); rmax = fmax(rmax, fabs((double)r[i])); }
             printf("N=%d parity vs float64-accumulated reference: max|err| / max|ref| = %.3e\n", N, emax / rmax);
         }
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0); hipEventCreate(&e1);
-        const int reps = 10;
-        hipEventRecord(e0);
-        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(x3_direct_kernel, dim3(256), dim3(512), 0, 0, a);
-        hipEventRecord(e1);
-        hipEventSynchronize(e1);
-        float ms = 0;
-        hipEventElapsedTime(&ms, e0, e1);
-        ms /= reps;
-        const double gf = 2.0 * N * H * W * 9.0 * C * K / 1e9;
-        printf("N=%d 64->64 3x3 @%dx%d: %.3f ms  %.1f TF/s fp32-equivalent (%.0f TF/s executed bf16)  in+out %.2f TB/s\n", N, H, W, ms, gf / ms, 6 * gf / ms,
-               2.0 * nx * 4 / ms / 1e9);
+        auto timeit = [&](auto kern, const char* what) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            const int reps = 20;
+            for (int i = 0; i < 40; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, a);      // (clocks ramp up over the first milliseconds after an idle phase)
+            hipEventRecord(e0);
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, a);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            ms /= reps;
+            const double gf = 2.0 * N * H * W * 9.0 * C * K / 1e9;
+            printf("N=%d 64->64 3x3 @%dx%d %-34s: %.3f ms  %.1f TF/s fp32-equivalent (%.0f TF/s executed bf16)  in+out %.2f TB/s\n", N, H, W, what, ms, gf / ms, 6 * gf / ms,
+                   2.0 * nx * 4 / ms / 1e9);
+        };
+        timeit(x3_direct_kernel<0>, "everything");
+        if (N == 16) {
+            timeit(x3_direct_kernel<1>, "no patch loads");
+            timeit(x3_direct_kernel<2>, "no filter DMA");
+            timeit(x3_direct_kernel<3>, "no patch loads, no filter DMA");
+            timeit(x3_direct_kernel<4>, "no output stores");
+            timeit(x3_direct_kernel<7>, "consumers only");
+            timeit(x3_direct_kernel<16>, "output stores, default policy");
+            timeit(x3_direct_kernel<0>, "everything (again)");
+        }
         hipFree(dx); hipFree(dy); hipFree(dr); hipFree(dw); hipFree(dw3);
     }
     return 0;
