@@ -53,7 +53,7 @@ ALG_GFLOP_PER_SLICE = {"joint": 399.8 + 256.2, "segmenter": 248.95}
 
 def is_x3(name):
     """the split-bf16 GEMMs of the Winograd route (csrc/conv_wino_x3.hip): bf16 matrix pipe, six plane products per fp32 multiply-add"""
-    return name.startswith("wino_gemm_x3_kernel")
+    return name.startswith("wino_gemm_x3_kernel") or name.startswith("conv_x3_direct_kernel")
 
 
 def wino_alg_factor(name):
@@ -61,6 +61,8 @@ def wino_alg_factor(name):
     multiply-adds of the transform domain (F(2x2, 3x3): 2.25, F(4x4, 3x3): 4; exact for full tiles).  Symbols: wino_gemm_kernel<.., 0 / 1>
     F(2x2), <.., 2 / 3> F(4x4); wino_wgrad_gemm_kernel<.., TILE>; wino_gemm_x3_kernel<.., 0 / 1 / 4> F(2x2), <.., 2 / 3 / 5> F(4x4) — the x3
     kernel EXECUTES six bf16 MFMA products per fp32 multiply-add, so its factor is a sixth of the fp32 kernels'."""
+    if name.startswith("conv_x3_direct_kernel"):        # a direct convolution: every fp32 multiply-add of the layer, six bf16 products each
+        return 1.0 / 6.0
     if is_x3(name):
         return (4.0 if name.rstrip(">").split(",")[-1].strip() in ("2", "3", "5") else 2.25) / 6.0
     if name.startswith("wino_gemm_kernel"):

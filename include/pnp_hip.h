@@ -131,6 +131,13 @@ int32_t pnp_conv2d_wino_tile(int32_t tile);
  * whole layer's error against float64 falls from 4e-6..6e-6 to 1e-6..2e-6, because the chunked chain is shorter than the fp32 pipe's).
  * mode < 0: read only.  Returns the previous mode.  Workspace queries and the transformed-filter cache follow the mode in force. */
 int32_t pnp_conv2d_wino_x3(int32_t mode);
+/* Round 6: the narrow layers of the route (3x3, stride 1, 32 or 64 input channels, 64 or 128 filters, output a multiple of 16 x 16) as DIRECT
+ * split-bf16 convolutions (csrc/conv_x3_direct.hip): no transforms — a tile's halo patch is split into three bf16 planes once and the nine
+ * taps are LDS offsets; six plane products per fragment pair on v_mfma_f32_32x32x16_bf16, one fp32 chain of 9 C terms (8e-7 of max|ref|).
+ * Replaces, for those layers, the F(4x4) route that is bound by its 2.25x transformed tensors there (reference adversarial.py:337-366, the
+ * critics' 64-channel blocks at 256^2 / 128^2).  0: off, 1 (default): where a launch fills the chip (>= 256 tile x filter-block items), 2: wherever the
+ * shapes allow (environment PNP_X3_DIRECT); mode < 0: read only.  Returns the previous mode. */
+int32_t pnp_conv2d_x3_direct(int32_t mode);
 /* Transformed-filter cache of the route.  U = G g G^T (36 C K values per filter and pass: fp32, or three bf16 planes) only changes when the filter does: the caller
  * lends one buffer per (filter, pass) and reports weight writes; a launch whose filter has a valid entry skips wino_filter_kernel (the
  * frozen source segmenter / shared half of adversarial.py:839-882 never pay it again, a trained layer once per update instead of once per

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "pnp_conv2d_wino_wgrad_mode": (c_int32, [c_int32]),
     "pnp_conv2d_wino_tile": (c_int32, [c_int32]),
     "pnp_conv2d_wino_x3": (c_int32, [c_int32]),
+    "pnp_conv2d_x3_direct": (c_int32, [c_int32]),
     "pnp_conv2d_wino_filter_bytes": (c_size_t, [c_int32, c_int32]),
     "pnp_conv2d_wino_filter_bind": (c_int, [c_void_p, c_int32, c_void_p, c_size_t]),
     "pnp_weights_changed": (None, [c_void_p, c_void_p]),

@@ -382,6 +382,12 @@ int launch_n16_wgrad(const ConvArgs& a, float* part, hipStream_t st);
 // Round 5: the route has two output tiles, F(2x2, 3x3) and F(4x4, 3x3) (36 instead of 64 multiplications per 4x4 outputs; PNP_WINOGRAD_TILE /
 // pnp_conv2d_wino_tile: the largest the planner may pick).  wino_tile: 0 (direct kernels), 2 or 4 for the forward of this geometry.
 bool wino_eligible(const pnp_conv_geom* g);
+// conv_x3_direct.hip: direct split-bf16 3x3 convolutions of the narrow layers; launch_wino() hands over what x3d_chosen() takes
+bool x3d_chosen(const pnp_conv_geom* g);
+bool x3d_chosen(const ConvArgs& a);
+int x3d_stats_parts(const pnp_conv_geom* g);
+size_t x3d_filter_bytes(int C, int K);
+int launch_x3_direct(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size_t ws_bytes, hipStream_t st);
 bool wino_chosen(const pnp_conv_geom* g);
 int wino_tile(const pnp_conv_geom* g);
 size_t wino_workspace_bytes(const pnp_conv_geom* g);

@@ -2192,7 +2192,10 @@ size_t pnp_conv2d_fwd_workspace_bytes(const pnp_conv_geom* g) {
     if (!g) return 0;
     if (wino_chosen(g)) return wino_workspace_bytes(g);           // Winograd route: transformed filter + input + product (conv_wino.hip)
     const int ns = fwd_split(g);
-    return ns > 1 ? (size_t)ns * g->N * g->OH * g->OW * g->K * sizeof(float) : 0;
+    const size_t split = ns > 1 ? (size_t)ns * g->N * g->OH * g->OW * g->K * sizeof(float) : 0;
+    // direct split-bf16 convolution of a narrow layer the Winograd planner leaves alone (conv_x3_direct.hip): its filter image
+    const size_t x3d = x3d_chosen(g) ? x3d_filter_bytes(g->C, g->K) : 0;
+    return split > x3d ? split : x3d;
 }
 
 int pnp_conv2d_fwd(const float* x, const float* w, float* y, const pnp_conv_geom* g, float keep_prob, uint64_t seed,
@@ -2219,6 +2222,8 @@ int pnp_conv2d_fwd_ws(const float* x, const float* w, float* y, const pnp_conv_g
         if (workspace && workspace_bytes >= wino_workspace_bytes(g)) return launch_wino(a, 0, false, workspace, workspace_bytes, (hipStream_t)stream);
         return launch_fwd<0>(a, (hipStream_t)stream, nullptr);
     }
+    if (x3d_chosen(a) && workspace && workspace_bytes >= x3d_filter_bytes(a.C, a.K))
+        return launch_x3_direct(a, 0, false, workspace, workspace_bytes, (hipStream_t)stream);
     float* split_ws = (workspace && workspace_bytes >= pnp_conv2d_fwd_workspace_bytes(g) && pnp_conv2d_fwd_workspace_bytes(g) > 0)
                           ? (float*)workspace : nullptr;
     return launch_fwd<0>(a, (hipStream_t)stream, split_ws);
@@ -2250,6 +2255,7 @@ int pnp_conv2d_fwd_stats(const float* x, const float* w, float* y, const pnp_con
 int32_t pnp_conv2d_fwd_stats_ws_parts(const pnp_conv_geom* g) {
     if (!g || check_geom(g, "pnp_conv2d_fwd_stats_ws_parts") != PNP_OK) return 0;
     if (wino_chosen(g)) return wino_stats_parts(g);
+    if (x3d_chosen(g) && !n16_geom_ok(g) && !narrow_fwd_ok(g, nullptr)) return x3d_stats_parts(g);
     return pnp_conv2d_fwd_stats_parts(g);
 }
 
@@ -2267,7 +2273,9 @@ static int fwd_stats_impl(const float* x, const float* w, float* y, const pnp_co
     PNP_REQUIRE(keep_prob > 0.f, "pnp_conv2d_fwd_stats: keep_prob must be > 0");
     const bool wino = with_ws && wino_chosen(g);
     if (wino) PNP_REQUIRE(workspace && workspace_bytes >= wino_workspace_bytes(g), "pnp_conv2d_fwd_stats_ws: workspace too small (pnp_conv2d_fwd_workspace_bytes)");
-    const int nparts = wino ? wino_stats_parts(g) : pnp_conv2d_fwd_stats_parts(g);
+    const bool x3d = with_ws && !wino && x3d_chosen(g) && !n16_geom_ok(g) && !narrow_fwd_ok(g, nullptr);
+    if (x3d) PNP_REQUIRE(workspace && workspace_bytes >= x3d_filter_bytes(g->C, g->K), "pnp_conv2d_fwd_stats_ws: workspace too small (pnp_conv2d_fwd_workspace_bytes)");
+    const int nparts = wino ? wino_stats_parts(g) : (x3d ? x3d_stats_parts(g) : pnp_conv2d_fwd_stats_parts(g));
     PNP_REQUIRE(nparts > 0, "pnp_conv2d_fwd_stats: no epilogue statistics for this geometry (pnp_conv2d_fwd_stats_parts == 0)");
     if (parts_bytes < (size_t)nparts * 2 * g->K * sizeof(float)) {
         pnp_set_error("pnp_conv2d_fwd_stats: parts buffer too small (%zu < %zu)", parts_bytes, (size_t)nparts * 2 * g->K * sizeof(float));
@@ -2284,6 +2292,7 @@ static int fwd_stats_impl(const float* x, const float* w, float* y, const pnp_co
     a.stat_ws = parts;
     a.stat_shift = shift;
     if (wino) return launch_wino(a, 0, false, workspace, workspace_bytes, (hipStream_t)stream);
+    if (x3d) return launch_x3_direct(a, 0, false, workspace, workspace_bytes, (hipStream_t)stream);
     return launch_fwd<0>(a, (hipStream_t)stream);
 }
 

@@ -1391,6 +1391,7 @@ size_t wino_workspace_bytes(const pnp_conv_geom* g) {
 }
 
 int wino_stats_parts(const pnp_conv_geom* g) {
+    if (x3d_chosen(g)) return x3d_stats_parts(g);            // (conv_x3_direct.hip takes the layer from launch_wino)
     const int m = plan_tile(g, false);
     const WinoGeom w = make_wgeom(g, m ? m : 2);
     int tpb, nblk;
@@ -1493,6 +1494,9 @@ static int launch_wino_m(const ConvArgs& a, int kind, bool flip_transpose, void*
 // a.K = its C) with every epilogue field honoured; flip_transpose: a.w is the FORWARD filter [3][3][a.K][a.C].  The tile is planned here
 // from the same fields the workspace / parts queries see (one decision per call)
 int launch_wino(const ConvArgs& a, int kind, bool flip_transpose, void* ws, size_t ws_bytes, hipStream_t st) {
+    // the narrow layers (32 / 64 input channels, <= 128 filters) run as DIRECT split-bf16 convolutions where that is on: no transforms,
+    // no 2.25x tensors (conv_x3_direct.hip; the workspace this route asked for is more than its filter image needs)
+    if (x3d_chosen(a)) return launch_x3_direct(a, kind, flip_transpose, ws, ws_bytes, st);
     const int m = plan_tile(a, false);
     PNP_REQUIRE(m == 2 || m == 4, "launch_wino: the planner does not route this layer (policy changed between the query and the launch?)");
     return m == 4 ? launch_wino_m<4>(a, kind, flip_transpose, ws, ws_bytes, st) : launch_wino_m<2>(a, kind, flip_transpose, ws, ws_bytes, st);

@@ -157,6 +157,12 @@ def wino_x3(mode=-1):
     return int(_lib.load().pnp_conv2d_wino_x3(int(mode)))
 
 
+def x3_direct(mode=-1):
+    """the narrow 3x3 layers of the Winograd route (32 / 64 input channels, <= 128 filters) as direct split-bf16 convolutions
+    (csrc/conv_x3_direct.hip): 0 off, 1 on; returns the previous mode (mode < 0: read only)"""
+    return int(_lib.load().pnp_conv2d_x3_direct(int(mode)))
+
+
 def wino_chosen(g, kind=0):
     """pnp_conv2d_fwd* (kind 0) / pnp_conv2d_dgrad* (kind 1) / pnp_conv2d_wgrad* (kind 2) of this layer (g = the forward geometry): 0 = the
     direct kernels, else the output tile edge of the Winograd route (2 or 4) — truthy exactly when the layer is on the route"""
