@@ -2371,8 +2371,27 @@ int32_t pnp_conv2d_wino_chosen(const pnp_conv_geom* g, int32_t kind) {
     return kind == 0 ? wino_tile(g) : (dgrad_wino(g, &d) ? wino_tile(&d) : 0);
 }
 
+// the data gradient as a direct split-bf16 convolution of dy (conv_x3_direct.hip) where the Winograd planner leaves the layer alone
+static bool dgrad_x3d(const pnp_conv_geom* g, pnp_conv_geom* d) {
+    if (g->stride != 1 || g->pad_mode != PNP_PAD_ZERO) return false;
+    *d = dgrad_as_conv(g);
+    return d->pad_t >= 0 && d->pad_l >= 0 && !wino_chosen(d) && !n16_geom_ok(d) && !narrow_fwd_ok(d, nullptr) && x3d_chosen(d);
+}
+
+static size_t dgrad_ws_base(const pnp_conv_geom* g);
+
 size_t pnp_conv2d_dgrad_workspace_bytes(const pnp_conv_geom* g) {
     if (!g) return 0;
+    const size_t b = dgrad_ws_base(g);
+    pnp_conv_geom d;
+    if (dgrad_x3d(g, &d)) {
+        const size_t f = x3d_filter_bytes(d.C, d.K);
+        return b > f ? b : f;
+    }
+    return b;
+}
+
+static size_t dgrad_ws_base(const pnp_conv_geom* g) {
     {
         pnp_conv_geom d;
         if (dgrad_wino(g, &d)) return wino_workspace_bytes(&d);
@@ -2470,6 +2489,14 @@ static int dgrad_impl(const float* dy, const float* w, float* dx, const pnp_conv
             ConvArgs a = make_args(dy, w, dx, &dw_);
             a.res_add = residual;
             return launch_wino(a, 1, true, workspace, workspace_bytes, st);
+        }
+    }
+    {
+        pnp_conv_geom dx_;
+        if (dgrad_x3d(g, &dx_)) {            // direct split-bf16 convolution of dy: its filter image flips and transposes (no flip launch)
+            ConvArgs a = make_args(dy, w, dx, &dx_);
+            a.res_add = residual;
+            return launch_x3_direct(a, 1, true, workspace, workspace_bytes, st);
         }
     }
     dim3 tg((unsigned)pnp_cdiv(g->K, 32), (unsigned)pnp_cdiv(g->C, 32), (unsigned)(g->R * g->S));

@@ -37,10 +37,8 @@ constexpr int TH = 16, TW = 16, PH = TH + 2, PW = TW + 2, NPX = PH * PW;      //
 constexpr int ROWB = 64;                           // bytes per LDS row: 32 channels of one plane
 constexpr int PLANE_P = NPX * ROWB;                // 20 736 B per patch plane
 constexpr int PATCH = 3 * PLANE_P;                 // 62 208 B per patch (one channel half)
-constexpr int PLANE_F = 64 * ROWB;                 // 4 096 B per filter plane
-constexpr int FSTG = 3 * PLANE_F;                  // 12 288 B per (half, tap) stage
 constexpr int NF = 3;                              // filter stage buffers: NF - 1 stages in flight
-constexpr int LDS_BYTES = 2 * PATCH + NF * FSTG;   // 161 280 B
+constexpr int LDS_BYTES = 2 * PATCH + NF * 3 * 64 * ROWB;      // 161 280 B (filter stage of a 64-filter block: 3 planes x 4 096 B = 12 288 B)
 constexpr int NPL = 192;                           // patch-loader lanes (3 waves)
 constexpr int NPI = (NPX * 8 + NPL - 1) / NPL;     // float4 loads per patch-loader lane: 14
 
@@ -73,17 +71,22 @@ struct X3dArgs {
     const float* stat_shift;
 };
 
-// NH = C / 32 channel halves (1 or 2); KIND 0 / 1 only names the symbol (forward / data gradient: the difference is the filter image)
-template <int NH, int KIND>
+// NH = C / 32 channel halves (1 or 2); KW = filters per block (64; 32 for the 32-filter layers: the data gradient of a 32 -> 64 layer);
+// KIND 0 / 1 only names the symbol (forward / data gradient: the difference is the filter image)
+template <int NH, int KW, int KIND>
 __global__ void __launch_bounds__(512, 1) conv_x3_direct_kernel(X3dArgs a) {
     constexpr int NSTG = 9 * NH;
+    constexpr int PLANE_F = KW * ROWB;             // bytes per filter plane of a stage
+    constexpr int FSTG = 3 * PLANE_F;              // bytes per (half, tap) stage
+    constexpr int NPC = FSTG / 1024;               // LDS-DMA pieces per stage (1 KiB each)
+    constexpr int TN = KW / 32;
     static_assert(NSTG % NF == 0, "the filter buffer of a stage must not depend on the item");
     __shared__ __attribute__((aligned(256))) unsigned char lds[LDS_BYTES];
     unsigned char* const patch0 = lds;
     unsigned char* const filt0 = lds + 2 * PATCH;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int tiles_x = a.OW / TW, tiles_y = a.OH / TH, KB = a.K >> 6;
+    const int tiles_x = a.OW / TW, tiles_y = a.OH / TH, KB = a.K / KW;
     const int nitems = a.N * tiles_x * tiles_y * KB;
     int myitems = 0;
     for (int i = blockIdx.x; i < nitems; i += gridDim.x) ++myitems;
@@ -105,25 +108,26 @@ __global__ void __launch_bounds__(512, 1) conv_x3_direct_kernel(X3dArgs a) {
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(reinterpret_cast<const float*>(a.w3), (unsigned)(KB * NSTG * FSTG));
         // piece i (1 KiB = 16 rows of 64 B): lane (lrow = lane / 4, lchk = lane % 4) fetches chunk lchk ^ swz(row) of its row
         const int lrow = lane >> 2, lchk = lane & 3;
-        unsigned vo[12];
+        constexpr int PPP = KW / 16;                                   // pieces per plane
+        unsigned vo[NPC];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int row = (i & 3) * 16 + lrow;                      // row within the plane (filter index); plane = i / 4
-            vo[i] = (unsigned)((i >> 2) * PLANE_F + row * ROWB + ((lchk ^ swz(row)) << 4));
+        for (int i = 0; i < NPC; ++i) {
+            const int row = (i % PPP) * 16 + lrow;                    // row within the plane (filter index); plane = i / PPP
+            vo[i] = (unsigned)((i / PPP) * PLANE_F + row * ROWB + ((lchk ^ swz(row)) << 4));
         }
         auto issue = [&](int g) {
             const int it = g / NSTG, s = g - it * NSTG;
             const int kb = (int)((blockIdx.x + it * gridDim.x) % KB);
             unsigned char* bp = filt0 + (g % NF) * FSTG;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) dma16(rw, (lds_void*)(bp + i * 1024), vo[i], (kb * NSTG + s) * FSTG);
+            for (int i = 0; i < NPC; ++i) dma16(rw, (lds_void*)(bp + i * 1024), vo[i], (kb * NSTG + s) * FSTG);
         };
 #pragma unroll
         for (int b = 0; b < NF - 1; ++b)
             if (b < gstages) issue(b);
         for (int g = 0; g < gstages; ++g) {
             // stage g has landed; up to NF - 2 younger stages stay in flight (the tail issues nothing: drain)
-            if (g + NF - 2 < gstages) wait_vm<12 * (NF - 2)>();
+            if (g + NF - 2 < gstages) wait_vm<NPC * (NF - 2)>();
             else wait_vm0();
             __builtin_amdgcn_s_barrier();
             if (g + NF - 1 < gstages) issue(g + NF - 1);             // into the buffer of stage g - 1: every consumer is past it
@@ -206,13 +210,13 @@ __global__ void __launch_bounds__(512, 1) conv_x3_direct_kernel(X3dArgs a) {
     int aq[2];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) aq[tm] = (4 * wave + 2 * tm + prow) * PW + pcol;
-    int woff[2][2];                                 // [tn][ks]
+    int woff[TN][2];                                // [tn][ks]
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) woff[tn][ks] = (tn * 32 + l31) * ROWB + (((2 * ks + h) ^ swz(tn * 32 + l31)) << 4);
     constexpr int kTermX[6] = {2, 1, 0, 1, 0, 0}, kTermW[6] = {0, 1, 2, 0, 1, 0};      // the kept plane products, smallest first
-    f32x16 acc[2][2];                               // [tm (pixel block)][tn (filter block)]
+    f32x16 acc[2][TN];                              // [tm (pixel block)][tn (filter block)]
     bf16x8 xf[2][3][2];                             // [ks][plane][tm]: this tap's pixel fragments
     bf16x8 xn[3][2];                                // [plane][tm]: the NEXT tap's first 16-channel slice, read one stage ahead
     auto x_frag = [&](int pbuf, int tap, int ks, int p, int tm) {
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(512, 1) conv_x3_direct_kernel(X3dArgs a) {
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
         const int slot0 = it * NH;                   // (NH = 1: the patch buffer alternates with the item; NH = 2: half hsel is buffer hsel)
@@ -244,17 +248,17 @@ __global__ void __launch_bounds__(512, 1) conv_x3_direct_kernel(X3dArgs a) {
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) xf[0][p][tm] = (tap == 0) ? x_frag(pbuf, 0, 0, p, tm) : xn[p][tm];
             const unsigned char* B = filt0 + fb * FSTG;
-            bf16x8 wf[2][3][2];                      // [ks][plane][tn]
+            bf16x8 wf[2][3][TN];                     // [ks][plane][tn]
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn) wf[0][p][tn] = *reinterpret_cast<const bf16x8*>(B + p * PLANE_F + woff[tn][0]);
+                for (int tn = 0; tn < TN; ++tn) wf[0][p][tn] = *reinterpret_cast<const bf16x8*>(B + p * PLANE_F + woff[tn][0]);
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) xf[1][p][tm] = x_frag(pbuf, tap, 1, p, tm);
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn) wf[1][p][tn] = *reinterpret_cast<const bf16x8*>(B + p * PLANE_F + woff[tn][1]);
+                for (int tn = 0; tn < TN; ++tn) wf[1][p][tn] = *reinterpret_cast<const bf16x8*>(B + p * PLANE_F + woff[tn][1]);
             }
             if (tap != 8) {                          // the next tap's first slice: same patch, no barrier in between
 #pragma unroll
@@ -269,7 +273,7 @@ __global__ void __launch_bounds__(512, 1) conv_x3_direct_kernel(X3dArgs a) {
 #pragma unroll
                     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                        for (int tn = 0; tn < 2; ++tn)
+                        for (int tn = 0; tn < TN; ++tn)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks][kTermX[trm]][tm], wf[ks][kTermW[trm]][tn], acc[tm][tn], 0, 0, 0);
         }
         // ---------------- epilogue (conv_common.h: conv_epilogue, for the tiled pixel order): phases of pure loads / arithmetic, then stores
@@ -282,12 +286,12 @@ __global__ void __launch_bounds__(512, 1) conv_x3_direct_kernel(X3dArgs a) {
             const int ocol = ow0 + ((r < 16) ? r : ((r - 16 + 14) & 15));
             return (n * a.OH + orow) * a.OW + ocol;
         };
-        int ncol[2];
+        int ncol[TN];
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) ncol[tn] = kb * 64 + tn * 32 + l31;
+        for (int tn = 0; tn < TN; ++tn) ncol[tn] = kb * KW + tn * 32 + l31;
 #define X3D_FOR                                                      \
     _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                 \
-        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)             \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)            \
             _Pragma("unroll") for (int i = 0; i < 16; ++i)
         if (a.do_drop) {
             X3D_FOR {
@@ -299,13 +303,13 @@ __global__ void __launch_bounds__(512, 1) conv_x3_direct_kernel(X3dArgs a) {
             const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.res_add, (unsigned)((size_t)a.M * a.K * 4));
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {          // (one pixel block at a time: all loads, then all adds)
-                f32x16 rv[2];
+                f32x16 rv[TN];
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) rv[tn][i] = bload1(rr, (unsigned)(mlin_of(tm, i) * a.K + ncol[tn]) * 4u);
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[tm][tn][i] += rv[tn][i];
             }
@@ -313,7 +317,7 @@ __global__ void __launch_bounds__(512, 1) conv_x3_direct_kernel(X3dArgs a) {
         if (a.stat_ws) {
             const int part = tile * 4 + wave;
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
+            for (int tn = 0; tn < TN; ++tn) {
                 const float shift = a.stat_shift ? a.stat_shift[ncol[tn]] : 0.f;
                 float ssum = 0.f, ssq = 0.f;
 #pragma unroll
@@ -338,29 +342,29 @@ __global__ void __launch_bounds__(512, 1) conv_x3_direct_kernel(X3dArgs a) {
     }
 }
 
-// the filter image: [K / 64][C / 32][tap][plane][64 filters][32 channels] bf16.  FLIP = false: w is [3][3][C][K] (forward); true: w is the
+// the filter image: [K / KW][C / 32][tap][plane][KW filters][32 channels] bf16 (KW = 64; 32 for a 32-filter layer).  FLIP = false: w is [3][3][C][K] (forward); true: w is the
 // FORWARD filter [3][3][K][C] of a data gradient computed as a convolution of dy (C = the forward's K): taps reversed, roles transposed
 template <bool FLIP>
-__global__ void __launch_bounds__(256) x3d_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ w3, int C, int K) {
-    const int NH = C >> 5, KB = K >> 6;
-    const int total = KB * NH * 9 * 64 * 32;
+__global__ void __launch_bounds__(256) x3d_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ w3, int C, int K, int KW) {
+    const int NH = C >> 5, KB = K / KW;
+    const int total = KB * NH * 9 * KW * 32;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
-    const int i = e & 31, o = (e >> 5) & 63;
-    int r = e >> 11;
+    const int i = e & 31, o = (e >> 5) % KW;
+    int r = (e >> 5) / KW;
     const int tap = r % 9; r /= 9;
     const int hf = r % NH, kb = r / NH;
-    const int ic = hf * 32 + i, oc = kb * 64 + o;
+    const int ic = hf * 32 + i, oc = kb * KW + o;
     const float v = FLIP ? w[((size_t)(8 - tap) * K + oc) * C + ic] : w[((size_t)tap * C + ic) * K + oc];
     const __bf16 b0 = (__bf16)v;
     const float r1 = v - (float)b0;
     const __bf16 b1 = (__bf16)r1;
     const float r2 = r1 - (float)b1;
     const __bf16 b2 = (__bf16)r2;
-    const size_t base = ((((size_t)kb * NH + hf) * 9 + tap) * 3) * (64 * 32) + (size_t)o * 32 + i;
+    const size_t base = ((((size_t)kb * NH + hf) * 9 + tap) * 3) * ((size_t)KW * 32) + (size_t)o * 32 + i;
     w3[base] = __builtin_bit_cast(unsigned short, b0);
-    w3[base + 64 * 32] = __builtin_bit_cast(unsigned short, b1);
-    w3[base + 2 * 64 * 32] = __builtin_bit_cast(unsigned short, b2);
+    w3[base + (size_t)KW * 32] = __builtin_bit_cast(unsigned short, b1);
+    w3[base + 2 * (size_t)KW * 32] = __builtin_bit_cast(unsigned short, b2);
 }
 
 std::atomic<int> g_x3d_mode{-1};
@@ -377,10 +381,10 @@ int x3d_mode() {
 // mode 1: layers with at least one (tile, filter block) item per CU — a persistent launch of fewer leaves CUs idle and the old route wins;
 // mode 2: wherever the shapes allow (tests)
 bool dims_ok(int R, int S, int stride, int dil, int C, int K, int OH, int OW, long long M) {
-    if (!(R == 3 && S == 3 && stride == 1 && dil == 1 && (C == 32 || C == 64) && (K % 64) == 0 && K <= 128 && (OH % TH) == 0 && (OW % TW) == 0 &&
+    if (!(R == 3 && S == 3 && stride == 1 && dil == 1 && (C == 32 || C == 64) && (K == 32 || K == 64 || K == 128) && (OH % TH) == 0 && (OW % TW) == 0 &&
           M * (long long)K < (1ll << 30)))
         return false;
-    return x3d_mode() >= 2 || (M / (TH * TW)) * (K / 64) >= 256;
+    return x3d_mode() >= 2 || (M / (TH * TW)) * (K == 32 ? 1 : K / 64) >= 256;
 }
 
 }  // namespace
@@ -409,11 +413,12 @@ int launch_x3_direct(const ConvArgs& a, int kind, bool flip_transpose, void* ws,
     }
     unsigned short* w3 = (unsigned short*)ws;
     const int cls = prof_class(kind);
+    const int KW = a.K == 32 ? 32 : 64;
     {
         const int total = 9 * a.C * a.K;
         PnpProfScope ps(cls, st, 0.0, 4.0 * total + 6.0 * total, "x3d_filter_kernel<%s>", flip_transpose ? "true" : "false");
-        if (flip_transpose) hipLaunchKernelGGL((x3d_filter_kernel<true>), dim3((unsigned)pnp_cdiv(total, 256)), dim3(256), 0, st, a.w, w3, a.C, a.K);
-        else hipLaunchKernelGGL((x3d_filter_kernel<false>), dim3((unsigned)pnp_cdiv(total, 256)), dim3(256), 0, st, a.w, w3, a.C, a.K);
+        if (flip_transpose) hipLaunchKernelGGL((x3d_filter_kernel<true>), dim3((unsigned)pnp_cdiv(total, 256)), dim3(256), 0, st, a.w, w3, a.C, a.K, KW);
+        else hipLaunchKernelGGL((x3d_filter_kernel<false>), dim3((unsigned)pnp_cdiv(total, 256)), dim3(256), 0, st, a.w, w3, a.C, a.K, KW);
         PNP_CHECK_LAUNCH("x3d_filter_kernel");
     }
     X3dArgs x{};
@@ -421,19 +426,21 @@ int launch_x3_direct(const ConvArgs& a, int kind, bool flip_transpose, void* ws,
     x.N = a.N; x.H = a.H; x.W = a.W; x.C = a.C; x.K = a.K; x.OH = a.OH; x.OW = a.OW; x.pad_t = a.pad_t; x.pad_l = a.pad_l; x.M = a.M;
     x.do_drop = a.do_drop; x.drop_thresh = a.drop_thresh; x.drop_key = a.drop_key; x.drop_keep = a.drop_keep; x.sp = a.sp; x.drop_sid = a.drop_sid;
     x.res_add = a.res_add; x.stat_ws = a.stat_ws; x.stat_shift = a.stat_shift;
-    const long long nitems = (long long)a.N * (a.OH / TH) * (a.OW / TW) * (a.K / 64);
+    const long long nitems = (long long)a.N * (a.OH / TH) * (a.OW / TW) * (a.K / KW);
     const dim3 grid((unsigned)(nitems > 256 ? 256 : nitems));
     // flops = the bf16 MFMA flops the kernel EXECUTES (six plane products per fp32 multiply-add): its roof is the dense bf16 peak
     const double fl = 6.0 * 2.0 * (double)a.M * 9.0 * a.C * a.K;
     const double by = 4.0 * ((double)a.N * a.H * a.W * a.C + (double)a.M * a.K) + 6.0 * 9.0 * a.C * a.K;
-    PnpProfScope ps(cls, st, fl, by, "conv_x3_direct_kernel<%d, %d>", a.C / 32, kind);
+    PnpProfScope ps(cls, st, fl, by, "conv_x3_direct_kernel<%d, %d, %d>", a.C / 32, KW, kind);
+#define X3D_LAUNCH(NH_, KW_, KIND_) hipLaunchKernelGGL((conv_x3_direct_kernel<NH_, KW_, KIND_>), grid, dim3(512), 0, st, x)
     if (a.C == 32) {
-        if (kind == 0) hipLaunchKernelGGL((conv_x3_direct_kernel<1, 0>), grid, dim3(512), 0, st, x);
-        else hipLaunchKernelGGL((conv_x3_direct_kernel<1, 1>), grid, dim3(512), 0, st, x);
+        if (KW == 32) { if (kind == 0) X3D_LAUNCH(1, 32, 0); else X3D_LAUNCH(1, 32, 1); }
+        else { if (kind == 0) X3D_LAUNCH(1, 64, 0); else X3D_LAUNCH(1, 64, 1); }
     } else {
-        if (kind == 0) hipLaunchKernelGGL((conv_x3_direct_kernel<2, 0>), grid, dim3(512), 0, st, x);
-        else hipLaunchKernelGGL((conv_x3_direct_kernel<2, 1>), grid, dim3(512), 0, st, x);
+        if (KW == 32) { if (kind == 0) X3D_LAUNCH(2, 32, 0); else X3D_LAUNCH(2, 32, 1); }
+        else { if (kind == 0) X3D_LAUNCH(2, 64, 0); else X3D_LAUNCH(2, 64, 1); }
     }
+#undef X3D_LAUNCH
     PNP_CHECK_LAUNCH("conv_x3_direct_kernel");
     return PNP_OK;
 }

@@ -14,15 +14,16 @@ from oracle import tf_ops as T
 
 pytestmark = pytest.mark.gpu
 
-# (N, H, W, C, K, padding): output extents are multiples of 16, 32 / 64 input channels, 64 / 128 filters
+# (N, H, W, C, K, padding): output extents are multiples of 16, 32 / 64 input channels, 32 / 64 / 128 filters
 CASES = [
     (2, 64, 64, 64, 64, "SAME"),          # critic cls_1's 64 -> 64 (at 256^2 in the model)
-    (3, 32, 48, 64, 128, "SAME"),         # cls_2's 64 -> 128: two filter blocks per tile; its data gradient is 128 -> 64 (not taken: C = 128)
+    (3, 32, 48, 64, 128, "SAME"),         # cls_2's 64 -> 128: two filter blocks per tile; its data gradient is 128 -> 64 (not taken: 128 input channels)
     (2, 32, 32, 32, 64, "SAME"),          # one channel half per tile (the patch buffer alternates with the item)
     (1, 34, 50, 64, 64, "VALID"),         # a mirror-padded input run as VALID (padding 0): the forward is taken (32 x 48 outputs), its data
                                           # gradient (34 x 50 outputs) is not
     (1, 32, 48, 64, 64, "VALID"),         # ... and the other way round: a data gradient with padding 2
     (5, 16, 16, 32, 128, "SAME"),         # fewer items than workgroups on most of the chip: 10 items
+    (2, 32, 48, 64, 32, "SAME"),          # 32 filters: 32-filter blocks (the data gradient of a 32 -> 64 layer is this shape)
 ]
 BAR = 5e-6
 
@@ -74,14 +75,14 @@ def test_direct_split_bf16_fwd_dgrad_vs_float64(dev, route, case):
     y1, names1 = _ran(L, lambda: K.conv2d_fwd(xd, wd, g), L.PROF_CONV_FWD)
     taken_f = g.OH % 16 == 0 and g.OW % 16 == 0
     if taken_f:
-        assert names1 == sorted(["x3d_filter_kernel<false>", "conv_x3_direct_kernel<%d, 0>" % (C // 32)]), names1
+        assert names1 == sorted(["x3d_filter_kernel<false>", "conv_x3_direct_kernel<%d, %d, 0>" % (C // 32, 32 if Kf == 32 else 64)]), names1
     else:
         assert not any("x3_direct" in n for n in names1), names1
     dx1, names2 = _ran(L, lambda: K.conv2d_dgrad(dyd, wd, g), L.PROF_CONV_DGRAD)
     # (the data gradient is a convolution of dy: Kf input channels, C filters, H x W outputs — taken when THOSE fit)
-    taken_d = Kf in (32, 64) and C in (64, 128) and H % 16 == 0 and W % 16 == 0
+    taken_d = Kf in (32, 64) and C in (32, 64, 128) and H % 16 == 0 and W % 16 == 0
     if taken_d:
-        assert names2 == sorted(["x3d_filter_kernel<true>", "conv_x3_direct_kernel<%d, 1>" % (Kf // 32)]), names2
+        assert names2 == sorted(["x3d_filter_kernel<true>", "conv_x3_direct_kernel<%d, %d, 1>" % (Kf // 32, 32 if C == 32 else 64)]), names2
     else:
         assert not any("x3_direct" in n for n in names2), names2
     dxr = K.conv2d_dgrad(dyd, wd, g, residual=resd)
