@@ -500,19 +500,21 @@ def main():
 
     # The headline's Winograd GEMMs run on split-bf16 operands (csrc/conv_wino_x3.hip: every fp32 value as three bf16 planes, six products,
     # fp32 accumulation in 64-channel chunks — fp32 results, measured CLOSER to float64 than the fp32 matrix pipe's: DESIGN.md §2).  The
-    # same step with every GEMM on the native fp32 MFMA pipe (PNP_WINOGRAD_X3=0, round 5's arithmetic) stays selectable and is reported
+    # same step with every GEMM on the native fp32 MFMA pipe (PNP_WINOGRAD_X3=0 PNP_X3_DIRECT=0, round 5's arithmetic) stays selectable and is reported
     # beside the headline: 2 warm-up + 8 timed steps
     sub_fp32 = None
     if not args.no_sub and args.dtype == "f32" and world == 1 and K.wino_x3(-1) != 0:
         prev_x3 = K.wino_x3(0)
+        prev_x3d = K.x3_direct(0)        # (and the narrow layers back on the fp32-pipe routes: nothing of this sub-run touches the bf16 pipe)
         try:
             K.weights_changed()
             nf = 8
             el4, loss4 = timed_loop(makers[args.workload](), 2, nf, world, dev, None)
-            sub_fp32 = {"workload": "the headline step with the Winograd GEMMs on the fp32 matrix pipe (PNP_WINOGRAD_X3=0)", "value": world * B * nf / el4,
+            sub_fp32 = {"workload": "the headline step with every convolution on the fp32 matrix pipe (PNP_WINOGRAD_X3=0 PNP_X3_DIRECT=0)", "value": world * B * nf / el4,
                         "unit": "slices/s", "ms_per_step": 1e3 * el4 / nf, "steps": nf, "warmup": 2, "final_loss": loss4}
         finally:
             K.wino_x3(prev_x3)
+            K.x3_direct(prev_x3d)
             K.weights_changed()
 
     # BASELINE configs[4] arithmetic (bf16 MFMA operands, fp32 accumulation / master weights / BN) on the headline workload, as a

@@ -27,6 +27,8 @@ timeout 300 python tools/bench_conv.py > $O/conv_layers_f32.txt 2>/dev/null
 PROF=1 ONLY="g5/6,g7,g8,g10,cls2 128,cls3 256,cls5" timeout 200 python tools/bench_conv.py 2>/dev/null > $O/per_kernel_layers.txt
 # the route's GEMMs on the fp32 matrix pipe (X3=0) and on split-bf16 operands (X3=1: planner; X3=2: wherever the shapes allow), per kernel
 for x3 in 0 1 2; do echo "== X3=$x3 (pnp_conv2d_wino_x3)"; X3=$x3 PROF=1 ONLY="g4 128,g5,g7,g8,g10,cls1 64,cls2 64,cls2 128,cls3 128,cls3 256,cls5" WINO=1 WINO_WGRAD=1 TILE=4 timeout 300 python tools/bench_conv.py 2>/dev/null; done > $O/x3_layers_B16.txt
+# the narrow layers with the direct split-bf16 route off / on (conv_x3_direct.hip)
+for v in 0 1; do echo "== PNP_X3_DIRECT=$v"; PNP_X3_DIRECT=$v PROF=1 ONLY="g2 32,g3,cls1 32,cls1 64,cls2 64" timeout 300 python tools/bench_conv.py 2>/dev/null; done > $O/x3_direct_layers_B16.txt
 timeout 400 python -m pytest tests/test_gpu_trajectory.py -q -m gpu -s -p no:cacheprovider 2>&1 | grep -vE "amdgpu.ids|^make" > $O/trajectory.log
 pmc() { local d=$1 o=$2 s=$3 rx=$4; shift 4; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
   timeout -k 10 $s rocprofv3 --pmc "${ctr[@]}" --kernel-trace --kernel-include-regex "$rx" --output-format csv -d $d -o $o -- "$@" > $d.log 2>&1; echo "PMC pass $d rc=$?"; }

@@ -2,8 +2,8 @@
 // would it beat the Winograd F(4x4) fp32-pipe route on the narrow, large-map layers (cls1 64->64 @ 256^2, B = 16: 0.59 ms forward,
 // traffic-bound on the 2.25x transformed tensors)?  Standalone: synthetic data, checked against a float64-accumulating kernel, timed with
 // HIP events, with ablation instances.  ANSWER (tools/experiments/README.md, round 6): yes — 0.37 ms (209 TF/s fp32-equivalent, 1.33 x the
-// fp32 MFMA peak; Winograd route 0.593 ms), 8.0e-7 of max|ref| (the direct fp32 kernel: 2.9e-6, the F(4x4) routes 1.2e-6 .. 8e-6).  Not in
-// the library: a prototype of "what comes next" (DESIGN.md section 10).
+// fp32 MFMA peak; Winograd route 0.593 ms), 8.0e-7 of max|ref| (the direct fp32 kernel: 2.9e-6, the F(4x4) routes 1.2e-6 .. 8e-6).  The
+// library version is csrc/conv_x3_direct.hip; this file keeps the ablation instances.
 //   * input x [N][H][W][64] fp32: a 16 x 16 output tile's 18 x 18 x 32-channel halo patch is loaded ONCE per channel half by three
 //     loader waves (global -> VGPR -> split into three bf16 planes whose sum is the fp32 value -> LDS, the split spread over five stages),
 //     double-buffered across halves: every input value crosses L2 -> CU once per tile (1.27 x the tensor), not once per tap;
