@@ -117,14 +117,17 @@ def test_every_kernel_of_every_adaptation_unit_teacher_forced_B16(dev):
     V32, _, o32, gen32 = _gen_units(sd, ct, torch.float32, 22, units=False)
     g32 = {k: v.grad.clone() for k, v in V32.items() if v.requires_grad}
     # the product three times: the default route (F(4x4, 3x3) where its planner takes a layer, split-bf16 GEMMs with chunked accumulation
-    # on the reductions over >= 256 channels: round 6), F(4x4) with every GEMM on the fp32 matrix pipe (round 5's default), and F(2x2) only
+    # on the reductions over >= 256 channels, direct split-bf16 convolutions of the 32- / 64-channel layers: round 6), F(4x4) with every GEMM on the fp32 matrix pipe (round 5's default), and F(2x2) only
     K = pkg("kernels")
-    prev_tile, prev_x3 = K.wino_tile(-1), K.wino_x3(-1)
+    prev_tile, prev_x3, prev_x3d = K.wino_tile(-1), K.wino_x3(-1), K.x3_direct(-1)
     stats = {}
     try:
         for tile, x3 in ((4, 1), (4, 0), (2, 0)):
             K.wino_tile(tile)
             K.wino_x3(x3)
+            # the direct split-bf16 convolutions of the narrow layers (csrc/conv_x3_direct.hip) belong to the default; the two older
+            # configurations are measured in THEIR arithmetic (every convolution on the fp32 matrix pipe)
+            K.x3_direct(prev_x3d if x3 else 0)
             net.store.load_state_dict(sd)
             loss = net.gen_loss_and_grads(torch.from_numpy(ct).to(dev), KEEP, drop_seed=22)
             g_hip = {v.name: v.tensor.grad.detach().cpu().clone() for v in net.store.trainable() if v.name.startswith("adapt_")}
@@ -138,6 +141,7 @@ def test_every_kernel_of_every_adaptation_unit_teacher_forced_B16(dev):
     finally:
         K.wino_tile(prev_tile)
         K.wino_x3(prev_x3)
+        K.x3_direct(prev_x3d)
     for (tile, x3), (lossv, elog, eh, ec, cmin) in stats.items():
         assert elog < 1e-4
         # (the loss is a 0.002-weighted mean of critic scores that nearly cancel: float32 evaluation noise on it is ~3e-4 relative — measured

@@ -4,7 +4,7 @@ The reference's only validation is watching its loss / Dice curves (/root/refere
 Per-kernel parity says every launch is within 1e-6..1e-5 of float64; this file says what that does to a RUN: the segmenter trained for
 150 Adam steps and the adaptation phase for 20 joint iterations (1 discriminator + 1 generator update each) on synthetic blob slices,
 from the same weights, batches and dropout seeds, once per arithmetic
-    default            F(4x4, 3x3) with split-bf16 chunked GEMMs on the deep reductions (round 6)
+    default            F(4x4, 3x3) with split-bf16 chunked GEMMs on the deep reductions, direct split-bf16 convolutions of the narrow layers (round 6)
     F(4x4) fp32 pipe   round 5's default (PNP_WINOGRAD_X3=0)
     F(2x2)             round 4's route
     direct             no Winograd route at all
@@ -25,7 +25,9 @@ from conftest import pkg
 
 pytestmark = pytest.mark.gpu
 
-ARITH = {"default": (1, 4, 1), "F(4x4) fp32 pipe": (1, 4, 0), "F(2x2)": (1, 2, 0), "direct": (0, 4, 0)}       # (route mode, tile, x3)
+# (route mode, tile, x3, x3_direct): only the default uses the bf16 matrix pipe (split operands: the route's deep GEMMs and the direct
+# convolutions of the narrow layers); the other three run every convolution on the fp32 matrix pipe
+ARITH = {"default": (1, 4, 1, 1), "F(4x4) fp32 pipe": (1, 4, 0, 0), "F(2x2)": (1, 2, 0, 0), "direct": (0, 4, 0, 0)}
 
 
 def _slices(n, seed):
@@ -46,12 +48,12 @@ class _Modes:
 
     def __enter__(self):
         K = self.K
-        self.prev = (K.wino_mode(-1), K.wino_wgrad_mode(-1), K.wino_tile(-1), K.wino_x3(-1))
-        K.wino_mode(self.want[0]); K.wino_wgrad_mode(self.want[0]); K.wino_tile(self.want[1]); K.wino_x3(self.want[2])
+        self.prev = (K.wino_mode(-1), K.wino_wgrad_mode(-1), K.wino_tile(-1), K.wino_x3(-1), K.x3_direct(-1))
+        K.wino_mode(self.want[0]); K.wino_wgrad_mode(self.want[0]); K.wino_tile(self.want[1]); K.wino_x3(self.want[2]); K.x3_direct(self.want[3])
 
     def __exit__(self, *a):
         K = self.K
-        K.wino_mode(self.prev[0]); K.wino_wgrad_mode(self.prev[1]); K.wino_tile(self.prev[2]); K.wino_x3(self.prev[3])
+        K.wino_mode(self.prev[0]); K.wino_wgrad_mode(self.prev[1]); K.wino_tile(self.prev[2]); K.wino_x3(self.prev[3]); K.x3_direct(self.prev[4])
         K.wino_u_cache_clear()
 
 
