@@ -85,8 +85,9 @@ def workspace_canary(request):
 # adjudication alone: 250 vs 347 s), not GPU time; the guard moved to 1050 s so that a slow host fails here, loudly, before the driver's
 # 1200 s limit ends the run silently.
 # Round 6: 785 s mid-round (x3 variants, trajectory tests), 625 s once the teacher-forced walks compared in float64 on the device instead of
-# on the host (tests/parity_util.py::rel) — the guard is back at round 4's 900 s (625 s x the 1.23 box-to-box spread above = 770 s).
-GPU_SUITE_BUDGET_S = float(os.environ.get("PNP_GPU_SUITE_BUDGET_S", "900"))
+# on the host (tests/parity_util.py::rel); 622 / 694 s on two boxes with the direct split-bf16 route's tests added.  The guard: 1000 s
+# (694 s x the 1.23 box-to-box spread above = 854 s; the driver's limit is 1200 s).
+GPU_SUITE_BUDGET_S = float(os.environ.get("PNP_GPU_SUITE_BUDGET_S", "1000"))
 _suite = {"t0": None, "gpu_tests": 0}
 
 
